@@ -1,0 +1,186 @@
+// Multi-head self-attention of the ViT tower (K4 of SURVEY.md §2.2): per (crop, head)
+//   O = softmax(Q K^T / sqrt(64)) V,  no mask, n_tok <= 32*NKT keys, head dim 64.
+// This is the nn.MultiheadAttention step of the open_clip forward the reference reaches through
+// /root/reference/utils/embedder.py:98.
+//
+// One workgroup (4 waves) per (crop, head).  K and V of that head are staged once into LDS
+// (rows of 128 B, 16-B chunks XOR-swizzled so that the row-wise K reads (ds_read_b128) and the
+// transposed V reads (ds_read_b64_tr_b16) are bank-conflict free).  Each wave owns 32-query blocks.
+// Scores are computed TRANSPOSED, S^T = K . Q^T with the 32x32x16 MFMA, so a lane holds one query
+// column: the softmax row reductions are lane-local (plus one exchange with lane^32), and the S^T
+// accumulator registers feed the P.V MFMA directly as its B operand (guide §3 "An accumulator tile
+// as the next MFMA's operand"); V^T comes from the hardware-transposing LDS read.
+// The whole key range fits the register file (<= 9 tiles x 16 fp32), so the softmax is exact
+// two-pass (true row max), not an online rescale.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ int k_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+__device__ __forceinline__ int v_swz(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
+
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                      int n_tok, int width, int heads, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = NKT * 32;
+  char* Ks = smem;
+  char* Vs = smem + ROWS * 128;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int crop = blockIdx.x / heads, head = blockIdx.x % heads;
+  const size_t ld = (size_t)3 * width;                         // qkv row stride (elements)
+  const bf16_t* base = qkv + (size_t)crop * n_tok * ld + head * 64;
+
+  // ---- stage K, V (zero rows beyond n_tok) ----
+  for (int idx = tid; idx < ROWS * 8; idx += 256) {
+    const int row = idx >> 3, c = idx & 7;
+    uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+    if (row < n_tok) {
+      const bf16_t* g = base + (size_t)row * ld + c * 8;
+      kv = *(const uint4*)(g + width);
+      vv = *(const uint4*)(g + 2 * width);
+    }
+    *(uint4*)(Ks + k_swz(row, c)) = kv;
+    *(uint4*)(Vs + v_swz(row, c)) = vv;
+  }
+  __syncthreads();
+
+  const int r = lane & 31, h = lane >> 5;
+  const int n_qb = (n_tok + 31) >> 5;
+  for (int qb = wave; qb < n_qb; qb += 4) {
+    // ---- Q fragments straight from global: lane (r,h) holds Q[q0+r][16*step + 8h .. +7] ----
+    const int q = qb * 32 + r;
+    const bf16_t* qrow = base + (size_t)min(q, n_tok - 1) * ld;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qrow + st * 16 + h * 8);
+
+    // ---- S^T tiles: s[kt][reg] = <K[32kt + krow(reg,h)], Q[q]> ----
+    f32x16_t s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        bf16x8_t kf = *(const bf16x8_t*)(Ks + k_swz(kt * 32 + r, st * 2 + h));
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kt], 0, 0, 0);
+      }
+    }
+    // ---- mask padded keys, row max ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (kt == NKT - 1) {                                   // only the last key tile can be partial
+          const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= n_tok) s[kt][e] = -INFINITY;
+        }
+        mx = fmaxf(mx, s[kt][e]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float moff = mx * scale_log2e;
+
+    // ---- P = exp2(s*c - m*c), row sum, and O^T += V^T . P^T ----
+    f32x16_t o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          if (kt < NKT - 1 || s2 == 0 || kt * 32 + 16 < n_tok) {   // wave-uniform; skips an all-padding k-step
+            bf16x8_t pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][s2 * 8 + j], scale_log2e, -moff));
+              const __bf16 pb = (__bf16)pv;
+              lsum += (float)pb;                               // normaliser of the ROUNDED weights
+              pf[j] = pb;
+            }
+            // element j of lane half h is key 16*s2 + 8*(j>>2) + 4h + (j&3) of the tile
+            const int key0 = kt * 32 + s2 * 16 + 4 * h;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+              // transposed read: 16-lane group g reads keys key0.. (+8), d columns dt*32 + 16*(g&1) ..
+              const int i = lane & 15, qq = i >> 2, pp = i & 3, g1 = (lane >> 4) & 1;
+              const int dcol = dt * 32 + g1 * 16 + pp * 4;      // 4 contiguous d of one key row
+              const int ra = key0 + qq, rb = key0 + 8 + qq;
+              s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(ra, dcol >> 3) + (dcol & 7) * 2));
+              s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                  (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(rb, dcol >> 3) + (dcol & 7) * 2));
+              typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+              s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+              o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, o[dt], 0, 0, 0);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    lsum += __shfl_xor(lsum, 32);
+    const float inv = 1.0f / lsum;
+
+    // ---- store O[q][head*64 + d]: reg group g4 holds d = dt*32 + 8*g4 + 4h + (0..3) ----
+    if (q < n_tok) {
+      bf16_t* orow = out + ((size_t)crop * n_tok + q) * width + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          uint2 pk = {pack_bf16x2(o[dt][g4 * 4 + 0] * inv, o[dt][g4 * 4 + 1] * inv),
+                      pack_bf16x2(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv)};
+          *(uint2*)(orow + dt * 32 + g4 * 8 + h * 4) = pk;
+        }
+    }
+  }
+}
+
+template <int NKT>
+hipError_t launch_attn(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
+                       hipStream_t stream) {
+  const int lds = NKT * 32 * 128 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const float scale_log2e = 0.125f * 1.44269504088896340736f;   // 64^-0.5 * log2(e)
+  hipLaunchKernelGGL((attn_kernel<NKT>), dim3(n_crops * heads), dim3(256), lds, stream, qkv, out, n_tok, width,
+                     heads, scale_log2e);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// qkv: [n_crops*n_tok][3*width] bf16 ([q|k|v], head = 64-wide slice); out: [n_crops*n_tok][width] bf16
+hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int width, int heads,
+                        hipStream_t stream) {
+  if (width != heads * 64 || n_tok < 1 || n_crops < 1) return hipErrorInvalidValue;
+  const int nkt = (n_tok + 31) / 32;
+  const bf16_t* q = (const bf16_t*)qkv;
+  bf16_t* o = (bf16_t*)out;
+  switch (nkt) {                 // NKT must equal ceil(n_tok/32): only the last key tile is masked
+    case 1: return launch_attn<1>(q, o, n_crops, n_tok, width, heads, stream);
+    case 2: return launch_attn<2>(q, o, n_crops, n_tok, width, heads, stream);
+    case 3: return launch_attn<3>(q, o, n_crops, n_tok, width, heads, stream);
+    case 4: return launch_attn<4>(q, o, n_crops, n_tok, width, heads, stream);
+    case 5: return launch_attn<5>(q, o, n_crops, n_tok, width, heads, stream);
+    case 6: return launch_attn<6>(q, o, n_crops, n_tok, width, heads, stream);
+    case 7: return launch_attn<7>(q, o, n_crops, n_tok, width, heads, stream);
+    case 8: return launch_attn<8>(q, o, n_crops, n_tok, width, heads, stream);
+    case 9: return launch_attn<9>(q, o, n_crops, n_tok, width, heads, stream);
+    default: return hipErrorInvalidValue;   // > 288 tokens (ViT-L-14-336): not built yet
+  }
+}

@@ -1,0 +1,456 @@
+// C ABI of libclipenc_hip.so (see include/clipenc.h): handle management, weight preparation
+// (bf16 conversion + LayerNorm folding), workspace, and the kernel chain of the ViT tower.
+#include "../../include/clipenc.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "common.h"
+#include "gemm.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return 1;
+}
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  hipError_t alloc(size_t n) {
+    release();
+    hipError_t e = hipMalloc(&p, n ? n : 16);
+    if (e == hipSuccess) bytes = n;
+    return e;
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+};
+
+template <typename F>
+void parallel_for(int n, F f) {
+  int nt = (int)std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+  nt = std::min(nt, n);
+  if (nt <= 1) { for (int i = 0; i < n; ++i) f(i); return; }
+  std::vector<std::thread> th;
+  for (int t = 0; t < nt; ++t) th.emplace_back([=] { for (int i = t; i < n; i += nt) f(i); });
+  for (auto& t : th) t.join();
+}
+
+struct LayerDev {
+  bf16_t *w_qkv, *w_out, *w_fc, *w_proj;                 // bf16 [N][K]
+  float *cs_qkv, *b_qkv, *b_out, *cs_fc, *b_fc, *b_proj;
+};
+
+}  // namespace
+
+struct clipenc_s {
+  clipenc_config cfg;
+  int device = 0;
+  int tokens = 0, kpad = 0;
+  DevBuf weights;                                        // one slab
+  bf16_t* w_conv = nullptr;                              // [width][kpad]
+  float *cls = nullptr, *pos = nullptr, *ln_pre_w = nullptr, *ln_pre_b = nullptr;
+  float *ln_post_w = nullptr, *ln_post_b = nullptr, *proj = nullptr;
+  std::vector<LayerDev> layers;
+  // workspace (sized for `chunk` crops)
+  int chunk = 2048, ws_chunk = 0;
+  DevBuf ws;
+  bf16_t *a_patch = nullptr, *pe = nullptr, *x = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr;
+  float *stats0 = nullptr, *stats_a = nullptr, *stats_b = nullptr;
+};
+
+struct fcreg_s {
+  int device = 0;
+  int n_layers = 0;
+  int sizes[CE_FC_MAX_LAYERS + 1];
+  float negative_slope = 0.01f;
+  DevBuf slab;
+  const float* Wt[CE_FC_MAX_LAYERS];
+  const float* b[CE_FC_MAX_LAYERS];
+};
+
+namespace {
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int ensure_workspace(clipenc_s* e, int n_crops) {
+  const int c = std::min(n_crops, e->chunk);
+  if (c <= e->ws_chunk) return 0;
+  const clipenc_config& g = e->cfg;
+  const size_t T = (size_t)c * e->tokens, P = (size_t)c * (e->tokens - 1);
+  const size_t parts = g.width / 256;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  const size_t o_ap = take(P * e->kpad * 2), o_pe = take(P * g.width * 2), o_x = take(T * g.width * 2);
+  const size_t o_qkv = take(T * 3 * g.width * 2), o_at = take(T * g.width * 2), o_h = take(T * g.mlp_dim * 2);
+  const size_t o_s0 = take(T * 8), o_sa = take(parts * T * 8), o_sb = take(parts * T * 8);
+  HIP_TRY(hipSetDevice(e->device));
+  HIP_TRY(e->ws.alloc(off));
+  char* b = (char*)e->ws.p;
+  e->a_patch = (bf16_t*)(b + o_ap); e->pe = (bf16_t*)(b + o_pe); e->x = (bf16_t*)(b + o_x);
+  e->qkv = (bf16_t*)(b + o_qkv); e->attn = (bf16_t*)(b + o_at); e->hid = (bf16_t*)(b + o_h);
+  e->stats0 = (float*)(b + o_s0); e->stats_a = (float*)(b + o_sa); e->stats_b = (float*)(b + o_sb);
+  e->ws_chunk = c;
+  return 0;
+}
+
+// runs patch-embed + ln_pre + `n_layers` blocks on `c` crops; leaves the residual stream in e->x
+int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers, hipStream_t st) {
+  const clipenc_config& g = e->cfg;
+  const int T = c * e->tokens, P = c * (e->tokens - 1);
+  const int parts = g.width / 256;
+  HIP_TRY(ce_patchify(crops, in_dtype, e->a_patch, c, g.image_size, g.patch, e->kpad, st));
+  GemmParams p{};
+  p.A = e->a_patch; p.lda = e->kpad; p.W = e->w_conv; p.ldw = e->kpad; p.M = P; p.N = g.width; p.K = e->kpad;
+  p.out = e->pe; p.ldo = g.width; p.bias = nullptr;
+  HIP_TRY(ce_gemm_nt(p, CE_DT_BF16, EPI_STORE_BF16, st));
+  HIP_TRY(ce_embed_ln_pre(e->pe, e->cls, e->pos, e->ln_pre_w, e->ln_pre_b, e->x, e->stats0, c, e->tokens, g.width,
+                          g.ln_eps, st));
+  const float* stats_in = e->stats0;
+  int stats_parts = 1;
+  for (int l = 0; l < n_layers; ++l) {
+    const LayerDev& L = e->layers[l];
+    // K3: qkv = LN1(x) . Wqkv^T + b   (LayerNorm folded into the GEMM epilogue)
+    GemmParams q{};
+    q.A = e->x; q.lda = g.width; q.W = L.w_qkv; q.ldw = g.width; q.M = T; q.N = 3 * g.width; q.K = g.width;
+    q.out = e->qkv; q.ldo = 3 * g.width; q.bias = L.b_qkv; q.colsum = L.cs_qkv;
+    q.stats_in = stats_in; q.stats_in_parts = stats_parts; q.inv_width = 1.0f / g.width; q.eps = g.ln_eps; q.act = -1;
+    HIP_TRY(ce_gemm_nt(q, CE_DT_BF16, EPI_LNFOLD, st));
+    // K4
+    HIP_TRY(ce_attention(e->qkv, e->attn, c, e->tokens, g.width, g.heads, st));
+    // K5: x += attn . Wo^T + bo
+    GemmParams o{};
+    o.A = e->attn; o.lda = g.width; o.W = L.w_out; o.ldw = g.width; o.M = T; o.N = g.width; o.K = g.width;
+    o.out = e->x; o.ldo = g.width; o.bias = L.b_out; o.resid = e->x; o.stats_out = e->stats_a;
+    HIP_TRY(ce_gemm_nt(o, CE_DT_BF16, EPI_RESID, st));
+    // K6: h = act(LN2(x) . Wfc^T + b)
+    GemmParams f{};
+    f.A = e->x; f.lda = g.width; f.W = L.w_fc; f.ldw = g.width; f.M = T; f.N = g.mlp_dim; f.K = g.width;
+    f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
+    f.stats_in = e->stats_a; f.stats_in_parts = parts; f.inv_width = 1.0f / g.width; f.eps = g.ln_eps; f.act = g.act;
+    HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
+    // K7: x += h . Wproj^T + b
+    GemmParams r{};
+    r.A = e->hid; r.lda = g.mlp_dim; r.W = L.w_proj; r.ldw = g.mlp_dim; r.M = T; r.N = g.width; r.K = g.mlp_dim;
+    r.out = e->x; r.ldo = g.width; r.bias = L.b_proj; r.resid = e->x; r.stats_out = e->stats_b;
+    HIP_TRY(ce_gemm_nt(r, CE_DT_BF16, EPI_RESID, st));
+    stats_in = e->stats_b; stats_parts = parts;
+  }
+  return 0;
+}
+
+size_t crop_bytes(const clipenc_config& g, int in_dtype) {
+  return (size_t)3 * g.image_size * g.image_size * (in_dtype == CLIPENC_IN_F32 ? 4 : 2);
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* clipenc_last_error(void) { return g_err.c_str(); }
+
+int clipenc_device_count(int* count) {
+  if (!count) return fail("count is NULL");
+  HIP_TRY(hipGetDeviceCount(count));
+  return 0;
+}
+
+int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int device, clipenc_t* out) {
+  if (!cfg || !w || !out) return fail("clipenc_create: NULL argument");
+  const clipenc_config g = *cfg;
+  if (g.width <= 0 || g.width % 256 != 0) return fail("width %d must be a positive multiple of 256", g.width);
+  if (g.mlp_dim <= 0 || g.mlp_dim % 256 != 0) return fail("mlp_dim %d must be a positive multiple of 256", g.mlp_dim);
+  if (g.heads * 64 != g.width) return fail("only head dim 64 is built (width %d, heads %d)", g.width, g.heads);
+  if (g.patch <= 0 || g.image_size % g.patch != 0) return fail("image_size %d not divisible by patch %d", g.image_size, g.patch);
+  if (g.embed_dim <= 0 || g.embed_dim > 1024) return fail("embed_dim %d out of range (1..1024)", g.embed_dim);
+  if (g.width > 2048) return fail("width %d > 2048 not built", g.width);
+  if (g.layers < 1) return fail("layers %d < 1", g.layers);
+  if (g.act != CLIPENC_ACT_QUICK_GELU && g.act != CLIPENC_ACT_GELU_ERF) return fail("unknown activation %d", g.act);
+  const int grid = g.image_size / g.patch, tokens = grid * grid + 1;
+  if (tokens > 288) return fail("%d tokens > 288: the long-sequence attention variant is not built yet", tokens);
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail("device %d out of range (%d visible)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  clipenc_s* e = new clipenc_s();
+  e->cfg = g; e->device = device; e->tokens = tokens;
+  const int kreal = 3 * g.patch * g.patch;
+  e->kpad = (int)align_up(kreal, 128);
+  const int D = g.width, M = g.mlp_dim, L = g.layers, E = g.embed_dim;
+
+  // ---- host staging slab (bf16 weights with LayerNorm gamma folded in; fp32 vectors) ----
+  size_t off = 0;
+  auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+  const size_t o_conv = take((size_t)D * e->kpad * 2);
+  const size_t o_cls = take(D * 4), o_pos = take((size_t)tokens * D * 4);
+  const size_t o_lpw = take(D * 4), o_lpb = take(D * 4), o_low = take(D * 4), o_lob = take(D * 4);
+  const size_t o_proj = take((size_t)D * E * 4);
+  struct LOff { size_t w_qkv, w_out, w_fc, w_proj, cs_qkv, b_qkv, b_out, cs_fc, b_fc, b_proj; };
+  std::vector<LOff> lo(L);
+  for (int l = 0; l < L; ++l) {
+    lo[l].w_qkv = take((size_t)3 * D * D * 2); lo[l].w_out = take((size_t)D * D * 2);
+    lo[l].w_fc = take((size_t)M * D * 2); lo[l].w_proj = take((size_t)D * M * 2);
+    lo[l].cs_qkv = take(3 * D * 4); lo[l].b_qkv = take(3 * D * 4); lo[l].b_out = take(D * 4);
+    lo[l].cs_fc = take(M * 4); lo[l].b_fc = take(M * 4); lo[l].b_proj = take(D * 4);
+  }
+  std::vector<char> host(off);
+  char* hb = host.data();
+  {
+    bf16_t* wc = (bf16_t*)(hb + o_conv);
+    for (int n = 0; n < D; ++n)
+      for (int k = 0; k < e->kpad; ++k)
+        wc[(size_t)n * e->kpad + k] = k < kreal ? host_f32_to_bf16(w->conv1_weight[(size_t)n * kreal + k]) : 0;
+    memcpy(hb + o_cls, w->class_embedding, D * 4);
+    memcpy(hb + o_pos, w->positional_embedding, (size_t)tokens * D * 4);
+    memcpy(hb + o_lpw, w->ln_pre_w, D * 4); memcpy(hb + o_lpb, w->ln_pre_b, D * 4);
+    memcpy(hb + o_low, w->ln_post_w, D * 4); memcpy(hb + o_lob, w->ln_post_b, D * 4);
+    memcpy(hb + o_proj, w->proj, (size_t)D * E * 4);
+  }
+  // LayerNorm folding:  LN(x).W^T + b = rstd*(x.(g*W)^T - mean*colsum) + (b + W.beta)
+  auto fold = [&](const float* W, const float* b, const float* gamma, const float* beta, int N, int K, bf16_t* Wq,
+                  float* colsum, float* bias) {
+    parallel_for(N, [=](int n) {
+      double cs = 0.0, bb = 0.0;
+      for (int k = 0; k < K; ++k) {
+        const float wv = W[(size_t)n * K + k];
+        const bf16_t q = host_f32_to_bf16(wv * gamma[k]);
+        Wq[(size_t)n * K + k] = q;
+        cs += (double)host_bf16_to_f32(q);
+        bb += (double)wv * (double)beta[k];
+      }
+      colsum[n] = (float)cs;
+      bias[n] = (float)((double)b[n] + bb);
+    });
+  };
+  auto plain = [&](const float* W, int N, int K, bf16_t* Wq) {
+    parallel_for(N, [=](int n) {
+      for (int k = 0; k < K; ++k) Wq[(size_t)n * K + k] = host_f32_to_bf16(W[(size_t)n * K + k]);
+    });
+  };
+  for (int l = 0; l < L; ++l) {
+    fold(w->in_proj_w[l], w->in_proj_b[l], w->ln_1_w[l], w->ln_1_b[l], 3 * D, D, (bf16_t*)(hb + lo[l].w_qkv),
+         (float*)(hb + lo[l].cs_qkv), (float*)(hb + lo[l].b_qkv));
+    plain(w->out_proj_w[l], D, D, (bf16_t*)(hb + lo[l].w_out));
+    memcpy(hb + lo[l].b_out, w->out_proj_b[l], D * 4);
+    fold(w->c_fc_w[l], w->c_fc_b[l], w->ln_2_w[l], w->ln_2_b[l], M, D, (bf16_t*)(hb + lo[l].w_fc),
+         (float*)(hb + lo[l].cs_fc), (float*)(hb + lo[l].b_fc));
+    plain(w->c_proj_w[l], D, M, (bf16_t*)(hb + lo[l].w_proj));
+    memcpy(hb + lo[l].b_proj, w->c_proj_b[l], D * 4);
+  }
+  hipError_t err = e->weights.alloc(off);
+  if (err == hipSuccess) err = hipMemcpy(e->weights.p, hb, off, hipMemcpyHostToDevice);
+  if (err != hipSuccess) { e->weights.release(); delete e; return fail("weight upload failed: %s", hipGetErrorString(err)); }
+  char* db = (char*)e->weights.p;
+  e->w_conv = (bf16_t*)(db + o_conv); e->cls = (float*)(db + o_cls); e->pos = (float*)(db + o_pos);
+  e->ln_pre_w = (float*)(db + o_lpw); e->ln_pre_b = (float*)(db + o_lpb);
+  e->ln_post_w = (float*)(db + o_low); e->ln_post_b = (float*)(db + o_lob); e->proj = (float*)(db + o_proj);
+  e->layers.resize(L);
+  for (int l = 0; l < L; ++l) {
+    LayerDev& d = e->layers[l];
+    d.w_qkv = (bf16_t*)(db + lo[l].w_qkv); d.w_out = (bf16_t*)(db + lo[l].w_out);
+    d.w_fc = (bf16_t*)(db + lo[l].w_fc); d.w_proj = (bf16_t*)(db + lo[l].w_proj);
+    d.cs_qkv = (float*)(db + lo[l].cs_qkv); d.b_qkv = (float*)(db + lo[l].b_qkv); d.b_out = (float*)(db + lo[l].b_out);
+    d.cs_fc = (float*)(db + lo[l].cs_fc); d.b_fc = (float*)(db + lo[l].b_fc); d.b_proj = (float*)(db + lo[l].b_proj);
+  }
+  *out = e;
+  return 0;
+}
+
+int clipenc_destroy(clipenc_t e) {
+  if (!e) return 0;
+  (void)hipSetDevice(e->device);
+  e->weights.release();
+  e->ws.release();
+  delete e;
+  return 0;
+}
+
+int clipenc_set_chunk(clipenc_t e, int chunk_crops) {
+  if (!e) return fail("NULL handle");
+  if (chunk_crops < 1) return fail("chunk_crops %d < 1", chunk_crops);
+  e->chunk = chunk_crops;
+  return 0;
+}
+
+int clipenc_get_info(clipenc_t e, int* tokens, int* embed_dim, int* chunk_crops, size_t* workspace_bytes) {
+  if (!e) return fail("NULL handle");
+  if (tokens) *tokens = e->tokens;
+  if (embed_dim) *embed_dim = e->cfg.embed_dim;
+  if (chunk_crops) *chunk_crops = e->chunk;
+  if (workspace_bytes) *workspace_bytes = e->ws.bytes;
+  return 0;
+}
+
+int clipenc_encode(clipenc_t e, const void* crops_dev, int n_crops, int in_dtype, float* emb_dev, int normalize,
+                   void* stream) {
+  if (!e) return fail("NULL handle");
+  if (n_crops < 0) return fail("n_crops %d < 0", n_crops);
+  if (n_crops == 0) return 0;
+  if (!crops_dev || !emb_dev) return fail("NULL device pointer");
+  if (in_dtype != CLIPENC_IN_F32 && in_dtype != CLIPENC_IN_F16) return fail("unknown in_dtype %d", in_dtype);
+  if (((uintptr_t)crops_dev & 3) || ((uintptr_t)emb_dev & 3)) return fail("misaligned device pointer");
+  HIP_TRY(hipSetDevice(e->device));
+  if (int rc = ensure_workspace(e, n_crops)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  const clipenc_config& g = e->cfg;
+  const size_t cb = crop_bytes(g, in_dtype);
+  for (int c0 = 0; c0 < n_crops; c0 += e->chunk) {
+    const int c = std::min(e->chunk, n_crops - c0);
+    if (int rc = run_tower(e, (const char*)crops_dev + (size_t)c0 * cb, c, in_dtype, g.layers, st)) return rc;
+    HIP_TRY(ce_head(e->x, e->ln_post_w, e->ln_post_b, e->proj, emb_dev + (size_t)c0 * g.embed_dim, c, e->tokens,
+                    g.width, g.embed_dim, g.ln_eps, normalize, st));
+  }
+  return 0;
+}
+
+int clipenc_debug_run_layers(clipenc_t e, const void* crops_dev, int n_crops, int in_dtype, int n_layers,
+                             void* x_out, void* stream) {
+  if (!e || !crops_dev || !x_out) return fail("NULL argument");
+  if (n_crops < 1 || n_crops > e->chunk) return fail("n_crops %d outside 1..chunk(%d)", n_crops, e->chunk);
+  if (n_layers < 0 || n_layers > e->cfg.layers) return fail("n_layers %d out of range", n_layers);
+  HIP_TRY(hipSetDevice(e->device));
+  if (int rc = ensure_workspace(e, n_crops)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = run_tower(e, crops_dev, n_crops, in_dtype, n_layers, st)) return rc;
+  HIP_TRY(hipMemcpyAsync(x_out, e->x, (size_t)n_crops * e->tokens * e->cfg.width * 2, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int fcreg_create(int n_layers, const int* sizes, const float* const* W, const float* const* b, float negative_slope,
+                 int device, fcreg_t* out) {
+  if (!sizes || !W || !b || !out) return fail("fcreg_create: NULL argument");
+  if (n_layers < 1 || n_layers > CE_FC_MAX_LAYERS) return fail("n_layers %d outside 1..%d", n_layers, CE_FC_MAX_LAYERS);
+  for (int l = 0; l <= n_layers; ++l)
+    if (sizes[l] < 1) return fail("layer size %d at %d", sizes[l], l);
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail("device %d out of range (%d visible)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  fcreg_s* r = new fcreg_s();
+  r->device = device; r->n_layers = n_layers; r->negative_slope = negative_slope;
+  size_t off = 0;
+  std::vector<size_t> ow(n_layers), ob(n_layers);
+  for (int l = 0; l <= n_layers; ++l) r->sizes[l] = sizes[l];
+  for (int l = 0; l < n_layers; ++l) {
+    ow[l] = off; off += align_up((size_t)sizes[l] * sizes[l + 1] * 4, 256);
+    ob[l] = off; off += align_up((size_t)sizes[l + 1] * 4, 256);
+  }
+  std::vector<char> host(off);
+  for (int l = 0; l < n_layers; ++l) {
+    const int in = sizes[l], on = sizes[l + 1];
+    float* wt = (float*)(host.data() + ow[l]);
+    for (int j = 0; j < on; ++j)
+      for (int k = 0; k < in; ++k) wt[(size_t)k * on + j] = W[l][(size_t)j * in + k];     // transpose to [in][out]
+    memcpy(host.data() + ob[l], b[l], (size_t)on * 4);
+  }
+  hipError_t err = r->slab.alloc(off);
+  if (err == hipSuccess) err = hipMemcpy(r->slab.p, host.data(), off, hipMemcpyHostToDevice);
+  if (err != hipSuccess) { r->slab.release(); delete r; return fail("regressor upload failed: %s", hipGetErrorString(err)); }
+  for (int l = 0; l < n_layers; ++l) {
+    r->Wt[l] = (const float*)((char*)r->slab.p + ow[l]);
+    r->b[l] = (const float*)((char*)r->slab.p + ob[l]);
+  }
+  *out = r;
+  return 0;
+}
+
+int fcreg_destroy(fcreg_t r) {
+  if (!r) return 0;
+  (void)hipSetDevice(r->device);
+  r->slab.release();
+  delete r;
+  return 0;
+}
+
+int fcreg_forward(fcreg_t r, const float* x_dev, int n_rows, long row_stride, int n_seg, int seg_len,
+                  const int* seg_off, float* y_dev, void* stream) {
+  if (!r) return fail("NULL handle");
+  if (n_rows < 0) return fail("n_rows %d < 0", n_rows);
+  if (n_rows == 0) return 0;
+  if (!x_dev || !y_dev || !seg_off) return fail("NULL pointer");
+  if (n_seg < 1 || n_seg > CE_FC_MAX_SEG) return fail("n_seg %d outside 1..%d", n_seg, CE_FC_MAX_SEG);
+  if ((long)n_seg * seg_len != r->sizes[0])
+    return fail("input width mismatch: %d segments x %d != regressor input %d", n_seg, seg_len, r->sizes[0]);
+  HIP_TRY(hipSetDevice(r->device));
+  FcRegParams p{};
+  p.n_layers = r->n_layers;
+  for (int l = 0; l <= r->n_layers; ++l) p.sizes[l] = r->sizes[l];
+  for (int l = 0; l < r->n_layers; ++l) { p.Wt[l] = r->Wt[l]; p.b[l] = r->b[l]; }
+  p.negative_slope = r->negative_slope;
+  p.x = x_dev; p.row_stride = row_stride; p.n_seg = n_seg; p.seg_len = seg_len;
+  for (int s = 0; s < n_seg; ++s) p.seg_off[s] = seg_off[s];
+  p.y = y_dev; p.n_rows = n_rows;
+  HIP_TRY(ce_fcreg_forward(p, (hipStream_t)stream));
+  return 0;
+}
+
+int clipenc_encode_score(clipenc_t e, fcreg_t r, const void* crops_dev, int n_images, int crops_per_image, int in_dtype,
+                         const int* crop_select, int n_select, float* emb_dev, float* score_dev, void* stream) {
+  if (!e || !r) return fail("NULL handle");
+  if (e->device != r->device) return fail("encoder on device %d, regressor on device %d", e->device, r->device);
+  if (n_images < 0 || crops_per_image < 1) return fail("bad shape: %d images x %d crops", n_images, crops_per_image);
+  if (!crop_select || n_select < 1 || n_select > CE_FC_MAX_SEG) return fail("bad crop selection");
+  const int E = e->cfg.embed_dim;
+  int seg_off[CE_FC_MAX_SEG];
+  for (int s = 0; s < n_select; ++s) {
+    if (crop_select[s] < 0 || crop_select[s] >= crops_per_image) return fail("crop_select[%d] = %d out of range", s, crop_select[s]);
+    seg_off[s] = crop_select[s] * E;
+  }
+  if (n_images == 0) return 0;
+  if (int rc = clipenc_encode(e, crops_dev, n_images * crops_per_image, in_dtype, emb_dev, 1, stream)) return rc;
+  return fcreg_forward(r, emb_dev, n_images, (long)crops_per_image * E, n_select, E, seg_off, score_dev, stream);
+}
+
+int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int fp16_compare, void* ehat_ws_dev,
+                     long long* pairs_dev, float* vals_dev, unsigned long long capacity,
+                     unsigned long long* count_dev, void* stream) {
+  if (n < 0 || d < 1) return fail("dedup_find_pairs: bad shape n=%d d=%d", n, d);
+  if (!count_dev) return fail("dedup_find_pairs: count_dev is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), st));
+  if (n < 2) return 0;
+  if (!emb_f16_dev || !ehat_ws_dev || (capacity && (!pairs_dev || !vals_dev))) return fail("dedup_find_pairs: NULL device pointer");
+  const int ld = (d + 127) / 128 * 128;
+  HIP_TRY(ce_dedup_normalize_f16(emb_f16_dev, ehat_ws_dev, n, d, ld, st));
+  HIP_TRY(ce_dedup_pairs(ehat_ws_dev, n, d, ld, threshold, fp16_compare, pairs_dev, vals_dev, capacity, count_dev, st));
+  return 0;
+}
+
+int clipenc_op_gemm_nt(const void* a_dev, const void* w_dev, int m, int n, int k, int dtype, int epi,
+                       const float* bias_dev, void* out_dev, void* stream) {
+  if (epi != CLIPENC_EPI_STORE_F32 && epi != CLIPENC_EPI_STORE_BF16) return fail("epi %d not exposed", epi);
+  GemmParams p{};
+  p.A = a_dev; p.lda = k; p.W = w_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out_dev; p.ldo = n; p.bias = bias_dev;
+  hipError_t err = ce_gemm_nt(p, dtype, epi, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("gemm_nt(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
+  return 0;
+}
+
+int clipenc_op_attention(const void* qkv_dev, void* out_dev, int n_crops, int n_tok, int width, int heads, void* stream) {
+  hipError_t err = ce_attention(qkv_dev, out_dev, n_crops, n_tok, width, heads, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("attention(%d crops, %d tok) failed: %s", n_crops, n_tok, hipGetErrorString(err));
+  return 0;
+}
+
+}  // extern "C"

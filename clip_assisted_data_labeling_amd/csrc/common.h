@@ -1,0 +1,34 @@
+// Shared device/host helpers for the CLIP-embed HIP library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;                                             // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;          // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;            // 16x16 accumulator
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;          // 32x32 accumulator
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {              // round-to-nearest-even, NaN kept
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// host-side bf16 rounding identical to the device cast (RNE)
+static inline uint16_t host_f32_to_bf16(float f) {
+  uint32_t u; __builtin_memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float host_bf16_to_f32(uint16_t h) {
+  uint32_t u = ((uint32_t)h) << 16; float f; __builtin_memcpy(&f, &u, 4); return f;
+}
+
+#define CE_ACT_QUICK_GELU 0
+#define CE_ACT_GELU_ERF 1

@@ -1,0 +1,227 @@
+// Bandwidth-bound helpers around the GEMM chain of the ViT tower (K0, K2, K8, K9 of SURVEY.md §2.2;
+// the open_clip steps behind /root/reference/utils/embedder.py:98 and the normalise of :99).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// K0: fp32 NCHW crops -> bf16 patch rows  A[(crop*g + gy)*g + gx][k],  k = (c*p + ky)*p + kx,
+// zero-padded to kpad (the conv-as-GEMM operand; conv1 has stride = patch and no bias).
+// One block per (crop, gy): the 3*p input rows it touches are read in contiguous runs of p floats.
+// ---------------------------------------------------------------------------------------------
+template <typename TIN>
+__global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ in, bf16_t* __restrict__ out,
+                                                       int image, int patch, int kpad) {
+  const int g = image / patch;
+  const int crop = blockIdx.x / g, gy = blockIdx.x % g;
+  const int k_real = 3 * patch * patch;
+  const TIN* src = in + (size_t)crop * 3 * image * image;
+  bf16_t* dst = out + ((size_t)crop * g + gy) * g * kpad;
+  const int total = g * kpad;
+  for (int idx = threadIdx.x; idx < total; idx += 256) {
+    const int gx = idx / kpad, k = idx - gx * kpad;
+    float v = 0.f;
+    if (k < k_real) {
+      const int c = k / (patch * patch), rem = k - c * patch * patch;
+      const int ky = rem / patch, kx = rem - ky * patch;
+      v = (float)src[((size_t)c * image + gy * patch + ky) * image + gx * patch + kx];
+    }
+    dst[idx] = f32_to_bf16(v);
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: x[crop][tok] = LayerNorm_pre( (tok == 0 ? class_embedding : patch_emb[crop][tok-1]) + pos[tok] )
+// written as bf16, plus the per-row (sum, sumsq) of the ROUNDED row for the LayerNorm folded into
+// the first QKV GEMM.  One wave per token row; lanes own 8-element (16 B) column chunks.
+// ---------------------------------------------------------------------------------------------
+constexpr int LN_MAX_CHUNKS = 4;   // width <= 2048
+
+__global__ __launch_bounds__(256) void embed_ln_pre_kernel(const bf16_t* __restrict__ pe, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, bf16_t* __restrict__ x,
+                                                           float* __restrict__ stats, int n_rows, int n_tok, int width,
+                                                           float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int crop = row / n_tok, tok = row - crop * n_tok;
+  float v[LN_MAX_CHUNKS][8];
+  float s = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < LN_MAX_CHUNKS; ++ci) {
+    const int c = ci * 512 + lane * 8;
+    if (c < width) {
+      float4 p0 = *(const float4*)(pos + (size_t)tok * width + c);
+      float4 p1 = *(const float4*)(pos + (size_t)tok * width + c + 4);
+      float e[8];
+      if (tok == 0) {
+        float4 c0 = *(const float4*)(cls + c), c1 = *(const float4*)(cls + c + 4);
+        e[0] = c0.x; e[1] = c0.y; e[2] = c0.z; e[3] = c0.w; e[4] = c1.x; e[5] = c1.y; e[6] = c1.z; e[7] = c1.w;
+      } else {
+        uint4 raw = *(const uint4*)(pe + ((size_t)crop * (n_tok - 1) + tok - 1) * width + c);
+        e[0] = __uint_as_float(raw.x << 16); e[1] = __uint_as_float(raw.x & 0xffff0000u);
+        e[2] = __uint_as_float(raw.y << 16); e[3] = __uint_as_float(raw.y & 0xffff0000u);
+        e[4] = __uint_as_float(raw.z << 16); e[5] = __uint_as_float(raw.z & 0xffff0000u);
+        e[6] = __uint_as_float(raw.w << 16); e[7] = __uint_as_float(raw.w & 0xffff0000u);
+      }
+      v[ci][0] = e[0] + p0.x; v[ci][1] = e[1] + p0.y; v[ci][2] = e[2] + p0.z; v[ci][3] = e[3] + p0.w;
+      v[ci][4] = e[4] + p1.x; v[ci][5] = e[5] + p1.y; v[ci][6] = e[6] + p1.z; v[ci][7] = e[7] + p1.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[ci][j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)width;
+  float ss = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < LN_MAX_CHUNKS; ++ci) {
+    const int c = ci * 512 + lane * 8;
+    if (c < width) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[ci][j] - mean; ss += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)width + eps);
+  float rs = 0.f, rss = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < LN_MAX_CHUNKS; ++ci) {
+    const int c = ci * 512 + lane * 8;
+    if (c < width) {
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) y[j] = (v[ci][j] - mean) * rstd * gamma[c + j] + beta[c + j];
+      uint4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+      *(uint4*)(x + (size_t)row * width + c) = pk;
+      const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float a = __uint_as_float(w4[j] << 16), b = __uint_as_float(w4[j] & 0xffff0000u);
+        rs += a + b; rss += a * a + b * b;
+      }
+    }
+  }
+  rs = wave_sum(rs); rss = wave_sum(rss);
+  if (lane == 0) *(float2*)(stats + (size_t)row * 2) = float2{rs, rss};
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8 + K9: emb[crop] = normalise( LayerNorm_post(x[crop][0]) . proj[width][embed] )  in fp32.
+// HEAD_CROPS crops per block so that proj (3 MB at ViT-L/14) is streamed from L2 once per group.
+// ---------------------------------------------------------------------------------------------
+constexpr int HEAD_CROPS = 4;
+
+__global__ __launch_bounds__(256) void head_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ proj,
+                                                   float* __restrict__ emb, int n_crops, int n_tok, int width, int embed,
+                                                   float eps, int normalize) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* c = (float*)smem;                         // [HEAD_CROPS][width]
+  float* red = c + HEAD_CROPS * width;             // [HEAD_CROPS][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int crop0 = blockIdx.x * HEAD_CROPS;
+  // LayerNorm of the CLS rows: wave w handles crop crop0 + w
+  {
+    const int crop = crop0 + wave;
+    if (crop < n_crops) {
+      const bf16_t* row = x + (size_t)crop * n_tok * width;
+      float s = 0.f;
+      for (int k = lane; k < width; k += 64) s += bf16_to_f32(row[k]);
+      const float mean = wave_sum(s) / (float)width;
+      float ss = 0.f;
+      for (int k = lane; k < width; k += 64) { const float d = bf16_to_f32(row[k]) - mean; ss += d * d; }
+      const float rstd = rsqrtf(wave_sum(ss) / (float)width + eps);
+      for (int k = lane; k < width; k += 64)
+        c[wave * width + k] = (bf16_to_f32(row[k]) - mean) * rstd * gamma[k] + beta[k];
+    } else {
+      for (int k = lane; k < width; k += 64) c[wave * width + k] = 0.f;
+    }
+  }
+  __syncthreads();
+  float sq[HEAD_CROPS];
+#pragma unroll
+  for (int r = 0; r < HEAD_CROPS; ++r) sq[r] = 0.f;
+  constexpr int MAX_E_PER_THREAD = 4;              // embed <= 1024
+  float acc[MAX_E_PER_THREAD][HEAD_CROPS];
+#pragma unroll
+  for (int i = 0; i < MAX_E_PER_THREAD; ++i)
+#pragma unroll
+    for (int r = 0; r < HEAD_CROPS; ++r) acc[i][r] = 0.f;
+  for (int k = 0; k < width; ++k) {
+    float cv[HEAD_CROPS];
+#pragma unroll
+    for (int r = 0; r < HEAD_CROPS; ++r) cv[r] = c[r * width + k];
+#pragma unroll
+    for (int i = 0; i < MAX_E_PER_THREAD; ++i) {
+      const int e = tid + i * 256;
+      if (e < embed) {
+        const float w = proj[(size_t)k * embed + e];
+#pragma unroll
+        for (int r = 0; r < HEAD_CROPS; ++r) acc[i][r] = fmaf(cv[r], w, acc[i][r]);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAX_E_PER_THREAD; ++i)
+#pragma unroll
+    for (int r = 0; r < HEAD_CROPS; ++r) sq[r] += acc[i][r] * acc[i][r];
+#pragma unroll
+  for (int r = 0; r < HEAD_CROPS; ++r) {
+    const float t = wave_sum(sq[r]);
+    if (lane == 0) red[r * 4 + wave] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < HEAD_CROPS; ++r) {
+    const int crop = crop0 + r;
+    if (crop >= n_crops) continue;
+    float scale = 1.0f;
+    if (normalize) scale = 1.0f / sqrtf(red[r * 4 + 0] + red[r * 4 + 1] + red[r * 4 + 2] + red[r * 4 + 3]);
+#pragma unroll
+    for (int i = 0; i < MAX_E_PER_THREAD; ++i) {
+      const int e = tid + i * 256;
+      if (e < embed) emb[(size_t)crop * embed + e] = acc[i][r] * scale;
+    }
+  }
+}
+
+}  // namespace
+
+hipError_t ce_patchify(const void* crops, int in_dtype, void* a_patch, int n_crops, int image, int patch, int kpad,
+                       hipStream_t stream) {
+  if (image % patch != 0 || kpad < 3 * patch * patch || n_crops < 1) return hipErrorInvalidValue;
+  const int g = image / patch;
+  dim3 grid(n_crops * g), block(256);
+  if (in_dtype == 0)
+    hipLaunchKernelGGL(patchify_kernel<float>, grid, block, 0, stream, (const float*)crops, (bf16_t*)a_patch, image, patch, kpad);
+  else if (in_dtype == 1)
+    hipLaunchKernelGGL(patchify_kernel<_Float16>, grid, block, 0, stream, (const _Float16*)crops, (bf16_t*)a_patch, image, patch, kpad);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float* pos, const float* gamma,
+                           const float* beta, void* x, float* stats, int n_crops, int n_tok, int width, float eps,
+                           hipStream_t stream) {
+  if (width % 8 != 0 || width > LN_MAX_CHUNKS * 512) return hipErrorInvalidValue;
+  const int n_rows = n_crops * n_tok;
+  hipLaunchKernelGGL(embed_ln_pre_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, (const bf16_t*)patch_emb, cls,
+                     pos, gamma, beta, (bf16_t*)x, stats, n_rows, n_tok, width, eps);
+  return hipGetLastError();
+}
+
+hipError_t ce_head(const void* x, const float* gamma, const float* beta, const float* proj, float* emb, int n_crops,
+                   int n_tok, int width, int embed, float eps, int normalize, hipStream_t stream) {
+  if (embed > 1024 || width > 2048) return hipErrorInvalidValue;
+  const size_t lds = (size_t)HEAD_CROPS * width * 4 + HEAD_CROPS * 4 * 4;
+  hipLaunchKernelGGL(head_kernel, dim3((n_crops + HEAD_CROPS - 1) / HEAD_CROPS), dim3(256), lds, stream,
+                     (const bf16_t*)x, gamma, beta, proj, emb, n_crops, n_tok, width, embed, eps, normalize);
+  return hipGetLastError();
+}

@@ -1,0 +1,31 @@
+// Internal launcher interface of the tiled MFMA GEMM (gemm_bf16.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+enum { CE_DT_BF16 = 0, CE_DT_F16 = 1 };
+enum { EPI_STORE_F32 = 0, EPI_STORE_BF16 = 1, EPI_LNFOLD = 2, EPI_RESID = 3, EPI_THRESH = 4 };
+
+struct GemmParams {
+  const void* A; int lda;        // [M][lda] 16-bit elements, K-contiguous
+  const void* W; int ldw;        // [N][ldw] 16-bit elements, K-contiguous
+  int M, N, K;
+  void* out; int ldo;            // [M][ldo]
+  const float* bias;             // [N]
+  const float* colsum;           // [N]   EPI_LNFOLD: sum_k W'[n][k]
+  const float* stats_in;         // [parts][M][2] (sum, sumsq) of the rows of A   (EPI_LNFOLD)
+  int stats_in_parts;
+  float inv_width, eps;
+  int act;                       // EPI_LNFOLD: CE_ACT_* or -1
+  const void* resid;             // [M][ldo] bf16, may alias out                  (EPI_RESID)
+  float* stats_out;              // [N/256][M][2]                                 (EPI_RESID)
+  // EPI_THRESH (near-duplicate search): A == W == normalised embeddings, only tiles tn >= tm are
+  // launched (tri != 0) and every (i < j < n_valid) with value > thr is appended to pairs/vals.
+  int tri, n_valid, fp16_compare;
+  float thr;
+  long long* pairs;              // [cap][2]
+  float* vals;                   // [cap]
+  unsigned long long cap;
+  unsigned long long* count;
+};
+
+hipError_t ce_gemm_nt(const GemmParams& p, int dtype, int epi, hipStream_t stream);

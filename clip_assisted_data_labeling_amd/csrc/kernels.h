@@ -1,0 +1,38 @@
+// Internal launcher interface of the non-GEMM kernels (attention.hip, elementwise.hip, fcreg.hip, dedup.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// attention.hip
+hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int width, int heads, hipStream_t stream);
+
+// elementwise.hip
+hipError_t ce_patchify(const void* crops, int in_dtype, void* a_patch, int n_crops, int image, int patch, int kpad,
+                       hipStream_t stream);
+hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float* pos, const float* gamma,
+                           const float* beta, void* x, float* stats, int n_crops, int n_tok, int width, float eps,
+                           hipStream_t stream);
+hipError_t ce_head(const void* x, const float* gamma, const float* beta, const float* proj, float* emb, int n_crops,
+                   int n_tok, int width, int embed, float eps, int normalize, hipStream_t stream);
+
+// fcreg.hip
+#define CE_FC_MAX_LAYERS 8
+#define CE_FC_MAX_SEG 16
+struct FcRegParams {
+  int n_layers;
+  int sizes[CE_FC_MAX_LAYERS + 1];
+  const float* Wt[CE_FC_MAX_LAYERS];   // [in][out] (transposed nn.Linear weight)
+  const float* b[CE_FC_MAX_LAYERS];
+  float negative_slope;
+  const float* x; long row_stride;     // input row i, segment s: x + i*row_stride + seg_off[s], seg_len floats
+  int n_seg, seg_len; int seg_off[CE_FC_MAX_SEG];
+  float* y;                            // [n_rows][sizes[n_layers]]
+  int n_rows;
+};
+hipError_t ce_fcreg_forward(const FcRegParams& p, hipStream_t stream);
+
+// dedup.hip
+hipError_t ce_dedup_normalize_f16(const void* emb_f16, void* out_f16, int n, int d, int ld_out, hipStream_t stream);
+hipError_t ce_dedup_pairs(const void* ehat_f16, int n, int d, int ld, float threshold, int fp16_compare,
+                          long long* pairs, float* vals, unsigned long long capacity, unsigned long long* count,
+                          hipStream_t stream);

@@ -1,0 +1,102 @@
+"""CPU-side data prep of the embed path: the 4-crop geometry and the CLIP validation transform.
+
+Restates /root/reference/utils/embedder.py:184-251 (`CustomImageDataset.extract_crops`) and the
+open_clip validation transform returned by `CLIP_Encoder.get_preprocess_transform`
+(/root/reference/utils/embedder.py:90-92; constants visible at :121-124) with PIL + torch only —
+torchvision is not available in this environment. SURVEY.md Appendix C documents the geometry.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+from PIL import Image
+
+OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+CROP_NAMES = ["centre_crop", "square_padded_crop", "subcrop1", "subcrop2"]   # _1_embed_with_CLIP.py:200
+
+
+def _center_crop_box(w: int, h: int, cw: int, ch: int) -> Tuple[int, int, int, int]:
+    # torchvision CenterCrop: top = int(round((h - ch) / 2.0)), left likewise (Python banker's rounding)
+    top = int(round((h - ch) / 2.0))
+    left = int(round((w - cw) / 2.0))
+    return left, top, left + cw, top + ch
+
+
+def crop_boxes(width: int, height: int, crop_names: Sequence[str] = CROP_NAMES):
+    """Integer geometry of the crops of a width x height image.
+
+    Returns a list of (name, kind, box): kind 'crop' -> box (left, top, right, bottom) in the image;
+    kind 'pad' -> box (side, paste_x, paste_y): black square canvas with the image pasted.
+    Mirrors utils/embedder.py:196-245 including the clipping at :233-236.
+    """
+    out = []
+    if "centre_crop" in crop_names:
+        s = min(width, height)
+        out.append(("centre_crop", "crop", _center_crop_box(width, height, s, s)))
+    if "square_padded_crop" in crop_names:
+        s = max(width, height)
+        out.append(("square_padded_crop", "pad", (s, (s - width) // 2, (s - height) // 2)))
+    if any("subcrop1" in n for n in crop_names) or any("subcrop2" in n for n in crop_names):
+        s1 = int((width * height * 0.15) ** 0.5)
+        s2 = int((width * height * 0.1) ** 0.5)
+        if width >= height:
+            centers = [(width // 4, height // 2), (width // 4 * 3, height // 2)]
+        else:
+            centers = [(width // 2, height // 4), (width // 2, height // 4 * 3)]
+        for name, (cx, cy), s in zip(["subcrop1", "subcrop2"], centers, [s1, s2]):
+            if name in crop_names:
+                left = max(0, cx - s // 2)
+                top = max(0, cy - s // 2)
+                right = min(width, left + s)
+                bottom = min(height, top + s)
+                if right - left > 0 and bottom - top > 0:
+                    out.append((name, "crop", (left, top, right, bottom)))
+    return out
+
+
+def extract_crops(pil_img: Image.Image, crop_names: Sequence[str] = CROP_NAMES) -> Tuple[List[Image.Image], List[str]]:
+    crops, names = [], []
+    for name, kind, box in crop_boxes(pil_img.width, pil_img.height, crop_names):
+        if kind == "crop":
+            crops.append(pil_img.crop(box))
+        else:
+            side, px, py = box
+            canvas = Image.new("RGB", (side, side), (0, 0, 0))
+            canvas.paste(pil_img, (px, py))
+            crops.append(canvas)
+        names.append(name)
+    return crops, names
+
+
+class ClipValTransform:
+    """Resize(R, bicubic, shorter side) -> CenterCrop(R) -> RGB -> ToTensor -> Normalize(mean, std)."""
+
+    def __init__(self, size: int, mean=OPENAI_CLIP_MEAN, std=OPENAI_CLIP_STD):
+        self.size = size
+        self.mean = torch.tensor(mean, dtype=torch.float32).view(3, 1, 1)
+        self.std = torch.tensor(std, dtype=torch.float32).view(3, 1, 1)
+
+    def __call__(self, img: Image.Image) -> torch.Tensor:
+        w, h = img.size
+        R = self.size
+        if w <= h:
+            nw, nh = R, int(R * h / w)
+        else:
+            nh, nw = R, int(R * w / h)
+        if (nw, nh) != (w, h):
+            img = img.resize((nw, nh), Image.BICUBIC)
+        img = img.crop(_center_crop_box(nw, nh, R, R))
+        img = img.convert("RGB")
+        arr = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+        return (arr - self.mean) / self.std
+
+    def __repr__(self):
+        return f"ClipValTransform(size={self.size})"
+
+
+def clip_val_transform(size: int) -> ClipValTransform:
+    return ClipValTransform(size)

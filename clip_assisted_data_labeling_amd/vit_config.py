@@ -1,0 +1,213 @@
+"""ViT image-tower configurations and weight containers for the CLIP embed path.
+
+The reference never spells these shapes out: it asks open_clip for a model by name
+(/root/reference/utils/embedder.py:59-74, name convention "<arch>/<pretrained>" split at :63).
+The table below restates the open_clip architectures the reference can name (SURVEY.md
+Appendix A.1) so that the HIP library can be configured without open_clip installed.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+import os
+from typing import Dict, Optional
+
+import torch
+
+ACT_QUICK_GELU = 0  # x * sigmoid(1.702 x): every "<arch>/openai" checkpoint
+ACT_GELU_ERF = 1    # erf GELU: laion* / datacomp* tags
+
+
+@dataclasses.dataclass(frozen=True)
+class ViTConfig:
+    image_size: int
+    patch: int
+    width: int
+    layers: int
+    heads: int
+    mlp_dim: int
+    embed_dim: int
+    act: int = ACT_QUICK_GELU
+    ln_eps: float = 1e-5
+
+    @property
+    def grid(self) -> int:
+        return self.image_size // self.patch
+
+    @property
+    def tokens(self) -> int:
+        return self.grid * self.grid + 1
+
+    @property
+    def patch_k(self) -> int:
+        return 3 * self.patch * self.patch
+
+    def macs_per_crop(self) -> int:
+        """Algorithmic MACs of one crop (unpadded tokens, CLS-only projection)."""
+        n, d, m = self.tokens, self.width, self.mlp_dim
+        per_layer = n * d * 3 * d + 2 * n * n * d + n * d * d + 2 * n * d * m
+        return (n - 1) * self.patch_k * d + self.layers * per_layer + d * self.embed_dim
+
+
+ARCHS: Dict[str, ViTConfig] = {
+    "ViT-B-32": ViTConfig(224, 32, 768, 12, 12, 3072, 512),
+    "ViT-B-16": ViTConfig(224, 16, 768, 12, 12, 3072, 512),
+    "ViT-L-14": ViTConfig(224, 14, 1024, 24, 16, 4096, 768),
+    "ViT-L-14-336": ViTConfig(336, 14, 1024, 24, 16, 4096, 768),
+    # small shapes used by the parity tests (not open_clip names)
+    "ViT-tiny-test": ViTConfig(28, 14, 256, 2, 4, 512, 32),
+    "ViT-small-test": ViTConfig(98, 14, 256, 3, 4, 1024, 64),
+}
+
+
+def config_for(model_name: str) -> ViTConfig:
+    """'ViT-L-14/openai' -> ViTConfig. Unknown arch raises ValueError like _1_embed_with_CLIP.py:75."""
+    arch, _, pretrained = model_name.partition("/")
+    if arch not in ARCHS:
+        raise ValueError(f"Unknown model architecture: {arch!r} (known: {sorted(ARCHS)})")
+    cfg = ARCHS[arch]
+    if pretrained and pretrained != "openai" and not pretrained.startswith("seed"):
+        cfg = dataclasses.replace(cfg, act=ACT_GELU_ERF)
+    return cfg
+
+
+def state_dict_keys(cfg: ViTConfig):
+    """(key, shape) pairs of the OpenAI / open_clip `visual.` state dict."""
+    d, m = cfg.width, cfg.mlp_dim
+    keys = [
+        ("conv1.weight", (d, 3, cfg.patch, cfg.patch)),
+        ("class_embedding", (d,)),
+        ("positional_embedding", (cfg.tokens, d)),
+        ("ln_pre.weight", (d,)), ("ln_pre.bias", (d,)),
+    ]
+    for l in range(cfg.layers):
+        p = f"transformer.resblocks.{l}."
+        keys += [
+            (p + "ln_1.weight", (d,)), (p + "ln_1.bias", (d,)),
+            (p + "attn.in_proj_weight", (3 * d, d)), (p + "attn.in_proj_bias", (3 * d,)),
+            (p + "attn.out_proj.weight", (d, d)), (p + "attn.out_proj.bias", (d,)),
+            (p + "ln_2.weight", (d,)), (p + "ln_2.bias", (d,)),
+            (p + "mlp.c_fc.weight", (m, d)), (p + "mlp.c_fc.bias", (m,)),
+            (p + "mlp.c_proj.weight", (d, m)), (p + "mlp.c_proj.bias", (d,)),
+        ]
+    keys += [("ln_post.weight", (d,)), ("ln_post.bias", (d,)), ("proj", (d, cfg.embed_dim))]
+    return keys
+
+
+def seeded_state_dict(cfg: ViTConfig, seed: int = 0, randomize_affine: bool = True) -> Dict[str, torch.Tensor]:
+    """Seeded fp32 weights with OpenAI-style init scales.
+
+    There is no network in the build/bench environment, so parity and throughput runs use these
+    instead of the `openai` checkpoint. LayerNorm affine terms and biases are randomised (unlike a
+    fresh init) so that every term of the forward is exercised by the parity tests.
+    """
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    d, L = cfg.width, cfg.layers
+    attn_std = d ** -0.5
+    proj_std = (d ** -0.5) * ((2 * L) ** -0.5)
+    fc_std = (2 * d) ** -0.5
+    sd: Dict[str, torch.Tensor] = {}
+    for key, shape in state_dict_keys(cfg):
+        if key == "conv1.weight":
+            t = torch.randn(shape, generator=g) * (cfg.patch_k ** -0.5)
+        elif key in ("class_embedding", "positional_embedding", "proj"):
+            t = torch.randn(shape, generator=g) * attn_std
+        elif key.endswith("in_proj_weight"):
+            t = torch.randn(shape, generator=g) * attn_std
+        elif key.endswith("out_proj.weight") or key.endswith("c_proj.weight"):
+            t = torch.randn(shape, generator=g) * proj_std
+        elif key.endswith("c_fc.weight"):
+            t = torch.randn(shape, generator=g) * fc_std
+        elif key.endswith("ln_1.weight") or key.endswith("ln_2.weight") or key in ("ln_pre.weight", "ln_post.weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g) if randomize_affine else torch.ones(shape)
+        else:  # biases
+            t = 0.02 * torch.randn(shape, generator=g) if randomize_affine else torch.zeros(shape)
+        sd[key] = t.float().contiguous()
+    return sd
+
+
+def normalise_state_dict(raw: Dict[str, torch.Tensor], cfg: ViTConfig) -> Dict[str, torch.Tensor]:
+    """Accept a full CLIP state dict ('visual.' prefix), a bare visual dict, or a
+    `transformers` CLIPVisionModelWithProjection dict, and return the OpenAI `visual.` layout in fp32."""
+    if any(k.startswith("visual.") for k in raw):
+        raw = {k[len("visual."):]: v for k, v in raw.items() if k.startswith("visual.")}
+    if any(k.startswith("vision_model.") for k in raw):
+        raw = _from_transformers(raw, cfg)
+    out = {}
+    for key, shape in state_dict_keys(cfg):
+        if key not in raw:
+            raise KeyError(f"weight {key!r} missing from state dict")
+        t = raw[key].detach().to(torch.float32).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError(f"weight {key!r} has shape {tuple(t.shape)}, expected {shape}")
+        out[key] = t
+    return out
+
+
+def _from_transformers(hf: Dict[str, torch.Tensor], cfg: ViTConfig) -> Dict[str, torch.Tensor]:
+    """Key mapping of SURVEY.md Appendix A.3 (split q/k/v -> in_proj, visual_projection^T -> proj)."""
+    sd = {
+        "conv1.weight": hf["vision_model.embeddings.patch_embedding.weight"],
+        "class_embedding": hf["vision_model.embeddings.class_embedding"],
+        "positional_embedding": hf["vision_model.embeddings.position_embedding.weight"],
+        "ln_pre.weight": hf["vision_model.pre_layrnorm.weight"],
+        "ln_pre.bias": hf["vision_model.pre_layrnorm.bias"],
+        "ln_post.weight": hf["vision_model.post_layernorm.weight"],
+        "ln_post.bias": hf["vision_model.post_layernorm.bias"],
+        "proj": hf["visual_projection.weight"].t().contiguous(),
+    }
+    for l in range(cfg.layers):
+        s = f"vision_model.encoder.layers.{l}."
+        p = f"transformer.resblocks.{l}."
+        sd[p + "ln_1.weight"] = hf[s + "layer_norm1.weight"]
+        sd[p + "ln_1.bias"] = hf[s + "layer_norm1.bias"]
+        sd[p + "ln_2.weight"] = hf[s + "layer_norm2.weight"]
+        sd[p + "ln_2.bias"] = hf[s + "layer_norm2.bias"]
+        sd[p + "attn.in_proj_weight"] = torch.cat(
+            [hf[s + f"self_attn.{n}_proj.weight"] for n in "qkv"], 0)
+        sd[p + "attn.in_proj_bias"] = torch.cat(
+            [hf[s + f"self_attn.{n}_proj.bias"] for n in "qkv"], 0)
+        sd[p + "attn.out_proj.weight"] = hf[s + "self_attn.out_proj.weight"]
+        sd[p + "attn.out_proj.bias"] = hf[s + "self_attn.out_proj.bias"]
+        sd[p + "mlp.c_fc.weight"] = hf[s + "mlp.fc1.weight"]
+        sd[p + "mlp.c_fc.bias"] = hf[s + "mlp.fc1.bias"]
+        sd[p + "mlp.c_proj.weight"] = hf[s + "mlp.fc2.weight"]
+        sd[p + "mlp.c_proj.bias"] = hf[s + "mlp.fc2.bias"]
+    return sd
+
+
+def load_weights(model_name: str, model_path: Optional[str]) -> Dict[str, torch.Tensor]:
+    """Resolve the weights the reference would have fetched through open_clip
+    (/root/reference/utils/embedder.py:66-73, `cache_dir=model_path`).
+
+    * pretrained tag 'seed<N>'  -> seeded synthetic weights (bench / parity);
+    * otherwise a local file `<model_path>/<arch>-<pretrained>.{pt,pth,bin,safetensors}` (or
+      `model_path` itself when it is a file) holding an OpenAI/open_clip/transformers state dict.
+    No download is attempted: a missing file raises FileNotFoundError.
+    """
+    cfg = config_for(model_name)
+    arch, _, pretrained = model_name.partition("/")
+    if pretrained.startswith("seed"):
+        return seeded_state_dict(cfg, int(pretrained[4:] or 0))
+    candidates = []
+    if model_path and os.path.isfile(model_path):
+        candidates.append(model_path)
+    elif model_path:
+        for ext in ("pt", "pth", "bin", "safetensors"):
+            candidates.append(os.path.join(model_path, f"{arch}-{pretrained}.{ext}"))
+            candidates.append(os.path.join(model_path, f"{arch}_{pretrained}.{ext}"))
+    for path in candidates:
+        if os.path.isfile(path):
+            if path.endswith(".safetensors"):
+                from safetensors.torch import load_file
+                raw = load_file(path)
+            else:
+                raw = torch.load(path, map_location="cpu", weights_only=True)
+                if isinstance(raw, dict) and "state_dict" in raw:
+                    raw = raw["state_dict"]
+            return normalise_state_dict(raw, cfg)
+    raise FileNotFoundError(
+        f"No local weights for {model_name!r}: looked for {candidates or '(no model_path given)'}; "
+        "this build never downloads checkpoints. Pass model_path=<dir or file>, or use the "
+        f"synthetic tag '{arch}/seed0'.")

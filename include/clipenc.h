@@ -1,0 +1,127 @@
+/* C ABI of the MI355X-native CLIP-embed / label-score library (libclipenc_hip.so).
+ *
+ * Drop-in boundary for the hot path of aiXander/CLIP_assisted_data_labeling.  The reference is pure
+ * Python with no FFI of its own; each entry point below names the reference call it replaces, and
+ * INTEGRATION.md shows the ctypes stub a maintainer would put behind that call.
+ *
+ * Conventions: every function returns 0 on success or a non-zero status (clipenc_last_error()
+ * gives the message for the calling thread); nothing aborts the process.  `*_dev` pointers are
+ * device (HBM) addresses owned by the CALLER (e.g. torch tensors); the library owns only the weights
+ * and workspace inside its handles.  `stream` is a hipStream_t (NULL = default stream); calls are
+ * asynchronous on it and never synchronise the device.  One caller thread per handle at a time.
+ */
+#ifndef CLIPENC_H
+#define CLIPENC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct clipenc_s* clipenc_t;   /* ViT image tower: weights + workspace on one device */
+typedef struct fcreg_s* fcreg_t;       /* SimpleFC regressor weights on one device */
+
+#define CLIPENC_ACT_QUICK_GELU 0       /* "<arch>/openai" checkpoints */
+#define CLIPENC_ACT_GELU_ERF 1
+
+#define CLIPENC_IN_F32 0               /* crops as float32 NCHW (what _1_embed_with_CLIP.py:114-115 hands over) */
+#define CLIPENC_IN_F16 1               /* crops as float16 NCHW (the reference's cuda path, utils/embedder.py:96-97) */
+
+typedef struct clipenc_config {
+  int image_size, patch, width, layers, heads, mlp_dim, embed_dim;
+  int act;                             /* CLIPENC_ACT_* */
+  float ln_eps;
+} clipenc_config;
+
+/* Host float32 tensors in the OpenAI / open_clip `visual.` state-dict layout.
+ * Per-layer members are arrays of `layers` pointers.  Everything is copied/converted at create time. */
+typedef struct clipenc_weights {
+  const float* conv1_weight;           /* [width][3][patch][patch], no bias */
+  const float* class_embedding;        /* [width] */
+  const float* positional_embedding;   /* [tokens][width] */
+  const float* ln_pre_w;  const float* ln_pre_b;
+  const float* const* ln_1_w;          const float* const* ln_1_b;
+  const float* const* in_proj_w;       const float* const* in_proj_b;    /* [3*width][width], [3*width] : q|k|v */
+  const float* const* out_proj_w;      const float* const* out_proj_b;   /* [width][width] */
+  const float* const* ln_2_w;          const float* const* ln_2_b;
+  const float* const* c_fc_w;          const float* const* c_fc_b;       /* [mlp][width] */
+  const float* const* c_proj_w;        const float* const* c_proj_b;     /* [width][mlp] */
+  const float* ln_post_w; const float* ln_post_b;
+  const float* proj;                   /* [width][embed_dim], used as x @ proj */
+} clipenc_weights;
+
+const char* clipenc_last_error(void);
+int clipenc_device_count(int* count);
+
+/* Replaces the model construction of CLIP_Encoder.__init__
+ * (/root/reference/utils/embedder.py:66-74: open_clip.create_model_and_transforms + .to(device).eval()). */
+int clipenc_create(const clipenc_config* cfg, const clipenc_weights* weights, int device, clipenc_t* out);
+int clipenc_destroy(clipenc_t enc);
+
+/* Crops pushed through the 24-layer chain per pass (workspace is sized for it; default 2048). */
+int clipenc_set_chunk(clipenc_t enc, int chunk_crops);
+int clipenc_get_info(clipenc_t enc, int* tokens, int* embed_dim, int* chunk_crops, size_t* workspace_bytes);
+
+/* Replaces CLIP_Encoder.encode_image (/root/reference/utils/embedder.py:94-100):
+ *   crops_dev  [n_crops][3][R][R], contiguous NCHW, dtype `in_dtype`, row = image*4 + crop
+ *   emb_dev    float32 [n_crops][embed_dim]; L2-normalised rows when `normalize` != 0 (:99). */
+int clipenc_encode(clipenc_t enc, const void* crops_dev, int n_crops, int in_dtype, float* emb_dev,
+                   int normalize, void* stream);
+
+/* Replaces `torch.load(model_file)` of a pickled SimpleFC as far as its arithmetic goes
+ * (/root/reference/_5_predict_labels.py:107, utils/embedder.py:290; layer list utils/nn_model.py:21-33).
+ * sizes[0..n_layers] = in, hidden..., out; W[l] host float32 [sizes[l+1]][sizes[l]] (nn.Linear layout). */
+int fcreg_create(int n_layers, const int* sizes, const float* const* W, const float* const* b,
+                 float negative_slope, int device, fcreg_t* out);
+int fcreg_destroy(fcreg_t reg);
+
+/* Replaces `model(features.float())` (/root/reference/_5_predict_labels.py:135, utils/nn_model.py:38-41).
+ * Row i of the input is the concatenation of n_seg segments of seg_len floats found at
+ * x_dev + i*row_stride + seg_off[s] (n_seg*seg_len == sizes[0]); a plain [n_rows][in] matrix is
+ * n_seg = 1, seg_off = {0}, row_stride = in.   y_dev: float32 [n_rows][sizes[n_layers]]. */
+int fcreg_forward(fcreg_t reg, const float* x_dev, int n_rows, long row_stride, int n_seg, int seg_len,
+                  const int* seg_off, float* y_dev, void* stream);
+
+/* The fused composition AestheticRegressor.predict_score intends
+ * (/root/reference/utils/embedder.py:298-311; _5_predict_labels.py:79 for the crop selection):
+ * encode n_images*crops_per_image crops, then score each image on the embeddings of the crops
+ * listed in crop_select (crop-major, model.crop_names order) without leaving the device.
+ *   emb_dev    float32 [n_images][crops_per_image][embed_dim]  (normalised)
+ *   score_dev  float32 [n_images][out] */
+int clipenc_encode_score(clipenc_t enc, fcreg_t reg, const void* crops_dev, int n_images, int crops_per_image,
+                         int in_dtype, const int* crop_select, int n_select, float* emb_dev, float* score_dev,
+                         void* stream);
+
+/* Replaces the similarity search of find_near_duplicates (/root/reference/_2_remove_duplicates.py:63-80):
+ * rows of emb_f16_dev [n][d] (float16, as :38 casts them) are normalised (:67) and every pair i < j with
+ * cosine > threshold (:69-74) is appended, unordered, to pairs_dev (int64 [capacity][2]) / vals_dev
+ * (float32 [capacity]); *count_dev (uint64, zeroed by the call) receives the number found, which may
+ * exceed capacity (only `capacity` are stored).  ehat_ws_dev: scratch of n_pad*d_pad float16 where
+ * n_pad = n rounded up to 256 and d_pad = d rounded up to 128.  If fp16_compare != 0 the similarity is rounded to float16 before the
+ * comparison, as the reference's float16 matmul output is. */
+int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int fp16_compare,
+                     void* ehat_ws_dev, long long* pairs_dev, float* vals_dev, unsigned long long capacity,
+                     unsigned long long* count_dev, void* stream);
+
+/* Operator-level entry points (used by the parity tests to pin each kernel on its own). */
+#define CLIPENC_DT_BF16 0
+#define CLIPENC_DT_F16 1
+#define CLIPENC_EPI_STORE_F32 0
+#define CLIPENC_EPI_STORE_BF16 1
+/* out[M][N] = A[M][K] . W[N][K]^T (+ bias[N]); A, W 16-bit row-major; N % 256 == 0, K % 128 == 0 */
+int clipenc_op_gemm_nt(const void* a_dev, const void* w_dev, int m, int n, int k, int dtype, int epi,
+                       const float* bias_dev, void* out_dev, void* stream);
+/* qkv bf16 [n_crops*n_tok][3*width] -> out bf16 [n_crops*n_tok][width]; head dim 64, n_tok <= 288 */
+int clipenc_op_attention(const void* qkv_dev, void* out_dev, int n_crops, int n_tok, int width, int heads,
+                         void* stream);
+/* Residual stream after `layer` blocks (layer = 0: after ln_pre) of the LAST clipenc_encode chunk:
+ * copies bf16 [n_rows][width] from the handle's workspace into out_dev (test hook). */
+int clipenc_debug_run_layers(clipenc_t enc, const void* crops_dev, int n_crops, int in_dtype, int n_layers,
+                             void* x_out_bf16_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIPENC_H */

@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Generates the committed golden vectors under tests/golden/ — run ONLY in the authoring
+container, where /root/reference exists:   python tests/golden/make_golden.py
+
+What is pinned against what:
+  regressor_shipped.npz  the reference's own SimpleFC (/root/reference/utils/nn_model.py) with the
+                         shipped checkpoint models/single_crop_regression_9.4k_imgs_80_epochs.pth:
+                         exported weights (plain arrays), seeded unit-norm inputs, reference outputs.
+  regressor_4crop.npz    the reference SimpleFC class built at 3072->264->128->64->1 with numpy-seeded
+                         weights: inputs + reference outputs (weights regenerated from the seed).
+  dedup_planted.npz      the reference's find_near_duplicates (/root/reference/_2_remove_duplicates.py)
+                         run on a planted-pair set written as <uuid>.jpg/.pt files: reported pairs+values.
+  encoder_*.npz          oracle/vit_oracle.py outputs on seeded weights, after asserting agreement with
+                         transformers.CLIPVisionModelWithProjection (independent implementation; the
+                         reference has no vectors at the open_clip boundary).
+None of the reference's source travels: only arrays are written.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from clip_assisted_data_labeling_amd import vit_config  # noqa: E402
+from oracle import vit_oracle, fcreg_oracle, dedup_oracle  # noqa: E402
+
+
+def unit_rows(n, d, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, d, generator=g)
+    return (x / x.norm(dim=-1, keepdim=True)).float()
+
+
+def np_fc_weights(sizes, seed):
+    rs = np.random.RandomState(seed)
+    Ws, bs = [], []
+    for i in range(len(sizes) - 1):
+        bound = 1.0 / np.sqrt(sizes[i])
+        Ws.append(rs.uniform(-bound, bound, size=(sizes[i + 1], sizes[i])).astype(np.float32))
+        bs.append(rs.uniform(-bound, bound, size=(sizes[i + 1],)).astype(np.float32))
+    return Ws, bs
+
+
+def make_regressor():
+    sys.path.insert(0, REF)
+    from utils.nn_model import SimpleFC  # the reference class itself
+    model = torch.load(os.path.join(REF, "models/single_crop_regression_9.4k_imgs_80_epochs.pth"),
+                       map_location="cpu", weights_only=False)
+    model.eval()
+    lin = [m for m in model.layers if isinstance(m, torch.nn.Linear)]
+    x = unit_rows(64, 768, seed=0)
+    with torch.no_grad():
+        y = model(x).numpy()
+    out = {"x": x.numpy(), "y": y, "n_layers": len(lin), "negative_slope": 0.01,
+           "clip_models": np.array(model.clip_models), "crop_names": np.array(model.crop_names)}
+    for i, m in enumerate(lin):
+        out[f"W{i}"] = m.weight.detach().numpy().astype(np.float16 if False else np.float32)
+        out[f"b{i}"] = m.bias.detach().numpy()
+    np.savez_compressed(os.path.join(HERE, "regressor_shipped.npz"), **out)
+    # oracle pinned against the reference, here and in tests
+    Ws = [out[f"W{i}"] for i in range(len(lin))]
+    bs = [out[f"b{i}"] for i in range(len(lin))]
+    assert np.abs(fcreg_oracle.forward_c(Ws, bs, x.numpy()) - y).max() < 2e-6
+    assert np.abs(fcreg_oracle.forward_np(Ws, bs, x.numpy()) - y).max() < 2e-6
+    print("regressor_shipped: first rows", y[:4, 0])
+
+    sizes = [3072, 264, 128, 64, 1]
+    Ws, bs = np_fc_weights(sizes, seed=11)
+    m4 = SimpleFC(3072, [264, 128, 64], 1, clip_models=["ViT-L-14/openai"], dropout_prob=0.5)
+    lin4 = [m for m in m4.layers if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        for m, W, b in zip(lin4, Ws, bs):
+            m.weight.copy_(torch.from_numpy(W)); m.bias.copy_(torch.from_numpy(b))
+    m4.eval()
+    x4 = unit_rows(32 * 4, 768, seed=5).reshape(32, 3072) * 4.0
+    with torch.no_grad():
+        y4 = m4(x4).numpy()
+    assert np.abs(fcreg_oracle.forward_c(Ws, bs, x4.numpy()) - y4).max() < 2e-6
+    np.savez_compressed(os.path.join(HERE, "regressor_4crop.npz"), x=x4.numpy(), y=y4,
+                        sizes=np.array(sizes), weight_seed=11)
+    sys.path.remove(REF)
+    for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        del sys.modules[k]
+
+
+def make_dedup():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_dedup", os.path.join(REF, "_2_remove_duplicates.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    n, d, n_planted, thr = 2000, 768, 40, 0.96
+    g = torch.Generator().manual_seed(7)
+    e = torch.randn(n, d, generator=g)
+    src = torch.randperm(n - n_planted, generator=g)[:n_planted]
+    for t, s in enumerate(src.tolist()):
+        noise = torch.randn(d, generator=g)
+        scale = 0.1 + 0.25 * (t / n_planted)          # sweep across the 0.96 threshold
+        e[n - n_planted + t] = e[s] + scale * noise
+    e16 = e.to(torch.float16)
+    captured = []
+    ref.fix_duplicate = lambda i, paths, out_dir, sim, mode: captured.append((paths, float(sim)))
+    with tempfile.TemporaryDirectory() as tmp:
+        root = os.path.join(tmp, "imgs")
+        os.makedirs(root)
+        for i in range(n):
+            open(os.path.join(root, f"{i:06d}.jpg"), "wb").close()
+            torch.save({"ViT-L-14/openai": {"square_padded_crop": e16[i].float().unsqueeze(0)}},
+                       os.path.join(root, f"{i:06d}.pt"))
+        args = types.SimpleNamespace(root_dir=root, threshold=thr, mode="copy", clip_model_to_use=None,
+                                     chunk_size=10000, test=False)
+        ref.find_near_duplicates(args)
+    # os.walk file order is arbitrary: map paths back to indices
+    pairs = np.array([[int(os.path.basename(a)[:6]), int(os.path.basename(b)[:6])] for (a, b), _ in captured])
+    vals = np.array([v for _, v in captured], dtype=np.float32)
+    lo = np.minimum(pairs[:, 0], pairs[:, 1]); hi = np.maximum(pairs[:, 0], pairs[:, 1])
+    order = np.lexsort((hi, lo))
+    pairs = np.stack([lo, hi], 1)[order]; vals = vals[order]
+    # pin the oracle against the reference output
+    op, ov = dedup_oracle.near_duplicates(e16, thr)
+    assert op.shape[0] == pairs.shape[0] and (op.numpy() == pairs).all(), (op.shape, pairs.shape)
+    assert np.abs(ov.float().numpy() - vals).max() == 0.0
+    np.savez_compressed(os.path.join(HERE, "dedup_planted.npz"), emb_fp16=e16.numpy(), threshold=thr,
+                        pairs=pairs, values=vals)
+    print("dedup_planted:", pairs.shape[0], "pairs reported by the reference")
+
+
+def make_encoder(arch, n_crops, seed, in_seed):
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+    cfg = vit_config.ARCHS[arch]
+    sd = vit_config.seeded_state_dict(cfg, seed)
+    g = torch.Generator().manual_seed(in_seed)
+    u = torch.randint(0, 256, (n_crops, 3, cfg.image_size, cfg.image_size), generator=g).float()
+    mean = torch.tensor([0.48145466, 0.4578275, 0.40821073]).view(1, 3, 1, 1)
+    std = torch.tensor([0.26862954, 0.26130258, 0.27577711]).view(1, 3, 1, 1)
+    crops = (u / 255.0 - mean) / std
+    taps = {}
+    emb = vit_oracle.encode_image(sd, cfg, crops, taps)
+    # independent cross-check: transformers tower with the same weights (SURVEY.md Appendix A.3 mapping)
+    hf_cfg = CLIPVisionConfig(hidden_size=cfg.width, intermediate_size=cfg.mlp_dim, projection_dim=cfg.embed_dim,
+                              num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
+                              image_size=cfg.image_size, patch_size=cfg.patch, hidden_act="quick_gelu",
+                              layer_norm_eps=cfg.ln_eps)
+    hf = CLIPVisionModelWithProjection(hf_cfg).eval()
+    hsd = {}
+    d = cfg.width
+    hsd["vision_model.embeddings.patch_embedding.weight"] = sd["conv1.weight"]
+    hsd["vision_model.embeddings.class_embedding"] = sd["class_embedding"]
+    hsd["vision_model.embeddings.position_embedding.weight"] = sd["positional_embedding"]
+    hsd["vision_model.pre_layrnorm.weight"] = sd["ln_pre.weight"]
+    hsd["vision_model.pre_layrnorm.bias"] = sd["ln_pre.bias"]
+    hsd["vision_model.post_layernorm.weight"] = sd["ln_post.weight"]
+    hsd["vision_model.post_layernorm.bias"] = sd["ln_post.bias"]
+    hsd["visual_projection.weight"] = sd["proj"].t().contiguous()
+    for l in range(cfg.layers):
+        s, p = f"vision_model.encoder.layers.{l}.", f"transformer.resblocks.{l}."
+        for i, n in enumerate("qkv"):
+            hsd[s + f"self_attn.{n}_proj.weight"] = sd[p + "attn.in_proj_weight"][i * d:(i + 1) * d]
+            hsd[s + f"self_attn.{n}_proj.bias"] = sd[p + "attn.in_proj_bias"][i * d:(i + 1) * d]
+        hsd[s + "self_attn.out_proj.weight"] = sd[p + "attn.out_proj.weight"]
+        hsd[s + "self_attn.out_proj.bias"] = sd[p + "attn.out_proj.bias"]
+        hsd[s + "layer_norm1.weight"] = sd[p + "ln_1.weight"]; hsd[s + "layer_norm1.bias"] = sd[p + "ln_1.bias"]
+        hsd[s + "layer_norm2.weight"] = sd[p + "ln_2.weight"]; hsd[s + "layer_norm2.bias"] = sd[p + "ln_2.bias"]
+        hsd[s + "mlp.fc1.weight"] = sd[p + "mlp.c_fc.weight"]; hsd[s + "mlp.fc1.bias"] = sd[p + "mlp.c_fc.bias"]
+        hsd[s + "mlp.fc2.weight"] = sd[p + "mlp.c_proj.weight"]; hsd[s + "mlp.fc2.bias"] = sd[p + "mlp.c_proj.bias"]
+    missing, unexpected = hf.load_state_dict(hsd, strict=False)
+    assert not unexpected and all("position_ids" in m for m in missing), (missing, unexpected)
+    with torch.no_grad():
+        ref = hf(pixel_values=crops).image_embeds
+    ref = ref / ref.norm(dim=-1, keepdim=True)
+    err = (ref - emb).abs().max().item()
+    assert err < 1e-5, err
+    # round-trip through the transformers->openai key mapping of the product's loader
+    back = vit_config.normalise_state_dict(hf.state_dict(), cfg)
+    assert all(torch.equal(back[k], sd[k]) for k in sd)
+    wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+    np.savez_compressed(os.path.join(HERE, f"encoder_{arch}.npz"), arch=arch, weight_seed=seed, input_seed=in_seed,
+                        n_crops=n_crops, weight_abs_sum=wsum, crops_abs_sum=float(crops.double().abs().sum()),
+                        emb=emb.numpy(), ln_pre_cls=taps["ln_pre"][:, 0].numpy(),
+                        block0_cls=taps["block0"][:, 0].numpy(),
+                        last_block_tok1=taps[f"block{cfg.layers - 1}"][:, 1].numpy())
+    print(f"encoder_{arch}: oracle vs transformers max-abs {err:.2e}")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    make_regressor()
+    make_dedup()
+    make_encoder("ViT-tiny-test", 6, seed=3, in_seed=4)
+    make_encoder("ViT-small-test", 5, seed=1, in_seed=2)
+    make_encoder("ViT-B-32", 8, seed=0, in_seed=1234)
