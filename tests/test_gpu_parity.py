@@ -1,0 +1,308 @@
+"""GPU parity tests (-m gpu): every call goes through the C ABI of libclipenc_hip.so and is compared
+with the oracle / committed golden vectors.  Tolerances follow BASELINE.json north_star:
+embeddings 1 - cos <= 1e-3, scores <= 1e-4 abs; integer/index outputs bit-exact."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from clip_assisted_data_labeling_amd import _lib, vit_config
+from clip_assisted_data_labeling_amd.embedder import CLIP_Encoder, HipViT
+from clip_assisted_data_labeling_amd.nn_model import HipRegressor, SimpleFC
+from oracle import dedup_oracle, fcreg_oracle, vit_oracle
+from tests.helpers import np_fc_weights, one_minus_cos, synthetic_crops
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-3      # north_star: embeddings within 1e-3 cosine of the fp32 CPU path
+SCORE_TOL = 1e-4    # north_star: scores within 1e-4 abs
+
+
+def _stream(dev):
+    return _lib.current_stream_ptr(dev)
+
+
+# ------------------------------------------------------------------------------------------ GEMM
+def _gemm(gpu, a, w, dtype, epi, bias=None):
+    lib = _lib.load()
+    m, k = a.shape
+    n = w.shape[0]
+    out = torch.empty((m, n), device=gpu, dtype=torch.float32 if epi == 0 else torch.bfloat16)
+    out.fill_(float("nan"))
+    _lib.check(lib.clipenc_op_gemm_nt(a.data_ptr(), w.data_ptr(), m, n, k, dtype, epi,
+                                      bias.data_ptr() if bias is not None else None, out.data_ptr(), _stream(gpu)),
+               "gemm")
+    torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 128), (1, 256, 128), (255, 512, 256), (257, 256, 640),
+                                   (1285, 768, 1024), (4096, 1024, 4096), (65535, 256, 128)])
+def test_gemm_bf16_f32out_matches_torch(gpu, m, n, k):
+    g = torch.Generator().manual_seed(m * 7 + n * 3 + k)
+    a = torch.randn(m, k, generator=g).to(torch.bfloat16).to(gpu)
+    w = torch.randn(n, k, generator=g).to(torch.bfloat16).to(gpu)
+    out = _gemm(gpu, a, w, 0, 0)
+    ref = a.float() @ w.float().t()
+    # operands are exact bf16, products exact in fp32; only the fp32 summation order differs
+    assert torch.isfinite(out).all()
+    assert (out - ref).abs().max().item() <= 2e-3 * (k ** 0.5)
+
+
+def test_gemm_is_not_transposed_or_permuted(gpu):
+    # A = one-hot rows, asymmetric W: catches swapped row/col maps that random data can hide
+    m, n, k = 512, 512, 256
+    a = torch.zeros(m, k)
+    a[torch.arange(m), torch.arange(m) % k] = 1.0
+    w = (torch.arange(n).view(n, 1) * 0.25 + torch.arange(k).view(1, k) * 2.0) % 61.0
+    out = _gemm(gpu, a.to(torch.bfloat16).to(gpu), w.to(torch.bfloat16).to(gpu), 0, 0)
+    ref = a @ w.to(torch.bfloat16).float().t()
+    assert torch.equal(out.cpu(), ref)
+
+
+def test_gemm_f16_and_bf16_store_with_bias(gpu):
+    g = torch.Generator().manual_seed(5)
+    m, n, k = 777, 512, 384
+    a = torch.randn(m, k, generator=g)
+    w = torch.randn(n, k, generator=g)
+    bias = torch.randn(n, generator=g).to(gpu)
+    o16 = _gemm(gpu, a.half().to(gpu), w.half().to(gpu), 1, 0)
+    assert (o16.cpu() - a.half().float() @ w.half().float().t()).abs().max() < 2e-2
+    ob = _gemm(gpu, a.to(torch.bfloat16).to(gpu), w.to(torch.bfloat16).to(gpu), 0, 1, bias)
+    ref = a.to(torch.bfloat16).float() @ w.to(torch.bfloat16).float().t() + bias.cpu()
+    assert (ob.float().cpu() - ref).abs().max() <= 0.01 * ref.abs().max()      # one bf16 rounding
+
+
+def test_gemm_rejects_bad_shapes(gpu):
+    lib = _lib.load()
+    t = torch.zeros(256, 256, device=gpu, dtype=torch.bfloat16)
+    o = torch.zeros(256, 256, device=gpu)
+    assert lib.clipenc_op_gemm_nt(t.data_ptr(), t.data_ptr(), 256, 200, 256, 0, 0, None, o.data_ptr(), None) != 0
+    assert lib.clipenc_op_gemm_nt(t.data_ptr(), t.data_ptr(), 256, 256, 64, 0, 0, None, o.data_ptr(), None) != 0
+    assert b"gemm_nt" in lib.clipenc_last_error()
+
+
+# ------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("n_crops,n_tok,heads", [(3, 5, 4), (2, 32, 4), (2, 50, 12), (2, 197, 4), (3, 257, 16), (1, 288, 4)])
+def test_attention_matches_fp32_reference(gpu, n_crops, n_tok, heads):
+    lib = _lib.load()
+    width = heads * 64
+    g = torch.Generator().manual_seed(n_tok)
+    qkv = (torch.randn(n_crops * n_tok, 3 * width, generator=g) * 1.5).to(torch.bfloat16)
+    out = torch.full((n_crops * n_tok, width), float("nan"), dtype=torch.bfloat16, device=gpu)
+    _lib.check(lib.clipenc_op_attention(qkv.to(gpu).data_ptr(), out.data_ptr(), n_crops, n_tok, width, heads, _stream(gpu)),
+               "attention")
+    torch.cuda.synchronize()
+    q, k, v = qkv.float().view(n_crops, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v
+    ref = ref.permute(0, 2, 1, 3).reshape(n_crops * n_tok, width)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 0.03       # bf16 P and bf16 output rounding on |v| ~ 1.5
+    assert one_minus_cos(got, ref).max().item() < 2e-4
+
+
+def test_attention_large_logits_do_not_overflow(gpu):
+    # one key dominates every row: exercises the true-max subtraction
+    lib = _lib.load()
+    n_tok, heads, width = 257, 4, 256
+    qkv = torch.zeros(n_tok, 3 * width)
+    qkv[:, :width] = 30.0
+    qkv[7, width:2 * width] = 30.0                      # key 7: logit 30*30*64/8 = 7200
+    qkv[:, 2 * width:] = torch.arange(n_tok).view(-1, 1).float() / 64.0
+    out = torch.empty((n_tok, width), dtype=torch.bfloat16, device=gpu)
+    _lib.check(lib.clipenc_op_attention(qkv.to(torch.bfloat16).to(gpu).data_ptr(), out.data_ptr(), 1, n_tok, width, heads,
+                                        _stream(gpu)), "attention")
+    assert torch.allclose(out.float().cpu(), torch.full((n_tok, width), 7 / 64.0), atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------- regressor
+def test_regressor_matches_reference_golden(gpu, golden_dir):
+    g = np.load(os.path.join(golden_dir, "regressor_shipped.npz"))
+    n = int(g["n_layers"])
+    reg = HipRegressor([torch.from_numpy(g[f"W{i}"]) for i in range(n)], [torch.from_numpy(g[f"b{i}"]) for i in range(n)],
+                       float(g["negative_slope"]), gpu)
+    y = reg(torch.from_numpy(g["x"]).to(gpu)).cpu().numpy()
+    assert y.shape == g["y"].shape
+    assert np.abs(y - g["y"]).max() < SCORE_TOL
+
+
+def test_regressor_4crop_and_ragged_rows(gpu, golden_dir):
+    g = np.load(os.path.join(golden_dir, "regressor_4crop.npz"))
+    Ws, bs = np_fc_weights(list(g["sizes"]), int(g["weight_seed"]))
+    m = SimpleFC(3072, [264, 128, 64], 1, clip_models=["ViT-L-14/openai"], dropout_prob=0.5)
+    lin = m._linears()
+    with torch.no_grad():
+        for layer, W, b in zip(lin, Ws, bs):
+            layer.weight.copy_(torch.from_numpy(W)); layer.bias.copy_(torch.from_numpy(b))
+    m.eval()
+    x = torch.from_numpy(g["x"]).to(gpu)
+    y = m(x)                                        # the reference call shape: model(features) -> [B,1]
+    assert y.shape == (32, 1) and y.device.type == "cuda"
+    assert np.abs(y.cpu().numpy() - g["y"]).max() < SCORE_TOL
+    for rows in (1, 3, 5, 31):                       # row counts that are not a multiple of the row tile
+        assert np.abs(m(x[:rows]).cpu().numpy() - g["y"][:rows]).max() < SCORE_TOL
+    assert m(x[:0]).shape == (0, 1)                  # empty batch
+    with pytest.raises(ValueError):
+        m(x[:, :100])
+    m.train()
+    with pytest.raises(_lib.ClipencError):
+        m(x)
+
+
+def test_regressor_odd_layer_sizes_vs_oracle(gpu):
+    sizes = [37, 300, 5, 3]
+    Ws, bs = np_fc_weights(sizes, 3)
+    reg = HipRegressor([torch.from_numpy(w) for w in Ws], [torch.from_numpy(b) for b in bs], 0.2, gpu)
+    x = np.random.RandomState(1).randn(19, 37).astype(np.float32)
+    y = reg(torch.from_numpy(x).to(gpu)).cpu().numpy()
+    assert np.abs(y - fcreg_oracle.forward_c(Ws, bs, x, 0.2)).max() < 1e-5
+
+
+# --------------------------------------------------------------------------------------- encoder
+@pytest.mark.parametrize("arch", ["ViT-tiny-test", "ViT-small-test", "ViT-B-32"])
+def test_encoder_matches_golden_and_oracle(gpu, golden_dir, arch):
+    g = np.load(os.path.join(golden_dir, f"encoder_{arch}.npz"))
+    cfg = vit_config.ARCHS[arch]
+    sd = vit_config.seeded_state_dict(cfg, int(g["weight_seed"]))
+    crops = synthetic_crops(int(g["n_crops"]), cfg.image_size, int(g["input_seed"]))
+    vit = HipViT(cfg, sd, gpu)
+    emb = vit.encode(crops.to(gpu)).cpu()
+    gold = torch.from_numpy(g["emb"])
+    assert emb.shape == gold.shape and torch.isfinite(emb).all()
+    assert torch.allclose(emb.norm(dim=-1), torch.ones(emb.shape[0]), atol=1e-5)
+    omc = one_minus_cos(emb, gold)
+    assert omc.max().item() < COS_TOL, omc
+    # stage taps: ln_pre output and the residual stream after the first / last block
+    taps = {}
+    vit_oracle.encode_image(sd, cfg, crops, taps)
+    x0 = vit.debug_run_layers(crops.to(gpu), 0).float().cpu()
+    assert (x0 - taps["ln_pre"]).abs().max().item() < 0.05
+    assert one_minus_cos(x0.flatten(1), taps["ln_pre"].flatten(1)).max().item() < 1e-4
+    for l in (1, cfg.layers):
+        xl = vit.debug_run_layers(crops.to(gpu), l).float().cpu()
+        ref = taps[f"block{l - 1}"]
+        assert one_minus_cos(xl.flatten(1), ref.flatten(1)).max().item() < 5e-4, l
+    vit.close()
+
+
+def test_encoder_batch_chunk_and_dtype_invariance(gpu):
+    cfg = vit_config.ARCHS["ViT-small-test"]
+    sd = vit_config.seeded_state_dict(cfg, 4)
+    crops = synthetic_crops(11, cfg.image_size, 8).to(gpu)
+    vit = HipViT(cfg, sd, gpu)
+    full = vit.encode(crops)
+    assert torch.equal(full, vit.encode(crops))                      # deterministic: no atomics on the path
+    vit.set_chunk(4)                                                 # 4 + 4 + 3 crops per pass
+    chunked = vit.encode(crops)
+    assert one_minus_cos(full.cpu(), chunked.cpu()).max().item() < 1e-6
+    single = torch.cat([vit.encode(crops[i:i + 1]) for i in range(3)])
+    assert one_minus_cos(full[:3].cpu(), single.cpu()).max().item() < 1e-6
+    half = vit.encode(crops.half())                                  # the reference's cuda path hands over fp16
+    assert one_minus_cos(full.cpu(), half.cpu()).max().item() < 1e-4
+    unnorm = vit.encode(crops, normalize=False)
+    assert torch.allclose(unnorm / unnorm.norm(dim=-1, keepdim=True), full, atol=1e-6)
+    assert vit.encode(crops[:0]).shape == (0, cfg.embed_dim)         # empty batch
+    with pytest.raises(ValueError):
+        vit.encode(crops[:, :, :50, :50])
+    vit.close()
+
+
+def test_clip_encoder_surface_and_4crop_row_order(gpu):
+    enc = CLIP_Encoder("ViT-small-test/seed4", None, device="cuda")    # positional like _1_embed_with_CLIP.py:73
+    assert enc.img_resolution == 98 and enc.model_name == "ViT-small-test/seed4" and enc.device == "cuda"
+    B = 3
+    crops = synthetic_crops(B * 4, 98, 21).view(B, 4, 3, 98, 98)
+    stacked = crops.view(-1, 3, 98, 98).to("cuda")                     # _1_embed_with_CLIP.py:114-115
+    f = enc.encode_image(stacked)
+    assert f.shape == (B * 4, 64) and f.device.type == "cuda"
+    f = f.view(B, 4, -1)                                              # :132 row = image*4 + crop
+    cfg = vit_config.config_for("ViT-small-test/seed4")
+    ref = vit_oracle.encode_image(vit_config.seeded_state_dict(cfg, 4), cfg, crops[1]).view(4, -1)
+    assert one_minus_cos(f[1].cpu(), ref).max().item() < COS_TOL
+    with pytest.raises(ValueError):
+        CLIP_Encoder("RN50/openai", None, device="cuda")
+    with pytest.raises(FileNotFoundError):
+        CLIP_Encoder("ViT-B-32/openai", None, device="cuda")
+
+
+def test_encode_score_fused_matches_separate_calls(gpu, golden_dir):
+    lib = _lib.load()
+    cfg = vit_config.ARCHS["ViT-small-test"]
+    vit = HipViT(cfg, vit_config.seeded_state_dict(cfg, 4), gpu)
+    E = cfg.embed_dim
+    sizes = [2 * E, 48, 16, 1]
+    Ws, bs = np_fc_weights(sizes, 2)
+    reg = HipRegressor([torch.from_numpy(w) for w in Ws], [torch.from_numpy(b) for b in bs], 0.01, gpu)
+    n_img = 5
+    crops = synthetic_crops(n_img * 4, cfg.image_size, 3).to(gpu)
+    emb = torch.empty((n_img, 4, E), device=gpu)
+    score = torch.empty((n_img, 1), device=gpu)
+    sel = (ctypes.c_int * 2)(3, 1)                                    # crop_names order: subcrop2, square_padded
+    _lib.check(lib.clipenc_encode_score(vit.handle, reg.handle, crops.data_ptr(), n_img, 4, 0, sel, 2, emb.data_ptr(),
+                                        score.data_ptr(), _stream(gpu)), "encode_score")
+    torch.cuda.synchronize()
+    assert torch.equal(emb.view(-1, E), vit.encode(crops))
+    feats = torch.cat([emb[:, 3], emb[:, 1]], dim=1).cpu().numpy()    # _5_predict_labels.py:79 assembly
+    assert np.abs(score.cpu().numpy() - fcreg_oracle.forward_c(Ws, bs, feats)).max() < SCORE_TOL
+    assert lib.clipenc_encode_score(vit.handle, reg.handle, crops.data_ptr(), n_img, 4, 0, (ctypes.c_int * 2)(4, 1), 2,
+                                    emb.data_ptr(), score.data_ptr(), None) != 0
+    vit.close(); reg.close()
+
+
+# ----------------------------------------------------------------------------------------- dedup
+def _run_dedup(gpu, e16, thr, fp16_compare=1, capacity=4096):
+    lib = _lib.load()
+    n, d = e16.shape
+    n_pad, d_pad = (n + 255) // 256 * 256, (d + 127) // 128 * 128
+    ws = torch.empty(n_pad * d_pad, dtype=torch.float16, device=gpu)
+    pairs = torch.full((capacity, 2), -1, dtype=torch.int64, device=gpu)
+    vals = torch.zeros(capacity, dtype=torch.float32, device=gpu)
+    count = torch.full((1,), 123, dtype=torch.int64, device=gpu)
+    x = e16.to(gpu).contiguous()
+    _lib.check(lib.dedup_find_pairs(x.data_ptr(), n, d, thr, fp16_compare, ws.data_ptr(), pairs.data_ptr(), vals.data_ptr(),
+                                    capacity, count.data_ptr(), _stream(gpu)), "dedup")
+    torch.cuda.synchronize()
+    c = int(count.item())
+    p = pairs[:min(c, capacity)].cpu().numpy()
+    v = vals[:min(c, capacity)].cpu().numpy()
+    order = np.lexsort((p[:, 1], p[:, 0]))
+    return c, p[order], v[order]
+
+
+def test_dedup_matches_reference_golden(gpu, golden_dir):
+    g = np.load(os.path.join(golden_dir, "dedup_planted.npz"))
+    e16 = torch.from_numpy(g["emb_fp16"])
+    thr = float(g["threshold"])
+    c, p, v = _run_dedup(gpu, e16, thr)
+    # pairs whose fp32 similarity is within one fp16 ulp of the threshold may legitimately differ
+    # (fp16 accumulation-order ties); everything outside the band must match exactly
+    s32 = dedup_oracle.similarity_fp32(e16).numpy()
+    band = 1.0e-3
+    gold = {tuple(r) for r in g["pairs"].tolist()}
+    got = {tuple(r) for r in p.tolist()}
+    for (i, j) in gold ^ got:
+        assert abs(s32[i, j] - thr) < band, (i, j, s32[i, j])
+    assert c == len(got) and len(gold & got) >= len(gold) - 2
+    assert all(i < j for i, j in got)
+    gv = {tuple(r): val for r, val in zip(g["pairs"].tolist(), g["values"].tolist())}
+    for (i, j), val in zip(p.tolist(), v.tolist()):
+        if (i, j) in gv:
+            assert abs(val - gv[(i, j)]) <= 4.9e-4        # one fp16 ulp below 1.0
+
+
+def test_dedup_edge_cases(gpu):
+    g = torch.Generator().manual_seed(0)
+    e = torch.randn(300, 512, generator=g)
+    e[299] = e[0]                                          # exact duplicate across a tile boundary (row 299, col 0)
+    e[100] = e[101]
+    c, p, _ = _run_dedup(gpu, e.half(), 0.96)
+    assert c == 2 and p.tolist() == [[0, 299], [100, 101]]
+    c, p, _ = _run_dedup(gpu, e.half(), 0.96, capacity=1)  # overflow: count still exact, one pair stored
+    assert c == 2 and len(p) == 1
+    c, _, _ = _run_dedup(gpu, e[:1].half(), 0.5)           # a single row has no pairs
+    assert c == 0
+    c, p, _ = _run_dedup(gpu, torch.ones(5, 100).half(), 0.5, fp16_compare=0)   # d not a multiple of 128; all identical
+    assert c == 10
