@@ -55,7 +55,12 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p]),
     "dedup_find_pairs": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                  c_ulonglong, c_void_p, c_void_p]),
+    "clipenc_profile_enable": (c_int, [c_void_p, c_int]),
+    "clipenc_profile_kinds": (c_int, []),
+    "clipenc_profile_read": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(ctypes.c_double), POINTER(c_longlong),
+                                     POINTER(ctypes.c_double), c_int]),
     "clipenc_op_gemm_nt": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "clipenc_op_gemm_nt_stamps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "clipenc_op_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "clipenc_debug_run_layers": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
 }

@@ -63,7 +63,53 @@ struct LayerDev {
 
 }  // namespace
 
+enum { PK_PATCHIFY = 0, PK_GEMM_PATCH, PK_EMBED_LN_PRE, PK_GEMM_LNFOLD, PK_ATTENTION, PK_GEMM_RESID, PK_HEAD, PK_FCREG, PK_COUNT };
+static const char* const kProfileNames[PK_COUNT] = {
+    "patchify_kernel", "gemm_nt_kernel<bf16,EPI_STORE_BF16>", "embed_ln_pre_kernel", "gemm_nt_kernel<bf16,EPI_LNFOLD>",
+    "attn_kernel", "gemm_nt_kernel<bf16,EPI_RESID>", "head_kernel", "fcreg_kernel"};
+
+struct ProfRec { int kind; hipEvent_t a, b; double flops; };
+
+struct Profiler {
+  bool on = false;
+  std::vector<ProfRec> recs;
+  std::vector<hipEvent_t> pool;
+  double ms[PK_COUNT] = {0}, flops[PK_COUNT] = {0};
+  long long launches[PK_COUNT] = {0};
+  hipEvent_t get() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  void begin(int kind, double fl, hipStream_t st) {
+    if (!on) return;
+    ProfRec r{kind, get(), get(), fl};
+    (void)hipEventRecord(r.a, st);
+    recs.push_back(r);
+  }
+  void end(hipStream_t st) {
+    if (!on) return;
+    (void)hipEventRecord(recs.back().b, st);
+  }
+  void collect() {
+    for (auto& r : recs) {
+      (void)hipEventSynchronize(r.b);
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.kind] += t; flops[r.kind] += r.flops; launches[r.kind]++; }
+      pool.push_back(r.a); pool.push_back(r.b);
+    }
+    recs.clear();
+  }
+  void release() {
+    collect();
+    for (auto e : pool) (void)hipEventDestroy(e);
+    pool.clear();
+  }
+};
+
 struct clipenc_s {
+  Profiler prof;
   clipenc_config cfg;
   int device = 0;
   int tokens = 0, kpad = 0;
@@ -103,7 +149,8 @@ int ensure_workspace(clipenc_s* e, int n_crops) {
   auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
   const size_t o_ap = take(P * e->kpad * 2), o_pe = take(P * g.width * 2), o_x = take(T * g.width * 2);
   const size_t o_qkv = take(T * 3 * g.width * 2), o_at = take(T * g.width * 2), o_h = take(T * g.mlp_dim * 2);
-  const size_t o_s0 = take(T * 8), o_sa = take(parts * T * 8), o_sb = take(parts * T * 8);
+  const size_t Tp = align_up(T, 256);
+  const size_t o_s0 = take(Tp * 8), o_sa = take(parts * Tp * 8), o_sb = take(parts * Tp * 8);
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(e->ws.alloc(off));
   char* b = (char*)e->ws.p;
@@ -119,13 +166,22 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
   const clipenc_config& g = e->cfg;
   const int T = c * e->tokens, P = c * (e->tokens - 1);
   const int parts = g.width / 256;
+  const int Tp = (int)align_up((size_t)T, 256);
+  Profiler& pf = e->prof;
+  const double dT = (double)T, dD = (double)g.width;
+  pf.begin(PK_PATCHIFY, 0.0, st);
   HIP_TRY(ce_patchify(crops, in_dtype, e->a_patch, c, g.image_size, g.patch, e->kpad, st));
+  pf.end(st);
   GemmParams p{};
   p.A = e->a_patch; p.lda = e->kpad; p.W = e->w_conv; p.ldw = e->kpad; p.M = P; p.N = g.width; p.K = e->kpad;
   p.out = e->pe; p.ldo = g.width; p.bias = nullptr;
+  pf.begin(PK_GEMM_PATCH, 2.0 * P * dD * (3.0 * g.patch * g.patch), st);
   HIP_TRY(ce_gemm_nt(p, CE_DT_BF16, EPI_STORE_BF16, st));
+  pf.end(st);
+  pf.begin(PK_EMBED_LN_PRE, 0.0, st);
   HIP_TRY(ce_embed_ln_pre(e->pe, e->cls, e->pos, e->ln_pre_w, e->ln_pre_b, e->x, e->stats0, c, e->tokens, g.width,
                           g.ln_eps, st));
+  pf.end(st);
   const float* stats_in = e->stats0;
   int stats_parts = 1;
   for (int l = 0; l < n_layers; ++l) {
@@ -134,26 +190,36 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     GemmParams q{};
     q.A = e->x; q.lda = g.width; q.W = L.w_qkv; q.ldw = g.width; q.M = T; q.N = 3 * g.width; q.K = g.width;
     q.out = e->qkv; q.ldo = 3 * g.width; q.bias = L.b_qkv; q.colsum = L.cs_qkv;
-    q.stats_in = stats_in; q.stats_in_parts = stats_parts; q.inv_width = 1.0f / g.width; q.eps = g.ln_eps; q.act = -1;
+    q.stats_in = stats_in; q.stats_in_parts = stats_parts; q.stats_ld = Tp; q.inv_width = 1.0f / g.width; q.eps = g.ln_eps; q.act = -1;
+    pf.begin(PK_GEMM_LNFOLD, 2.0 * dT * 3.0 * dD * dD, st);
     HIP_TRY(ce_gemm_nt(q, CE_DT_BF16, EPI_LNFOLD, st));
+    pf.end(st);
     // K4
+    pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * e->tokens * dD, st);
     HIP_TRY(ce_attention(e->qkv, e->attn, c, e->tokens, g.width, g.heads, st));
+    pf.end(st);
     // K5: x += attn . Wo^T + bo
     GemmParams o{};
     o.A = e->attn; o.lda = g.width; o.W = L.w_out; o.ldw = g.width; o.M = T; o.N = g.width; o.K = g.width;
-    o.out = e->x; o.ldo = g.width; o.bias = L.b_out; o.resid = e->x; o.stats_out = e->stats_a;
+    o.out = e->x; o.ldo = g.width; o.bias = L.b_out; o.resid = e->x; o.stats_out = e->stats_a; o.stats_ld = Tp;
+    pf.begin(PK_GEMM_RESID, 2.0 * dT * dD * dD, st);
     HIP_TRY(ce_gemm_nt(o, CE_DT_BF16, EPI_RESID, st));
+    pf.end(st);
     // K6: h = act(LN2(x) . Wfc^T + b)
     GemmParams f{};
     f.A = e->x; f.lda = g.width; f.W = L.w_fc; f.ldw = g.width; f.M = T; f.N = g.mlp_dim; f.K = g.width;
     f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
-    f.stats_in = e->stats_a; f.stats_in_parts = parts; f.inv_width = 1.0f / g.width; f.eps = g.ln_eps; f.act = g.act;
+    f.stats_in = e->stats_a; f.stats_in_parts = parts; f.stats_ld = Tp; f.inv_width = 1.0f / g.width; f.eps = g.ln_eps; f.act = g.act;
+    pf.begin(PK_GEMM_LNFOLD, 2.0 * dT * dD * g.mlp_dim, st);
     HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
+    pf.end(st);
     // K7: x += h . Wproj^T + b
     GemmParams r{};
     r.A = e->hid; r.lda = g.mlp_dim; r.W = L.w_proj; r.ldw = g.mlp_dim; r.M = T; r.N = g.width; r.K = g.mlp_dim;
-    r.out = e->x; r.ldo = g.width; r.bias = L.b_proj; r.resid = e->x; r.stats_out = e->stats_b;
+    r.out = e->x; r.ldo = g.width; r.bias = L.b_proj; r.resid = e->x; r.stats_out = e->stats_b; r.stats_ld = Tp;
+    pf.begin(PK_GEMM_RESID, 2.0 * dT * dD * g.mlp_dim, st);
     HIP_TRY(ce_gemm_nt(r, CE_DT_BF16, EPI_RESID, st));
+    pf.end(st);
     stats_in = e->stats_b; stats_parts = parts;
   }
   return 0;
@@ -280,6 +346,7 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
 int clipenc_destroy(clipenc_t e) {
   if (!e) return 0;
   (void)hipSetDevice(e->device);
+  e->prof.release();
   e->weights.release();
   e->ws.release();
   delete e;
@@ -318,9 +385,35 @@ int clipenc_encode(clipenc_t e, const void* crops_dev, int n_crops, int in_dtype
   for (int c0 = 0; c0 < n_crops; c0 += e->chunk) {
     const int c = std::min(e->chunk, n_crops - c0);
     if (int rc = run_tower(e, (const char*)crops_dev + (size_t)c0 * cb, c, in_dtype, g.layers, st)) return rc;
+    e->prof.begin(PK_HEAD, 2.0 * c * (double)g.width * g.embed_dim, st);
     HIP_TRY(ce_head(e->x, e->ln_post_w, e->ln_post_b, e->proj, emb_dev + (size_t)c0 * g.embed_dim, c, e->tokens,
                     g.width, g.embed_dim, g.ln_eps, normalize, st));
+    e->prof.end(st);
   }
+  return 0;
+}
+
+int clipenc_profile_enable(clipenc_t e, int on) {
+  if (!e) return fail("NULL handle");
+  HIP_TRY(hipSetDevice(e->device));
+  e->prof.collect();
+  e->prof.on = on != 0;
+  return 0;
+}
+
+int clipenc_profile_kinds(void) { return PK_COUNT; }
+
+int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total_ms, long long* launches,
+                         double* algorithmic_flops, int reset) {
+  if (!e) return fail("NULL handle");
+  if (kind < 0 || kind >= PK_COUNT) return fail("profile kind %d out of range", kind);
+  HIP_TRY(hipSetDevice(e->device));
+  e->prof.collect();
+  if (name) *name = kProfileNames[kind];
+  if (total_ms) *total_ms = e->prof.ms[kind];
+  if (launches) *launches = e->prof.launches[kind];
+  if (algorithmic_flops) *algorithmic_flops = e->prof.flops[kind];
+  if (reset) { e->prof.ms[kind] = 0; e->prof.launches[kind] = 0; e->prof.flops[kind] = 0; }
   return 0;
 }
 
@@ -419,7 +512,12 @@ int clipenc_encode_score(clipenc_t e, fcreg_t r, const void* crops_dev, int n_im
   }
   if (n_images == 0) return 0;
   if (int rc = clipenc_encode(e, crops_dev, n_images * crops_per_image, in_dtype, emb_dev, 1, stream)) return rc;
-  return fcreg_forward(r, emb_dev, n_images, (long)crops_per_image * E, n_select, E, seg_off, score_dev, stream);
+  double fl = 0.0;
+  for (int l = 0; l < r->n_layers; ++l) fl += 2.0 * n_images * (double)r->sizes[l] * r->sizes[l + 1];
+  e->prof.begin(PK_FCREG, fl, (hipStream_t)stream);
+  const int rc = fcreg_forward(r, emb_dev, n_images, (long)crops_per_image * E, n_select, E, seg_off, score_dev, stream);
+  e->prof.end((hipStream_t)stream);
+  return rc;
 }
 
 int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int fp16_compare, void* ehat_ws_dev,
@@ -444,6 +542,16 @@ int clipenc_op_gemm_nt(const void* a_dev, const void* w_dev, int m, int n, int k
   p.A = a_dev; p.lda = k; p.W = w_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out_dev; p.ldo = n; p.bias = bias_dev;
   hipError_t err = ce_gemm_nt(p, dtype, epi, (hipStream_t)stream);
   if (err != hipSuccess) return fail("gemm_nt(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
+  return 0;
+}
+
+int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n, int k, void* out_dev,
+                              unsigned long long* stamps_dev, void* stream) {
+  GemmParams p{};
+  p.A = a_dev; p.lda = k; p.W = w_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out_dev; p.ldo = n;
+  p.dbg = stamps_dev;
+  hipError_t err = ce_gemm_nt(p, CE_DT_BF16, EPI_STORE_BF16, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("gemm_nt_stamps failed: %s", hipGetErrorString(err));
   return 0;
 }
 

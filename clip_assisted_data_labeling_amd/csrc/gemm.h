@@ -14,6 +14,7 @@ struct GemmParams {
   const float* colsum;           // [N]   EPI_LNFOLD: sum_k W'[n][k]
   const float* stats_in;         // [parts][M][2] (sum, sumsq) of the rows of A   (EPI_LNFOLD)
   int stats_in_parts;
+  int stats_ld;                  // row stride (in rows) between the parts of stats_in / stats_out (>= M, multiple of 256)
   float inv_width, eps;
   int act;                       // EPI_LNFOLD: CE_ACT_* or -1
   const void* resid;             // [M][ldo] bf16, may alias out                  (EPI_RESID)
@@ -26,6 +27,9 @@ struct GemmParams {
   float* vals;                   // [cap]
   unsigned long long cap;
   unsigned long long* count;
+  unsigned long long* dbg;       // optional [tiles][8] timing stamps (diagnostic entry point only)
+  int stagger_ns;                // spread of the first-wave start delays (set by the launcher)
 };
 
 hipError_t ce_gemm_nt(const GemmParams& p, int dtype, int epi, hipStream_t stream);
+hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream);   // bf16; EPI_STORE_BF16 / LNFOLD / RESID

@@ -21,6 +21,8 @@
 // (wr=0 / wr=1; they are the two waves of every SIMD) run half a phase apart, so one issues MFMAs
 // while the other issues LDS reads and DMA.  DMA stays in flight across barriers; one counted
 // s_waitcnt vmcnt per K-tile (phase 4) retires the next tile.  Ordering proof is in DESIGN.md §GEMM.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm.h"
 
@@ -29,7 +31,8 @@ namespace {
 constexpr int BM = 256, BN = 256, BK = 64;
 constexpr int HALF = 128 * BK * 2;          // 16384 B
 constexpr int BUF = 4 * HALF;               // 65536 B: A0 A1 W0 W1
-constexpr int LDS_BYTES = 2 * BUF;          // 131072 B
+constexpr int AUX_OFF = 2 * BUF;            // 8 KiB behind the ring: row statistics
+constexpr int LDS_BYTES = 2 * BUF + 8192;   // 139264 B
 
 #define LDS_PTR(off) ((__attribute__((address_space(3))) void*)(smem + (off)))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -59,7 +62,12 @@ __device__ __forceinline__ void glds16(const char* g, char* smem, int lds_off) {
   __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(lds_off), 16, 0, 0);
 }
 
-template <typename T, int EPI>
+#define STAMP(i)                                                                           \
+  do {                                                                                     \
+    if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+
+template <typename T, int EPI, int IMPL>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
   typedef typename Mfma<T>::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -69,6 +77,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 2, wc = w & 3;
 
+  STAMP(0);
   // ---- tile id: XCD-aware (blocks b, b+8, ... share an L2) + grouped along M ----
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
   const int nwg = tiles_m * tiles_n;
@@ -98,6 +107,45 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
+  // De-synchronise the CUs: every tile costs the same, so without this all 256 workgroups reach their
+  // epilogue together and the output burst (256 x 128 KiB) is HBM-write bound while the MFMAs idle.
+  // The first workgroup of each CU starts after a distinct delay spread over one tile time; later
+  // workgroups inherit the offset because a CU takes its next tile when it finishes the previous one.
+  if (p.stagger_ns > 0 && blockIdx.x < 256) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();           // 100 MHz
+    const unsigned long long wait = ((unsigned long long)((blockIdx.x * 97) & 255) * p.stagger_ns) / 2560;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
+
+  f32x4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15;
+
+  // EPI_LNFOLD: (mean, rstd) of the tile's 256 rows from the producer's per-row partial sums.  The loads
+  // are issued here, ahead of the prologue DMA, and consumed after it (LNFOLD_FINISH) so their latency
+  // hides behind the first stages; the values are read back from LDS in the epilogue.
+  float ln_s = 0.f, ln_ss = 0.f;
+  if constexpr (EPI == EPI_LNFOLD) {
+    if (tid < 256) {
+      const int m = min(m0 + tid, p.M - 1);
+      for (int part = 0; part < p.stats_in_parts; ++part) {
+        const float2 t = *(const float2*)(p.stats_in + ((size_t)part * p.stats_ld + m) * 2);
+        ln_s += t.x; ln_ss += t.y;
+      }
+    }
+  }
+#define LNFOLD_FINISH()                                                                   \
+  if constexpr (EPI == EPI_LNFOLD) {                                                      \
+    if (tid < 256) {                                                                      \
+      const float mean = ln_s * p.inv_width;                                              \
+      const float var = fmaxf(ln_ss * p.inv_width - mean * mean, 0.f);                    \
+      *(float2*)(smem + AUX_OFF + tid * 8) = float2{mean, rsqrtf(var + p.eps)};           \
+    }                                                                                     \
+  }
+  if constexpr (IMPL == 1) {
   // ---- LDS-DMA source offsets (per lane, relative to the tile's first row) ----
   // instruction j of a half-tile fills LDS rows 64j + 8w + (lane>>3); LDS chunk lane&7 holds logical
   // chunk (lane&7) ^ ((row>>1)&7), and (row>>1)&7 == 4*(w&1) + (lane>>4) for both j.
@@ -117,17 +165,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
   const int dma_lds = w * 1024;              // + 8192 for j = 1
 
   // ---- fragment read offsets ----
-  const int frow = lane & 15;
   const int rd0 = frow * 128 + (((lane >> 4) ^ ((frow >> 1) & 7)) << 4);      // k-step 0
   const int rd1 = rd0 ^ 64;                                                   // k-step 1 (chunk + 4)
   const int a_base = wr * HALF;                                               // + buf*BUF + mt*2048
   const int w_base = 2 * HALF + (wc >> 1) * HALF + (wc & 1) * 64 * 128;       // + buf*BUF + nt*2048
 
-  f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   frag_t fa[8], fb0[4], fb1[4];
 
 #define STAGE_A(buf, half, kbyte)                                                            \
@@ -173,7 +215,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
 
   // ---- prologue: tile 0 (4 half-tiles) + W0 of tile 1 ----
   STAGE_A(0, 0, 0); STAGE_A(0, 1, 0); STAGE_W(0, 0, 0); STAGE_W(0, 1, 0);
-  if (nk > 1) { STAGE_W(1, 0, 128); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+  if (nk > 1) STAGE_W(1, 0, 128);
+  LNFOLD_FINISH()
+  if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   BARRIER();
   if (wr == 1) BARRIER();                    // second wave row runs half a phase behind
@@ -209,6 +253,97 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
   }
   if (wr == 0) BARRIER();                    // re-align the two wave rows
 
+  } else {
+
+  // ================= IMPL 2: 4-slot ring of K=32 stages (A part 16 KiB | W part 16 KiB per slot) =================
+  // LDS subtile = 16 rows x 64 B (1 KiB, what one LDS-DMA instruction writes); 16-B chunk c of row r sits at
+  // chunk c ^ (2*(r>>3)) (guide "st_16x32"): every ds_read_b128 fragment read is conflict-free.
+  // Two phases per stage: (a) reads W frags + A frags of m-tiles 0-3, issues the W part of stage t+2;
+  //                       (b) reads A frags of m-tiles 4-7, issues the A part of stage t+3, and retires stage
+  //                           t+1 with ONE counted vmcnt that leaves the 3 youngest parts (6 DMA) in flight.
+  // A slot is re-staged >= 2 phases after its last read; a stage is read >= 1 phase after the wait that
+  // retired it (both with the half-phase stagger of the two wave rows taken into account: DESIGN.md).
+  {
+    constexpr int STG = 32768, WPART = 16384;
+    const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
+    const char* Ablk = (const char*)p.A + (size_t)m0 * lda_b;
+    const char* Wblk = (const char*)p.W + (size_t)n0 * ldw_b;
+    const int lrow = 16 * w + (lane >> 2);
+    const int lchunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
+    int aoff[2], woff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = 128 * j + lrow;
+      const int ra = min(m0 + r, p.M - 1) - m0;
+      aoff[j] = (int)(ra * lda_b) + lchunk * 16;
+      woff[j] = (int)(r * ldw_b) + lchunk * 16;
+    }
+    const int dma_lds = w * 1024;
+    const int rd = frow * 64 + (((lane >> 4) ^ ((frow >> 3) << 1)) << 4);
+    const int a_rd = wr * 8 * 1024 + rd;                 // + slot*STG + mt*1024
+    const int w_rd = WPART + wc * 4 * 1024 + rd;         // + slot*STG + nt*1024
+    frag_t fa[4], fb[4];
+
+#define S2_STAGE_A(slot, kbyte)                                                             \
+  do {                                                                                      \
+    glds16(Ablk + (kbyte) + aoff[0], smem, (slot) * STG + dma_lds);                          \
+    glds16(Ablk + (kbyte) + aoff[1], smem, (slot) * STG + 8192 + dma_lds);                   \
+  } while (0)
+#define S2_STAGE_W(slot, kbyte)                                                             \
+  do {                                                                                      \
+    glds16(Wblk + (kbyte) + woff[0], smem, (slot) * STG + WPART + dma_lds);                  \
+    glds16(Wblk + (kbyte) + woff[1], smem, (slot) * STG + WPART + 8192 + dma_lds);           \
+  } while (0)
+#define S2_LD_W(slot)                                                                       \
+  _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (slot) * STG + w_rd + j * 1024);
+#define S2_LD_A(slot, half)                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (slot) * STG + a_rd + ((half) * 4 + i) * 1024);
+#define S2_MMA(half)                                                                        \
+  do {                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
+      acc[(half) * 4 + i][j] = Mfma<T>::run(fb[j], fa[i], acc[(half) * 4 + i][j]);          \
+    __builtin_amdgcn_s_setprio(0);                                                          \
+  } while (0)
+#define S2_BARRIER() asm volatile("s_barrier" ::: "memory")
+#define S2_WAIT_LDS()                                                                       \
+  do {                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  } while (0)
+#define S2_STAGE(slot, kb)                                                                  \
+  do {                                                                                      \
+    /* phase a */                                                                           \
+    S2_LD_W(slot) __builtin_amdgcn_sched_barrier(0); S2_LD_A(slot, 0)                       \
+    if ((kb) + 128 < kend) S2_STAGE_W(((slot) + 2) & 3, (kb) + 128);                        \
+    S2_BARRIER(); S2_WAIT_LDS(); S2_MMA(0); S2_BARRIER();                                   \
+    /* phase b */                                                                           \
+    S2_LD_A(slot, 1)                                                                        \
+    if ((kb) + 192 < kend) { S2_STAGE_A(((slot) + 3) & 3, (kb) + 192); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } \
+    else if ((kb) + 128 < kend) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+    S2_BARRIER(); S2_WAIT_LDS(); S2_MMA(1); S2_BARRIER();                                   \
+  } while (0)
+
+    const int kend = p.K * 2;                // bytes along K; one stage = 64 B; K % 128 == 0 -> >= 4 stages
+    S2_STAGE_A(0, 0); S2_STAGE_W(0, 0); S2_STAGE_A(1, 64); S2_STAGE_W(1, 64); S2_STAGE_A(2, 128);
+    LNFOLD_FINISH()
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    S2_BARRIER();
+    STAMP(1);
+    if (wr == 1) S2_BARRIER();               // second wave row runs half a phase behind
+    for (int kb = 0; kb < kend; kb += 256) {
+      S2_STAGE(0, kb);
+      S2_STAGE(1, kb + 64);
+      S2_STAGE(2, kb + 128);
+      S2_STAGE(3, kb + 192);
+    }
+    if (wr == 0) S2_BARRIER();               // re-align the two wave rows
+    STAMP(2);
+  }
+  }
+
   // ---------------------------------- epilogue ----------------------------------
   const int q4 = (lane >> 4) * 4;
   const int ncol0 = n0 + wc * 64 + q4;       // + nt*16
@@ -226,95 +361,121 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
         }
       }
     }
-  } else if constexpr (EPI == EPI_STORE_BF16) {
+  } else if constexpr (EPI == EPI_STORE_BF16 || EPI == EPI_LNFOLD || EPI == EPI_RESID) {
+    // bf16 epilogues go through a wave-private 16 KiB LDS tile (the ring is idle: every wave has passed
+    // the final barrier, so all fragment reads and all DMA writes are complete).  A lane holds 4
+    // consecutive columns of 32 different (row, column-group) pairs; written as 8-B pieces into a
+    // [128 rows][128 B] image (16-B chunk index XOR row&7) and read back as whole 16-B chunks, one
+    // store instruction covers 8 full 128-B lines instead of 16 x 32-B fragments (store-issue bound
+    // otherwise: guide T21).  The residual is loaded through the same image in the other direction.
+    char* wl = smem + w * 16384;
+    const int qd = lane >> 4;
+    const int tw_base = frow * 128 + (qd & 1) * 8;                       // + mt*2048 + swizzled chunk
+    const int tw_sw = frow & 7;
+    const int tr_base = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // + k*1024
+    const int row_l = lane >> 3;                                         // + 8k : row inside the wave tile
+    const size_t gcol = (size_t)n0 + wc * 64 + (lane & 7) * 8;
+    const int mw0 = m0 + wr * 128;
+#define TW_ADDR(mt, nt) (wl + (mt) * 2048 + tw_base + ((((nt) * 2 + (qd >> 1)) ^ tw_sw) << 4))
+
+    if constexpr (EPI == EPI_STORE_BF16) {
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      const int m = mrow0 + mt * 16;
-      if (m < p.M) {
+      for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           f32x4_t v = acc[mt][nt];
-          if (p.bias) { f32x4_t b = *(const f32x4_t*)(p.bias + ncol0 + nt * 16); v += b; }
-          uint2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldo + ncol0 + nt * 16) = pk;
+          if (p.bias) { f32x4_t bb = *(const f32x4_t*)(p.bias + ncol0 + nt * 16); v += bb; }
+          *(uint2*)TW_ADDR(mt, nt) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         }
+    } else if constexpr (EPI == EPI_LNFOLD) {
+      // out = act( rstd_m * (acc - mean_m * colsum_n) + bias_n ): LayerNorm folded into the GEMM;
+      // (mean, rstd) of the tile's rows were put in LDS by the prologue.
+      const float2* mr = (const float2*)(smem + AUX_OFF);
+      f32x4_t cs[4], bs[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        cs[nt] = *(const f32x4_t*)(p.colsum + ncol0 + nt * 16);
+        bs[nt] = *(const f32x4_t*)(p.bias + ncol0 + nt * 16);
       }
-    }
-  } else if constexpr (EPI == EPI_LNFOLD) {
-    // out = act( rstd_m * (acc - mean_m * colsum_n) + bias_n ): LayerNorm folded into the GEMM.
-    // mean/rstd come from per-row partial sums (sum, sumsq) left by the producer of A.
-    f32x4_t cs[4], bs[4];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-      cs[nt] = *(const f32x4_t*)(p.colsum + ncol0 + nt * 16);
-      bs[nt] = *(const f32x4_t*)(p.bias + ncol0 + nt * 16);
-    }
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      const int m = mrow0 + mt * 16;
-      if (m < p.M) {
-        float s = 0.f, ss = 0.f;
-        for (int part = 0; part < p.stats_in_parts; ++part) {
-          float2 t = *(const float2*)(p.stats_in + ((size_t)part * p.M + m) * 2);
-          s += t.x; ss += t.y;
-        }
-        const float mean = s * p.inv_width;
-        const float var = fmaxf(ss * p.inv_width - mean * mean, 0.f);
-        const float rstd = rsqrtf(var + p.eps);
+      for (int mt = 0; mt < 8; ++mt) {
+        const float2 t = mr[wr * 128 + mt * 16 + frow];
+        const float mean = t.x, rstd = t.y;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
           f32x4_t v;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             v[e] = act_apply(rstd * (acc[mt][nt][e] - mean * cs[nt][e]) + bs[nt][e], p.act);
-          uint2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *(uint2*)((bf16_t*)p.out + (size_t)m * p.ldo + ncol0 + nt * 16) = pk;
+          *(uint2*)TW_ADDR(mt, nt) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         }
       }
-    }
-  } else if constexpr (EPI == EPI_RESID) {
-    // x_new = acc + bias + resid (bf16, may alias out); also per-row (sum, sumsq) of the ROUNDED x_new
-    // over this tile's 256 columns -> stats_out[tn][m][2] for the next LayerNorm-folded GEMM.
-    float* red = (float*)smem;               // [4 wc][256 rows][2]; LDS is idle after the K loop
-    f32x4_t bs[4];
+    } else {
+      // x_new = acc + bias + resid (bf16, may alias out); also per-row (sum, sumsq) of the ROUNDED x_new
+      // over this tile's 256 columns -> stats_out[tn][m][2] for the next LayerNorm-folded GEMM.
+      float* red = (float*)(smem + AUX_OFF);             // [4 wc][256 rows][2]
+      {
+        uint4 rr[16];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(p.bias + ncol0 + nt * 16);
+        for (int k = 0; k < 16; ++k) {
+          const int m = mw0 + k * 8 + row_l;
+          rr[k] = uint4{0, 0, 0, 0};
+          if (m < p.M) rr[k] = *(const uint4*)((const bf16_t*)p.resid + (size_t)m * p.ldo + gcol);
+        }
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      const int m = mrow0 + mt * 16;
-      float s = 0.f, ss = 0.f;
-      if (m < p.M) {
+        for (int k = 0; k < 16; ++k) *(uint4*)(wl + k * 1024 + tr_base) = rr[k];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      f32x4_t bs[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(p.bias + ncol0 + nt * 16);
+      uint2 pk[8][4];
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        float s = 0.f, ss = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          const size_t off = (size_t)m * p.ldo + ncol0 + nt * 16;
-          uint2 rr = *(const uint2*)((const bf16_t*)p.resid + off);
+          const uint2 rr = *(const uint2*)TW_ADDR(mt, nt);
           f32x4_t v = acc[mt][nt] + bs[nt];
           v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
           v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-          uint2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          *(uint2*)((bf16_t*)p.out + off) = pk;
-          float r0 = __uint_as_float(pk.x << 16), r1 = __uint_as_float(pk.x & 0xffff0000u);
-          float r2 = __uint_as_float(pk.y << 16), r3 = __uint_as_float(pk.y & 0xffff0000u);
+          pk[mt][nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          const float r0 = __uint_as_float(pk[mt][nt].x << 16), r1 = __uint_as_float(pk[mt][nt].x & 0xffff0000u);
+          const float r2 = __uint_as_float(pk[mt][nt].y << 16), r3 = __uint_as_float(pk[mt][nt].y & 0xffff0000u);
           s += (r0 + r1) + (r2 + r3);
           ss += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
         }
+        if (mrow0 + mt * 16 >= p.M) { s = 0.f; ss = 0.f; }
+        s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
+        s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+        if (lane < 16) *(float2*)(red + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane) * 2) = float2{s, ss};
       }
-      s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
-      s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-      if (lane < 16) {
-        const int r = wr * 128 + mt * 16 + lane;
-        *(float2*)(red + ((size_t)wc * 256 + r) * 2) = float2{s, ss};
-      }
-    }
-    __syncthreads();
-    if (tid < 256 && m0 + tid < p.M) {
-      float s = 0.f, ss = 0.f;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of the image done before it is overwritten
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float2 t = *(const float2*)(red + ((size_t)c * 256 + tid) * 2);
-        s += t.x; ss += t.y;
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) *(uint2*)TW_ADDR(mt, nt) = pk[mt][nt];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const uint4 v = *(const uint4*)(wl + k * 1024 + tr_base);
+      const int m = mw0 + k * 8 + row_l;
+      if (m < p.M) *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + gcol) = v;
+    }
+#undef TW_ADDR
+    if constexpr (EPI == EPI_RESID) {
+      const float* red = (const float*)(smem + AUX_OFF);
+      __syncthreads();
+      if (tid < 256 && m0 + tid < p.M) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float2 t = *(const float2*)(red + ((size_t)c * 256 + tid) * 2);
+          s += t.x; ss += t.y;
+        }
+        *(float2*)(p.stats_out + ((size_t)tn * p.stats_ld + m0 + tid) * 2) = float2{s, ss};
       }
-      *(float2*)(p.stats_out + ((size_t)tn * p.M + m0 + tid) * 2) = float2{s, ss};
     }
   } else if constexpr (EPI == EPI_THRESH) {
     // /root/reference/_2_remove_duplicates.py:74: where(triu(S, 1) > threshold) -> (i, j, S[i][j])
@@ -341,9 +502,16 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
       }
     }
   }
+  STAMP(3);
+  if (p.dbg && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    p.dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+    p.dbg[(size_t)blockIdx.x * 8 + 5] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) |
+                                        (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+  }
 }
 
-template <typename T>
+template <typename T, int IMPL>
 hipError_t launch_t(const GemmParams& p, int epi, hipStream_t stream) {
   int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
   if (epi == EPI_THRESH) { const int nt = p.N / BN; tiles = nt * (nt + 1) / 2; }
@@ -352,12 +520,12 @@ hipError_t launch_t(const GemmParams& p, int epi, hipStream_t stream) {
   case E: {                                                                                              \
     static bool attr_set = false;                                                                        \
     if (!attr_set) {                                                                                     \
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<T, E>,                              \
+      hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<T, E, IMPL>,                              \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);         \
       if (e != hipSuccess) return e;                                                                     \
       attr_set = true;                                                                                   \
     }                                                                                                    \
-    hipLaunchKernelGGL((gemm_nt_kernel<T, E>), grid, block, LDS_BYTES, stream, p);                       \
+    hipLaunchKernelGGL((gemm_nt_kernel<T, E, IMPL>), grid, block, LDS_BYTES, stream, p);                       \
     break;                                                                                               \
   }
   switch (epi) {
@@ -386,7 +554,25 @@ hipError_t ce_gemm_nt(const GemmParams& p, int dtype, int epi, hipStream_t strea
   if (epi == EPI_RESID && (!p.bias || !p.resid || !p.stats_out)) return hipErrorInvalidValue;
   if (epi == EPI_THRESH && (!p.tri || p.M != p.N || p.A != p.W || !p.pairs || !p.vals || !p.count || p.n_valid > p.M))
     return hipErrorInvalidValue;
-  if (dtype == CE_DT_BF16) return launch_t<__bf16>(p, epi, stream);
-  if (dtype == CE_DT_F16) return launch_t<_Float16>(p, epi, stream);
+  static const int impl = [] { const char* e = getenv("CLIPENC_GEMM_IMPL"); return e ? atoi(e) : 3; }();
+  static const double stagger = [] { const char* e = getenv("CLIPENC_GEMM_STAGGER"); return e ? atof(e) : 1.0; }();
+  GemmParams q = p;
+  {
+    const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN);
+    // estimated tile time: ~0.8 us per K=32 stage + ~8 us of prologue/epilogue; only worth it with >= 4 tiles per CU
+    q.stagger_ns = (tiles >= 4 * 256 && epi != EPI_THRESH) ? (int)(stagger * (p.K / 32 * 800 + 8000)) : 0;
+  }
+  if ((epi == EPI_LNFOLD || epi == EPI_RESID) && (q.stats_ld < p.M || q.stats_ld % 256 != 0)) return hipErrorInvalidValue;
+  if (impl == 3 && dtype == CE_DT_BF16 && (epi == EPI_STORE_BF16 || epi == EPI_LNFOLD || epi == EPI_RESID)) {
+    if (epi == EPI_LNFOLD && p.stats_in_parts > 4) return hipErrorInvalidValue;
+    return ce_gemm_nt_persist(q, epi, stream);
+  }
+  if (impl == 1) {
+    if (dtype == CE_DT_BF16) return launch_t<__bf16, 1>(q, epi, stream);
+    if (dtype == CE_DT_F16) return launch_t<_Float16, 1>(q, epi, stream);
+  } else {
+    if (dtype == CE_DT_BF16) return launch_t<__bf16, 2>(q, epi, stream);
+    if (dtype == CE_DT_F16) return launch_t<_Float16, 2>(q, epi, stream);
+  }
   return hipErrorInvalidValue;
 }

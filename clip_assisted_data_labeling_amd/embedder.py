@@ -118,6 +118,35 @@ class HipViT:
                                                      _lib.current_stream_ptr(self.device)), "clipenc_debug_run_layers")
         return x
 
+    @torch.no_grad()
+    def encode_score(self, crops: torch.Tensor, regressor, crops_per_image: int, crop_select):
+        """Fused encode + regressor (clipenc_encode_score): returns (emb [n_img, crops, E], score [n_img, out])."""
+        crops, dt = self._check_crops(crops)
+        n = crops.shape[0]
+        if n % crops_per_image:
+            raise ValueError(f"{n} crops is not a multiple of {crops_per_image} crops per image")
+        n_img = n // crops_per_image
+        emb = torch.empty((n_img, crops_per_image, self.cfg.embed_dim), dtype=torch.float32, device=self.device)
+        score = torch.empty((n_img, regressor.sizes[-1]), dtype=torch.float32, device=self.device)
+        sel = (ctypes.c_int * len(crop_select))(*crop_select)
+        _lib.check(self.lib.clipenc_encode_score(self.handle, regressor.handle, crops.data_ptr(), n_img, crops_per_image,
+                                                 dt, sel, len(crop_select), emb.data_ptr(), score.data_ptr(),
+                                                 _lib.current_stream_ptr(self.device)), "clipenc_encode_score")
+        return emb, score
+
+    def profile_enable(self, on: bool) -> None:
+        _lib.check(self.lib.clipenc_profile_enable(self.handle, 1 if on else 0), "clipenc_profile_enable")
+
+    def profile_read(self, reset: bool = True):
+        """{kernel name: (total_ms, launches, algorithmic_flops)} since the last reset."""
+        out = {}
+        for k in range(self.lib.clipenc_profile_kinds()):
+            name = ctypes.c_char_p(); ms = ctypes.c_double(); n = ctypes.c_longlong(); fl = ctypes.c_double()
+            _lib.check(self.lib.clipenc_profile_read(self.handle, k, ctypes.byref(name), ctypes.byref(ms), ctypes.byref(n),
+                                                     ctypes.byref(fl), 1 if reset else 0), "clipenc_profile_read")
+            out[name.value.decode()] = (ms.value, n.value, fl.value)
+        return out
+
     def close(self) -> None:
         if getattr(self, "handle", None):
             self.lib.clipenc_destroy(self.handle)

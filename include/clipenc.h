@@ -105,6 +105,16 @@ int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int
                      void* ehat_ws_dev, long long* pairs_dev, float* vals_dev, unsigned long long capacity,
                      unsigned long long* count_dev, void* stream);
 
+/* Per-kernel timing of the chain behind clipenc_encode / clipenc_encode_score, taken with HIP events on
+ * the caller's stream (used by bench.py for the roofline line).  While enabled, every kernel launch is
+ * bracketed by two events; clipenc_profile_read synchronises them and returns, for kernel kind
+ * 0 <= kind < clipenc_profile_kinds(): its name, summed duration, launch count and the ALGORITHMIC
+ * FLOPs (unpadded tokens / K) of those launches. */
+int clipenc_profile_enable(clipenc_t enc, int on);
+int clipenc_profile_kinds(void);
+int clipenc_profile_read(clipenc_t enc, int kind, const char** name, double* total_ms, long long* launches,
+                         double* algorithmic_flops, int reset);
+
 /* Operator-level entry points (used by the parity tests to pin each kernel on its own). */
 #define CLIPENC_DT_BF16 0
 #define CLIPENC_DT_F16 1
@@ -113,6 +123,10 @@ int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int
 /* out[M][N] = A[M][K] . W[N][K]^T (+ bias[N]); A, W 16-bit row-major; N % 256 == 0, K % 128 == 0 */
 int clipenc_op_gemm_nt(const void* a_dev, const void* w_dev, int m, int n, int k, int dtype, int epi,
                        const float* bias_dev, void* out_dev, void* stream);
+/* Diagnostic: bf16-store GEMM that also writes, per workgroup, 100 MHz timestamps
+ * {entry, prologue done, main loop done, stores issued, stores retired, hw id} into stamps_dev[tiles][8]. */
+int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n, int k, void* out_dev,
+                              unsigned long long* stamps_dev, void* stream);
 /* qkv bf16 [n_crops*n_tok][3*width] -> out bf16 [n_crops*n_tok][width]; head dim 64, n_tok <= 288 */
 int clipenc_op_attention(const void* qkv_dev, void* out_dev, int n_crops, int n_tok, int width, int heads,
                          void* stream);
