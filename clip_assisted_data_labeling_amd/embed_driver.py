@@ -1,0 +1,183 @@
+"""Embed driver: the counterpart of /root/reference/_1_embed_with_CLIP.py (`Feature_Dataset`, CLI).
+
+Same flags (:187-197), same file discovery (:47, :54-58), same `<image_basename>.pt` store
+(`{model_name: {crop_name: float32[1,E]}}`, several models merged per file,
+:136-168) and the same skip-if-already-embedded rule (:117-128), written the way the downstream readers
+(_5_predict_labels.py:79, _2_remove_duplicates.py:38) expect it: every image gets ALL of its crop keys,
+each holding that image's own crop embedding (the reference's writer mis-keys them for batch sizes
+above one; that defect is not reproduced).  The 22 `img_stat_*` scalars of
+utils/image_features.py are not produced (never consumed: _4_train_model.py:274).
+
+Differences that matter for speed: the resume check happens BEFORE images are decoded, per image
+rather than per batch; with torch.distributed initialised, each rank embeds a contiguous shard of the
+sorted file list (clip_assisted_data_labeling_amd/sharding.py) on its own GPU.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import random
+from typing import List, Optional, Sequence
+
+import torch
+from PIL import Image
+from torch.utils.data import DataLoader, Dataset
+
+from .preprocess import CROP_NAMES, extract_crops
+from .sharding import shard_list
+
+IMG_EXTENSIONS = (".png", ".jpg", ".jpeg", ".JPEG", ".JPG", ".PNG")      # _1_embed_with_CLIP.py:47
+
+
+class CustomImageDataset(Dataset):
+    """utils/embedder.py:153-181: path -> (crops[n_crops,3,R,R], crop_names, path)."""
+
+    def __init__(self, image_paths: Sequence[str], crop_names: Sequence[str], preprocess_transform):
+        self.image_paths = list(image_paths)
+        self.crop_names = list(crop_names)
+        self.preprocess_transform = preprocess_transform
+
+    def __len__(self):
+        return len(self.image_paths)
+
+    def __getitem__(self, idx):
+        img_path = self.image_paths[idx]
+        try:
+            pil_img = Image.open(img_path).convert("RGB")
+            raw_crops, names = extract_crops(pil_img, self.crop_names)
+            crops = torch.stack([self.preprocess_transform(c) for c in raw_crops])
+            return crops, ",".join(names), img_path, True
+        except Exception as e:  # unreadable image: report it, never substitute another one (Appendix D #4)
+            print(f"Error loading or processing image {img_path}: {e}")
+            return torch.zeros(0), "", img_path, False
+
+
+def _collate(batch):
+    ok = [b for b in batch if b[3]]
+    bad = [b[2] for b in batch if not b[3]]
+    return ok, bad
+
+
+def find_images(root_dir: str) -> List[str]:
+    paths = []
+    for root, _, files in os.walk(root_dir):
+        for name in files:
+            if name.endswith(IMG_EXTENSIONS):
+                paths.append(os.path.join(root, name))
+    return paths
+
+
+def already_embedded(feature_path: str, model_name: str) -> bool:
+    if not os.path.exists(feature_path):
+        return False
+    try:
+        return model_name in torch.load(feature_path, map_location="cpu", weights_only=True)
+    except Exception as e:
+        print(f"Warning: Could not load existing feature file {feature_path}: {e}")
+        return False
+
+
+class Feature_Dataset:
+    def __init__(self, root_dir, model_name, batch_size, model_path=None, force_reencode=False,
+                 shuffle_filenames=True, num_workers=0, crop_names=None, encoder=None, device="cuda"):
+        self.device = device
+        self.root_dir = root_dir
+        self.model_name = model_name
+        self.force_reencode = force_reencode
+        self.batch_size = batch_size
+        self.crop_names = list(crop_names) if crop_names is not None else list(CROP_NAMES)
+        print("Searching images..")
+        self.img_filepaths = find_images(root_dir)
+        dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+        if shuffle_filenames and not dist_on:
+            random.shuffle(self.img_filepaths)             # :60-61 (unseeded, single process only)
+        else:
+            self.img_filepaths.sort()
+        print(f"---> Found {len(self.img_filepaths)} images in {root_dir}")
+        if dist_on:                                        # one process per GPU: contiguous shard of the sorted list
+            self.img_filepaths = shard_list(self.img_filepaths, torch.distributed.get_rank(),
+                                            torch.distributed.get_world_size())
+        if encoder is not None:
+            self.encoder = encoder
+        elif "/" in model_name:
+            from .embedder import CLIP_Encoder
+            self.encoder = CLIP_Encoder(model_name, model_path, device=self.device)
+        else:
+            raise ValueError(f"Unknown model format: {model_name}. Expected 'Arch/Dataset'.")     # :75
+        self.preprocess = self.encoder.get_preprocess_transform()
+        self.num_workers = num_workers
+
+    def __len__(self):
+        return len(self.img_filepaths)
+
+    @torch.no_grad()
+    def process(self):
+        n_embedded, n_skipped, n_failed = 0, 0, 0
+        print(f"Embedding dataset of {len(self.img_filepaths)} images using {self.model_name}...")
+        todo = []
+        for p in self.img_filepaths:                       # resume check first: nothing is decoded for done images
+            fp = os.path.splitext(p)[0] + ".pt"
+            if not self.force_reencode and already_embedded(fp, self.model_name):
+                n_skipped += 1
+            else:
+                todo.append(p)
+        kwargs = dict(batch_size=self.batch_size, shuffle=False, num_workers=self.num_workers, collate_fn=_collate)
+        if self.num_workers > 0:
+            kwargs["prefetch_factor"] = 2
+        loader = DataLoader(CustomImageDataset(todo, self.crop_names, self.preprocess), **kwargs)
+        for ok, bad in loader:
+            n_failed += len(bad)
+            if not ok:
+                continue
+            counts = [b[0].shape[0] for b in ok]
+            stacked = torch.cat([b[0] for b in ok], 0).to(self.device)      # [sum crops, 3, R, R], row = image-major
+            features = self.encoder.encode_image(stacked).float().cpu()    # :130
+            row = 0
+            for (crops, names, img_path, _), n in zip(ok, counts):
+                feature_save_path = os.path.splitext(img_path)[0] + ".pt"
+                final = {}
+                if os.path.exists(feature_save_path) and not self.force_reencode:
+                    try:
+                        final = torch.load(feature_save_path, map_location="cpu", weights_only=True)
+                    except Exception as e:
+                        print(f"Warning: Failed to load existing {feature_save_path} for update: {e}")
+                per_model = {}
+                for j, crop_name in enumerate(names.split(",")):
+                    per_model[crop_name] = features[row + j].unsqueeze(0).clone()       # float32 [1, E] on CPU (:157-161)
+                row += n
+                final[self.model_name] = per_model                                     # :164
+                try:
+                    torch.save(final, feature_save_path)
+                except Exception as e:
+                    print(f"Error saving features to {feature_save_path}: {e}")
+                n_embedded += 1
+        print("\n--- Feature encoding done! ---\n")
+        print(f"Embedded {n_embedded} images ({n_skipped} images were already embedded, {n_failed} unreadable). "
+              f"Features saved with model key '{self.model_name}'.")
+        return n_embedded, n_skipped, n_failed
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--root_dir", type=str, required=True, help="Root directory of the dataset (can contain subdirectories)")
+    parser.add_argument("--models_to_use", type=str, nargs="+", default=["ViT-L-14/openai"],
+                        help="Which CLIP models to use, '<arch>/<pretrained>'")
+    parser.add_argument("--batch_size", type=int, default=128, help="Number of images to encode at once")
+    parser.add_argument("--num_workers", type=int, default=4, help="Number of workers for the dataloader")
+    parser.add_argument("--force_reencode", action="store_true", help="Force re-encoding of all images for the specified models")
+    parser.add_argument("--model_path", type=str, default=None, help="Local directory (or file) holding the model weights")
+    args = parser.parse_args(argv)
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        torch.distributed.init_process_group("nccl")
+    device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda"
+    print(f"Embedding all imgs with {len(args.models_to_use)} models: \n--> {args.models_to_use}")
+    for model_name in args.models_to_use:
+        print(f"\n--- Processing model: {model_name} ---")
+        Feature_Dataset(args.root_dir, model_name, args.batch_size, model_path=args.model_path,
+                        force_reencode=args.force_reencode, num_workers=args.num_workers, crop_names=CROP_NAMES,
+                        device=device).process()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,89 @@
+"""Host logic of the drivers on CPU: file discovery, `.pt` schema, resume rule, feature assembly.
+The encoder is replaced by a test double here; the real HIP path is exercised in test_gpu_drivers.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+from clip_assisted_data_labeling_amd import embed_driver, predict_driver
+from clip_assisted_data_labeling_amd.preprocess import CROP_NAMES, ClipValTransform
+
+
+class FakeEncoder:
+    """Deterministic stand-in: embedding = per-crop mean colour statistics (3 numbers, normalised)."""
+    img_resolution = 32
+
+    def __init__(self):
+        self.calls = 0
+
+    def get_preprocess_transform(self):
+        return ClipValTransform(32)
+
+    def encode_image(self, x):
+        self.calls += 1
+        f = x.float().mean(dim=(2, 3)) + torch.tensor([0.1, 0.2, 0.3])
+        return f / f.norm(dim=-1, keepdim=True)
+
+
+def _make_images(root, n, seed=0):
+    rs = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, "sub"), exist_ok=True)
+    paths = []
+    for i in range(n):
+        w, h = rs.randint(40, 90), rs.randint(40, 90)
+        p = os.path.join(root, "sub" if i % 2 else "", f"img{i:03d}" + (".jpg" if i % 3 else ".PNG"))
+        Image.fromarray(rs.randint(0, 256, (h, w, 3), dtype=np.uint8)).save(p)
+        paths.append(p)
+    open(os.path.join(root, "notes.txt"), "w").write("x")
+    open(os.path.join(root, "broken.jpg"), "wb").write(b"not an image")
+    return paths
+
+
+def test_embed_driver_schema_resume_and_merge(tmp_path):
+    root = str(tmp_path / "data")
+    os.makedirs(root)
+    paths = _make_images(root, 7)
+    enc = FakeEncoder()
+    ds = embed_driver.Feature_Dataset(root, "Fake-A/test", 3, shuffle_filenames=False, encoder=enc, device="cpu")
+    assert len(ds) == 8                                     # 7 images + broken.jpg; notes.txt ignored
+    n_emb, n_skip, n_fail = ds.process()
+    assert (n_emb, n_skip, n_fail) == (7, 0, 1)
+    for p in paths:
+        d = torch.load(os.path.splitext(p)[0] + ".pt", weights_only=True)      # plain tensors/strs only
+        assert list(d) == ["Fake-A/test"]
+        assert list(d["Fake-A/test"]) == CROP_NAMES           # every image has all four crop keys
+        for c in CROP_NAMES:
+            t = d["Fake-A/test"][c]
+            assert t.shape == (1, 3) and t.dtype == torch.float32
+        # each key holds THAT crop of THAT image (the reference's B>=2 mis-keying is not reproduced)
+        from clip_assisted_data_labeling_amd.preprocess import extract_crops
+        crops, _ = extract_crops(Image.open(p).convert("RGB"))
+        ref = enc.encode_image(torch.stack([ClipValTransform(32)(c) for c in crops]))
+        got = torch.cat([d["Fake-A/test"][c] for c in CROP_NAMES])
+        assert torch.allclose(got, ref, atol=1e-6)
+    assert not os.path.exists(os.path.join(root, "broken.pt"))
+    # resume: nothing is re-encoded, nothing is decoded
+    calls = enc.calls
+    assert embed_driver.Feature_Dataset(root, "Fake-A/test", 3, shuffle_filenames=False, encoder=enc, device="cpu").process()[:2] == (0, 7)
+    assert enc.calls == calls
+    # a second model merges into the same files; --force_reencode rewrites
+    embed_driver.Feature_Dataset(root, "Fake-B/test", 4, shuffle_filenames=False, encoder=enc, device="cpu").process()
+    d = torch.load(os.path.splitext(paths[0])[0] + ".pt", weights_only=True)
+    assert set(d) == {"Fake-A/test", "Fake-B/test"}
+    assert embed_driver.Feature_Dataset(root, "Fake-A/test", 8, force_reencode=True, shuffle_filenames=False,
+                                        encoder=enc, device="cpu").process()[0] == 7
+    with pytest.raises(ValueError):
+        embed_driver.Feature_Dataset(root, "no-slash-name", 2)
+
+
+def test_feature_assembly_order(tmp_path):
+    E = 4
+    d = {"M1/x": {c: torch.full((1, E), float(i)) for i, c in enumerate(CROP_NAMES)},
+         "M2/y": {c: torch.full((1, E), 10.0 + i) for i, c in enumerate(CROP_NAMES)}}
+    p = str(tmp_path / "u.pt")
+    torch.save(d, p)
+    f = predict_driver.assemble_features(p, ["M2/y", "M1/x"], ["subcrop2", "centre_crop", "missing_crop"])
+    assert f.tolist() == [13.0] * E + [10.0] * E + [3.0] * E + [0.0] * E     # [model][crop in crop_names order][E]
+    assert predict_driver.find_model("nope", str(tmp_path)) is None

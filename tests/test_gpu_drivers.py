@@ -1,0 +1,94 @@
+"""End-to-end drivers on the GPU: embed -> .pt store -> predict -> CSV/JSON/previews; dedup on the store."""
+import json
+import os
+import types
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+from PIL import Image
+
+from clip_assisted_data_labeling_amd import dedup_driver, embed_driver, predict_driver, vit_config
+from clip_assisted_data_labeling_amd.nn_model import SimpleFC
+from clip_assisted_data_labeling_amd.preprocess import CROP_NAMES, ClipValTransform, extract_crops
+from oracle import fcreg_oracle, vit_oracle
+from tests.helpers import np_fc_weights, one_minus_cos
+
+pytestmark = pytest.mark.gpu
+MODEL = "ViT-small-test/seed4"
+
+
+def _dataset(root, n):
+    rs = np.random.RandomState(3)
+    os.makedirs(root)
+    for i in range(n):
+        w, h = rs.randint(100, 200), rs.randint(100, 200)
+        arr = rs.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        if i == n - 1:                                  # exact duplicate of image 0 under another name
+            arr = np.asarray(Image.open(os.path.join(root, "a000.jpg")))
+        Image.fromarray(arr).save(os.path.join(root, f"a{i:03d}.jpg"), quality=95)
+    with open(os.path.join(root, "a001.json"), "w") as f:
+        json.dump({"prompt": "x"}, f)
+
+
+def test_embed_predict_dedup_pipeline(gpu, tmp_path):
+    root = str(tmp_path / "imgs")
+    _dataset(root, 9)
+    ds = embed_driver.Feature_Dataset(root, MODEL, 4, shuffle_filenames=False, num_workers=0, device="cuda")
+    assert ds.process() == (9, 0, 0)
+    cfg = vit_config.config_for(MODEL)
+    sd = vit_config.seeded_state_dict(cfg, 4)
+    # stored embeddings == oracle on the same crops
+    img = Image.open(os.path.join(root, "a003.jpg")).convert("RGB")
+    crops, names = extract_crops(img)
+    ref = vit_oracle.encode_image(sd, cfg, torch.stack([ClipValTransform(cfg.image_size)(c) for c in crops]))
+    d = torch.load(os.path.join(root, "a003.pt"), weights_only=True)[MODEL]
+    got = torch.cat([d[c] for c in CROP_NAMES])
+    assert got.shape == (4, cfg.embed_dim) and one_minus_cos(got, ref).max().item() < 1e-3
+
+    # regressor checkpoint in the reference's pickle format, then the predict driver
+    sizes = [2 * cfg.embed_dim, 32, 16, 8, 1]
+    Ws, bs = np_fc_weights(sizes, 5)
+    m = SimpleFC(sizes[0], sizes[1:-1], 1, clip_models=[MODEL], crop_names=["centre_crop", "subcrop1"], dropout_prob=0.3)
+    with torch.no_grad():
+        for layer, W, b in zip(m._linears(), Ws, bs):
+            layer.weight.copy_(torch.from_numpy(W)); layer.bias.copy_(torch.from_numpy(b))
+    os.makedirs(tmp_path / "models")
+    torch.save(m, tmp_path / "models" / "unit_test_regressor.pth")
+    args = types.SimpleNamespace(root_dir=root, model_file=str(tmp_path / "models" / "unit_test_regressor.pth"),
+                                 batch_size=4, copy_imgs_fraction=1.0, num_workers=0)
+    db = predict_driver.predict_labels(args)
+    csv = pd.read_csv(str(tmp_path / "imgs.csv"))
+    assert list(csv.columns) == ["uuid", "label", "timestamp", "predicted_label"] and len(csv) == 9
+    for uuid in ("a000", "a005"):
+        dd = torch.load(os.path.join(root, uuid + ".pt"), weights_only=True)[MODEL]
+        feat = torch.cat([dd["centre_crop"], dd["subcrop1"]], 0).flatten().numpy()[None]
+        want = fcreg_oracle.forward_c(Ws, bs, feat)[0, 0]
+        have = float(csv.loc[csv.uuid == uuid, "predicted_label"].iloc[0])
+        assert abs(have - want) < 1e-4
+    assert json.load(open(os.path.join(root, "a001.json")))["predicted_label"] == pytest.approx(
+        float(csv.loc[csv.uuid == "a001", "predicted_label"].iloc[0]), abs=1e-6)
+    previews = os.listdir(root + "_predicted_scores")
+    assert len(previews) == 9 and all(p[5] == "_" and p.endswith(".jpg") for p in previews)
+    # second run updates in place (new value overrides), no duplicate rows
+    predict_driver.predict_labels(args)
+    assert len(pd.read_csv(str(tmp_path / "imgs.csv"))) == 9
+
+    # dedup on the store: (a seeded-random tiny tower maps noise images close together, so the threshold is
+    # set from the data) the planted duplicate (a000, a008) must be reported, in row-major (i < j) order
+    embs = torch.stack([torch.load(os.path.join(root, f"a{i:03d}.pt"), weights_only=True)[MODEL]["square_padded_crop"][0]
+                        for i in range(9)]).half().float()
+    embs = embs / embs.norm(dim=1, keepdim=True)
+    sim = (embs @ embs.T).fill_diagonal_(0)
+    assert sim[0, 8] == sim.max()
+    others = sim.clone(); others[0, 8] = others[8, 0] = 0
+    thr = float((others.max() + sim[0, 8]) / 2)
+    dargs = types.SimpleNamespace(root_dir=root, threshold=thr, mode="copy", clip_model_to_use=None, chunk_size=10000, test=True)
+    found = dedup_driver.find_near_duplicates(dargs)
+    assert [(os.path.basename(a), os.path.basename(b)) for a, b, _ in found] == [("a000.jpg", "a008.jpg")]
+    assert abs(found[0][2] - float(sim[0, 8])) < 1e-3
+    dargs.test = False
+    dedup_driver.find_near_duplicates(dargs)
+    out = os.listdir(str(tmp_path / f"near_duplicates_cosine_{thr}"))
+    assert any("_source_a000.jpg" in f for f in out) and any("_target_a008.pt" in f for f in out)

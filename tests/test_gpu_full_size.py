@@ -1,0 +1,53 @@
+"""ViT-L/14 at BASELINE.json sizes: parity with the oracle on a sample the CPU finishes in seconds, and
+size-independent properties (determinism, unit norm, batch/chunk/order invariance) on a full chunk."""
+import numpy as np
+import pytest
+import torch
+
+from clip_assisted_data_labeling_amd import vit_config
+from clip_assisted_data_labeling_amd.embedder import HipViT
+from oracle import vit_oracle
+from tests.helpers import one_minus_cos, synthetic_crops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def vit_l14(gpu):
+    cfg = vit_config.ARCHS["ViT-L-14"]
+    sd = vit_config.seeded_state_dict(cfg, 0)
+    vit = HipViT(cfg, sd, gpu)
+    yield cfg, sd, vit
+    vit.close()
+
+
+def test_vit_l14_matches_fp32_oracle(vit_l14, gpu):
+    cfg, sd, vit = vit_l14
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    crops = synthetic_crops(6, 224, 77)
+    ref = vit_oracle.encode_image(sd, cfg, crops)
+    got = vit.encode(crops.to(gpu)).cpu()
+    omc = one_minus_cos(got, ref)
+    assert omc.max().item() < 1e-3, omc            # north_star: embeddings within 1e-3 cosine of the fp32 CPU path
+    assert (got - ref).abs().max().item() < 0.02
+
+
+def test_vit_l14_properties_at_batch_size(vit_l14, gpu):
+    cfg, _, vit = vit_l14
+    n = 512                                         # 128 images x 4 crops; 131 584 token rows, 514 M-tiles
+    g = torch.Generator(device=gpu).manual_seed(5)
+    crops = torch.randn(n, 3, 224, 224, device=gpu, generator=g)
+    crops[7] = crops[300]                           # duplicate crop
+    e1 = vit.encode(crops)
+    assert e1.shape == (n, 768) and torch.isfinite(e1).all()
+    assert torch.allclose(e1.norm(dim=-1), torch.ones(n, device=gpu), atol=1e-5)
+    assert torch.equal(e1, vit.encode(crops))                       # bitwise deterministic
+    assert torch.equal(e1[7], e1[300])                              # a crop's embedding does not depend on its row
+    rev = vit.encode(crops.flip(0)).flip(0)
+    assert one_minus_cos(e1.cpu(), rev.cpu()).max().item() < 1e-6   # order equivariance
+    vit.set_chunk(255)                                              # 255 + 255 + 2 crops per pass
+    chunked = vit.encode(crops)
+    vit.set_chunk(2048)
+    assert one_minus_cos(e1.cpu(), chunked.cpu()).max().item() < 1e-6
+    cs = (e1[:256] @ e1[:256].T).cpu()
+    assert cs.fill_diagonal_(0).abs().max().item() < 0.999          # distinct inputs stay distinct
