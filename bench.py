@@ -164,7 +164,9 @@ def main():
                          "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
                          "launches": d_n, "avg_launch_ms": round(d_ms / max(d_n, 1), 4),
                          "algorithmic_flop_per_launch": d_fl / max(d_n, 1)},
-            "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items()},
+            "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items() if not k.startswith("shape:")},
+            "gemm_shapes_tflops": {k[6:]: round(v[2] / (v[0] * 1e-3) / 1e12, 1) for k, v in prof.items()
+                                   if k.startswith("shape:") and v[0] > 0},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, Ws, bs)

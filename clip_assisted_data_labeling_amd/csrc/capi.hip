@@ -63,12 +63,14 @@ struct LayerDev {
 
 }  // namespace
 
-enum { PK_PATCHIFY = 0, PK_GEMM_PATCH, PK_EMBED_LN_PRE, PK_GEMM_LNFOLD, PK_ATTENTION, PK_GEMM_RESID, PK_HEAD, PK_FCREG, PK_COUNT };
+enum { PK_PATCHIFY = 0, PK_GEMM_PATCH, PK_EMBED_LN_PRE, PK_GEMM_LNFOLD, PK_ATTENTION, PK_GEMM_RESID, PK_HEAD, PK_FCREG,
+       PK_SUB_QKV, PK_SUB_FC1, PK_SUB_OUT, PK_SUB_FC2, PK_COUNT };   // PK_SUB_*: the same launches split by shape
 static const char* const kProfileNames[PK_COUNT] = {
     "patchify_kernel", "gemm_nt_kernel<bf16,EPI_STORE_BF16>", "embed_ln_pre_kernel", "gemm_nt_kernel<bf16,EPI_LNFOLD>",
-    "attn_kernel", "gemm_nt_kernel<bf16,EPI_RESID>", "head_kernel", "fcreg_kernel"};
+    "attn_kernel", "gemm_nt_kernel<bf16,EPI_RESID>", "head_kernel", "fcreg_kernel",
+    "shape:qkv(EPI_LNFOLD)", "shape:fc1(EPI_LNFOLD)", "shape:out_proj(EPI_RESID)", "shape:fc2(EPI_RESID)"};
 
-struct ProfRec { int kind; hipEvent_t a, b; double flops; };
+struct ProfRec { int kind, sub; hipEvent_t a, b; double flops; };
 
 struct Profiler {
   bool on = false;
@@ -82,9 +84,9 @@ struct Profiler {
     (void)hipEventCreate(&e);
     return e;
   }
-  void begin(int kind, double fl, hipStream_t st) {
+  void begin(int kind, double fl, hipStream_t st, int sub = -1) {
     if (!on) return;
-    ProfRec r{kind, get(), get(), fl};
+    ProfRec r{kind, sub, get(), get(), fl};
     (void)hipEventRecord(r.a, st);
     recs.push_back(r);
   }
@@ -96,7 +98,10 @@ struct Profiler {
     for (auto& r : recs) {
       (void)hipEventSynchronize(r.b);
       float t = 0.f;
-      if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.kind] += t; flops[r.kind] += r.flops; launches[r.kind]++; }
+      if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+        ms[r.kind] += t; flops[r.kind] += r.flops; launches[r.kind]++;
+        if (r.sub >= 0) { ms[r.sub] += t; flops[r.sub] += r.flops; launches[r.sub]++; }
+      }
       pool.push_back(r.a); pool.push_back(r.b);
     }
     recs.clear();
@@ -191,7 +196,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     q.A = e->x; q.lda = g.width; q.W = L.w_qkv; q.ldw = g.width; q.M = T; q.N = 3 * g.width; q.K = g.width;
     q.out = e->qkv; q.ldo = 3 * g.width; q.bias = L.b_qkv; q.colsum = L.cs_qkv;
     q.stats_in = stats_in; q.stats_in_parts = stats_parts; q.stats_ld = Tp; q.inv_width = 1.0f / g.width; q.eps = g.ln_eps; q.act = -1;
-    pf.begin(PK_GEMM_LNFOLD, 2.0 * dT * 3.0 * dD * dD, st);
+    pf.begin(PK_GEMM_LNFOLD, 2.0 * dT * 3.0 * dD * dD, st, PK_SUB_QKV);
     HIP_TRY(ce_gemm_nt(q, CE_DT_BF16, EPI_LNFOLD, st));
     pf.end(st);
     // K4
@@ -202,7 +207,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     GemmParams o{};
     o.A = e->attn; o.lda = g.width; o.W = L.w_out; o.ldw = g.width; o.M = T; o.N = g.width; o.K = g.width;
     o.out = e->x; o.ldo = g.width; o.bias = L.b_out; o.resid = e->x; o.stats_out = e->stats_a; o.stats_ld = Tp;
-    pf.begin(PK_GEMM_RESID, 2.0 * dT * dD * dD, st);
+    pf.begin(PK_GEMM_RESID, 2.0 * dT * dD * dD, st, PK_SUB_OUT);
     HIP_TRY(ce_gemm_nt(o, CE_DT_BF16, EPI_RESID, st));
     pf.end(st);
     // K6: h = act(LN2(x) . Wfc^T + b)
@@ -210,14 +215,14 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     f.A = e->x; f.lda = g.width; f.W = L.w_fc; f.ldw = g.width; f.M = T; f.N = g.mlp_dim; f.K = g.width;
     f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
     f.stats_in = e->stats_a; f.stats_in_parts = parts; f.stats_ld = Tp; f.inv_width = 1.0f / g.width; f.eps = g.ln_eps; f.act = g.act;
-    pf.begin(PK_GEMM_LNFOLD, 2.0 * dT * dD * g.mlp_dim, st);
+    pf.begin(PK_GEMM_LNFOLD, 2.0 * dT * dD * g.mlp_dim, st, PK_SUB_FC1);
     HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
     pf.end(st);
     // K7: x += h . Wproj^T + b
     GemmParams r{};
     r.A = e->hid; r.lda = g.mlp_dim; r.W = L.w_proj; r.ldw = g.mlp_dim; r.M = T; r.N = g.width; r.K = g.mlp_dim;
     r.out = e->x; r.ldo = g.width; r.bias = L.b_proj; r.resid = e->x; r.stats_out = e->stats_b; r.stats_ld = Tp;
-    pf.begin(PK_GEMM_RESID, 2.0 * dT * dD * g.mlp_dim, st);
+    pf.begin(PK_GEMM_RESID, 2.0 * dT * dD * g.mlp_dim, st, PK_SUB_FC2);
     HIP_TRY(ce_gemm_nt(r, CE_DT_BF16, EPI_RESID, st));
     pf.end(st);
     stats_in = e->stats_b; stats_parts = parts;
