@@ -1,5 +1,6 @@
 // Multi-head self-attention of the ViT tower (K4 of SURVEY.md §2.2): per (crop, head)
-//   O = softmax(Q K^T / sqrt(64)) V,  no mask, n_tok <= 32*NKT keys, head dim 64.
+//   O = softmax(Q K^T / sqrt(64)) V,  no mask, head dim 64; n_tok <= 288 in one pass (attn_kernel),
+//   up to 640 tokens with key chunks + online softmax (attn_long_kernel).
 // This is the nn.MultiheadAttention step of the open_clip forward the reference reaches through
 // /root/reference/utils/embedder.py:98.
 //
@@ -146,6 +147,160 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Long-sequence variant (n_tok > 288, e.g. ViT-L-14-336: 577 tokens — the reference's default model,
+// /root/reference/_1_embed_with_CLIP.py:190).  Same LDS images and MFMA orientation; the keys are walked
+// in chunks of CT tiles with an online softmax (running max m, running sum l, O rescaled when m grows),
+// because 19 x 16 score registers no longer fit the register file.  8 waves, one workgroup per CU
+// (K and V of one head take up to 152 KiB of LDS).
+// ---------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                           int n_tok, int width, int heads, float scale_log2e, int nkt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int rows = nkt * 32;
+  char* Ks = smem;
+  char* Vs = smem + rows * 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int crop = blockIdx.x / heads, head = blockIdx.x % heads;
+  const size_t ld = (size_t)3 * width;
+  const bf16_t* base = qkv + (size_t)crop * n_tok * ld + head * 64;
+
+  for (int idx = tid; idx < rows * 8; idx += 512) {
+    const int row = idx >> 3, c = idx & 7;
+    uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+    if (row < n_tok) {
+      const bf16_t* g = base + (size_t)row * ld + c * 8;
+      kv = *(const uint4*)(g + width);
+      vv = *(const uint4*)(g + 2 * width);
+    }
+    *(uint4*)(Ks + k_swz(row, c)) = kv;
+    *(uint4*)(Vs + v_swz(row, c)) = vv;
+  }
+  __syncthreads();
+
+  const int r = lane & 31, h = lane >> 5;
+  const int n_qb = (n_tok + 31) >> 5;
+  for (int qb = wave; qb < n_qb; qb += 8) {
+    const int q = qb * 32 + r;
+    const bf16_t* qrow = base + (size_t)min(q, n_tok - 1) * ld;
+    bf16x8_t qf[4];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qrow + st * 16 + h * 8);
+
+    f32x16_t o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+    float m_run = -INFINITY, lsum = 0.f;
+
+    for (int kt0 = 0; kt0 < nkt; kt0 += CT) {
+      // ---- scores of this chunk ----
+      f32x16_t s[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[c][e] = -INFINITY;
+        if (kt0 + c < nkt) {                                  // wave-uniform
+#pragma unroll
+          for (int e = 0; e < 16; ++e) s[c][e] = 0.f;
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            bf16x8_t kf = *(const bf16x8_t*)(Ks + k_swz((kt0 + c) * 32 + r, st * 2 + h));
+            s[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[c], 0, 0, 0);
+          }
+          if (kt0 + c == nkt - 1) {                           // the last key tile may be partial
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int key = (kt0 + c) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              if (key >= n_tok) s[c][e] = -INFINITY;
+            }
+          }
+        }
+      }
+      float mx = m_run;
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[c][e]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));                     // finite: every chunk holds >= 1 valid key
+      const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);   // 0 on the first chunk
+      m_run = mx;
+      const float moff = mx * scale_log2e;
+      lsum *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+
+      // ---- P of this chunk and O^T += V^T . P^T ----
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if (kt0 + c < nkt) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            if (kt0 + c < nkt - 1 || s2 == 0 || (kt0 + c) * 32 + 16 < n_tok) {
+              bf16x8_t pf;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float pv = __builtin_amdgcn_exp2f(fmaf(s[c][s2 * 8 + j], scale_log2e, -moff));
+                const __bf16 pb = (__bf16)pv;
+                lsum += (float)pb;
+                pf[j] = pb;
+              }
+              const int key0 = (kt0 + c) * 32 + s2 * 16 + 4 * h;
+#pragma unroll
+              for (int dt = 0; dt < 2; ++dt) {
+                const int i = lane & 15, qq = i >> 2, pp = i & 3, g1 = (lane >> 4) & 1;
+                const int dcol = dt * 32 + g1 * 16 + pp * 4;
+                const int ra = key0 + qq, rb = key0 + 8 + qq;
+                s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(ra, dcol >> 3) + (dcol & 7) * 2));
+                s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(rb, dcol >> 3) + (dcol & 7) * 2));
+                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+                s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, o[dt], 0, 0, 0);
+              }
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    lsum += __shfl_xor(lsum, 32);
+    const float inv = 1.0f / lsum;
+    if (q < n_tok) {
+      bf16_t* orow = out + ((size_t)crop * n_tok + q) * width + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          uint2 pk = {pack_bf16x2(o[dt][g4 * 4 + 0] * inv, o[dt][g4 * 4 + 1] * inv),
+                      pack_bf16x2(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv)};
+          *(uint2*)(orow + dt * 32 + g4 * 8 + h * 4) = pk;
+        }
+    }
+  }
+}
+
+hipError_t launch_attn_long(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
+                            hipStream_t stream) {
+  constexpr int CT = 7;
+  const int nkt = (n_tok + 31) / 32;
+  const int lds = nkt * 32 * 128 * 2;
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  hipError_t e = hipFuncSetAttribute((const void*)attn_long_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return e;
+  const float scale_log2e = 0.125f * 1.44269504088896340736f;
+  hipLaunchKernelGGL((attn_long_kernel<CT>), dim3(n_crops * heads), dim3(512), lds, stream, qkv, out, n_tok, width,
+                     heads, scale_log2e, nkt);
+  return hipGetLastError();
+}
+
 template <int NKT>
 hipError_t launch_attn(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
                        hipStream_t stream) {
@@ -181,6 +336,6 @@ hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int 
     case 7: return launch_attn<7>(q, o, n_crops, n_tok, width, heads, stream);
     case 8: return launch_attn<8>(q, o, n_crops, n_tok, width, heads, stream);
     case 9: return launch_attn<9>(q, o, n_crops, n_tok, width, heads, stream);
-    default: return hipErrorInvalidValue;   // > 288 tokens (ViT-L-14-336): not built yet
+    default: return launch_attn_long(q, o, n_crops, n_tok, width, heads, stream);   // up to 640 tokens (K, V of one head in LDS)
   }
 }

@@ -258,7 +258,7 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
   if (g.layers < 1) return fail("layers %d < 1", g.layers);
   if (g.act != CLIPENC_ACT_QUICK_GELU && g.act != CLIPENC_ACT_GELU_ERF) return fail("unknown activation %d", g.act);
   const int grid = g.image_size / g.patch, tokens = grid * grid + 1;
-  if (tokens > 288) return fail("%d tokens > 288: the long-sequence attention variant is not built yet", tokens);
+  if (tokens > 640) return fail("%d tokens > 640: K and V of one head no longer fit the 160 KiB LDS", tokens);
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail("device %d out of range (%d visible)", device, ndev);

@@ -57,6 +57,7 @@ ARCHS: Dict[str, ViTConfig] = {
     # small shapes used by the parity tests (not open_clip names)
     "ViT-tiny-test": ViTConfig(28, 14, 256, 2, 4, 512, 32),
     "ViT-small-test": ViTConfig(98, 14, 256, 3, 4, 1024, 64),
+    "ViT-long-test": ViTConfig(336, 14, 256, 2, 4, 512, 32),      # 577 tokens like ViT-L-14-336
 }
 
 

@@ -127,7 +127,7 @@ int clipenc_op_gemm_nt(const void* a_dev, const void* w_dev, int m, int n, int k
  * {entry, prologue done, main loop done, stores issued, stores retired, hw id} into stamps_dev[tiles][8]. */
 int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n, int k, void* out_dev,
                               unsigned long long* stamps_dev, void* stream);
-/* qkv bf16 [n_crops*n_tok][3*width] -> out bf16 [n_crops*n_tok][width]; head dim 64, n_tok <= 288 */
+/* qkv bf16 [n_crops*n_tok][3*width] -> out bf16 [n_crops*n_tok][width]; head dim 64, n_tok <= 640 */
 int clipenc_op_attention(const void* qkv_dev, void* out_dev, int n_crops, int n_tok, int width, int heads,
                          void* stream);
 /* Residual stream after `layer` blocks (layer = 0: after ln_pre) of the LAST clipenc_encode chunk:

@@ -85,7 +85,8 @@ def test_gemm_rejects_bad_shapes(gpu):
 
 
 # ------------------------------------------------------------------------------------- attention
-@pytest.mark.parametrize("n_crops,n_tok,heads", [(3, 5, 4), (2, 32, 4), (2, 50, 12), (2, 197, 4), (3, 257, 16), (1, 288, 4)])
+@pytest.mark.parametrize("n_crops,n_tok,heads", [(3, 5, 4), (2, 32, 4), (2, 50, 12), (2, 197, 4), (3, 257, 16), (1, 288, 4),
+                                                  (2, 289, 4), (2, 577, 16), (1, 640, 4)])
 def test_attention_matches_fp32_reference(gpu, n_crops, n_tok, heads):
     lib = _lib.load()
     width = heads * 64
@@ -185,6 +186,20 @@ def test_encoder_matches_golden_and_oracle(gpu, golden_dir, arch):
         xl = vit.debug_run_layers(crops.to(gpu), l).float().cpu()
         ref = taps[f"block{l - 1}"]
         assert one_minus_cos(xl.flatten(1), ref.flatten(1)).max().item() < 5e-4, l
+    vit.close()
+
+
+def test_encoder_577_tokens_like_vit_l_14_336(gpu):
+    # the reference's default model (ViT-L-14-336/openai, _1_embed_with_CLIP.py:190) has 577 tokens:
+    # exercises the key-chunked online-softmax attention inside the full tower
+    cfg = vit_config.ARCHS["ViT-long-test"]
+    sd = vit_config.seeded_state_dict(cfg, 6)
+    crops = synthetic_crops(3, cfg.image_size, 12)
+    vit = HipViT(cfg, sd, gpu)
+    emb = vit.encode(crops.to(gpu)).cpu()
+    ref = vit_oracle.encode_image(sd, cfg, crops)
+    assert one_minus_cos(emb, ref).max().item() < COS_TOL
+    assert vit_config.config_for("ViT-L-14-336/openai").tokens == 577
     vit.close()
 
 
