@@ -13,10 +13,20 @@
 // as the next MFMA's operand"); V^T comes from the hardware-transposing LDS read.
 // The whole key range fits the register file (<= 9 tiles x 16 fp32), so the softmax is exact
 // two-pass (true row max), not an online rescale.
+#include <stdlib.h>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace {
+
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+// two fp32 -> one packed bf16 pair (a single v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
 
 __device__ __forceinline__ int k_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 __device__ __forceinline__ int v_swz(int row, int chunk) { return row * 128 + ((chunk ^ (((row >> 1) & 1) << 2)) << 4); }
@@ -100,14 +110,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
           if (kt < NKT - 1 || s2 == 0 || kt * 32 + 16 < n_tok) {   // wave-uniform; skips an all-padding k-step
-            bf16x8_t pf;
+            float pv[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              const float pv = __builtin_amdgcn_exp2f(fmaf(s[kt][s2 * 8 + j], scale_log2e, -moff));
-              const __bf16 pb = (__bf16)pv;
-              lsum += (float)pb;                               // normaliser of the ROUNDED weights
-              pf[j] = pb;
+              pv[j] = __builtin_amdgcn_exp2f(fmaf(s[kt][s2 * 8 + j], scale_log2e, -moff));
+              lsum += pv[j];
             }
+            const u32x4_t pw = {cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]), cvt_pk_bf16(pv[6], pv[7])};
+            const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
             // element j of lane half h is key 16*s2 + 8*(j>>2) + 4h + (j&3) of the tile
             const int key0 = kt * 32 + s2 * 16 + 4 * h;
 #pragma unroll
@@ -243,14 +253,14 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
             if (kt0 + c < nkt - 1 || s2 == 0 || (kt0 + c) * 32 + 16 < n_tok) {
-              bf16x8_t pf;
+              float pv[8];
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
-                const float pv = __builtin_amdgcn_exp2f(fmaf(s[c][s2 * 8 + j], scale_log2e, -moff));
-                const __bf16 pb = (__bf16)pv;
-                lsum += (float)pb;
-                pf[j] = pb;
+                pv[j] = __builtin_amdgcn_exp2f(fmaf(s[c][s2 * 8 + j], scale_log2e, -moff));
+                lsum += pv[j];
               }
+              const u32x4_t pw = {cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]), cvt_pk_bf16(pv[6], pv[7])};
+              const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
               const int key0 = (kt0 + c) * 32 + s2 * 16 + 4 * h;
 #pragma unroll
               for (int dt = 0; dt < 2; ++dt) {
@@ -301,6 +311,246 @@ hipError_t launch_attn_long(const bf16_t* qkv, bf16_t* out, int n_crops, int n_t
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streaming variant for 225..288 tokens (ViT-L/14: 257): the throughput kernel.
+// One persistent workgroup per CU = 7 compute waves + 1 loader wave over a contiguous range of
+// (crop, head) tasks.  K and V of two tasks live in LDS (2 x 72 KiB).  The loader wave fills the buffer of
+// task k by LDS-DMA as soon as all 32-query blocks of task k-2 are done, so the HBM stream keeps
+// running while the compute waves work on the resident tasks.  The blocks of consecutive tasks form ONE
+// stream dealt round-robin to the compute waves (no 4+4+1 tail per task).  There is no s_barrier in the
+// steady state: the loader publishes `landed` (tasks whose K/V are readable) in LDS and the compute
+// waves count finished blocks per task in LDS; both sides poll with s_sleep and every spin is bounded.
+// Compute waves issue no LDS-DMA, so hipcc keeps counted waits for their Q loads and O stores.
+// O goes through a wave-private 2 KiB LDS image and leaves as whole 128-B rows.
+// ---------------------------------------------------------------------------------------------
+constexpr unsigned SPIN_LIMIT = 1u << 24;
+
+__device__ __forceinline__ unsigned lds_load_u32(const char* p) {
+  return __atomic_load_n((const unsigned*)p, __ATOMIC_RELAXED);
+}
+
+template <int NKT>
+__global__ __launch_bounds__(512, 2) void attn_stream_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                             int n_tok, int width, int heads, float scale_log2e,
+                                                             int n_tasks, int dbg_mode) {
+  // dbg_mode (timing experiments only, results invalid): 1 = loader alone, 2 = compute alone
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = NKT * 32, MAT = ROWS * 128, BUF = 2 * MAT;
+  constexpr int NCW = 7;                                        // compute waves
+  constexpr int CTRL = 2 * BUF + NCW * 2048;                    // [0]: landed, [16..]: done[k] per task (<= 496 tasks)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int t0 = (int)(((long long)n_tasks * wg) / G), t1 = (int)(((long long)n_tasks * (wg + 1)) / G);
+  const int ntask = t1 - t0;                                    // host guarantees 1 <= ntask <= 496
+  const int n_qb = (n_tok + 31) >> 5;
+  const int total_blocks = ntask * n_qb;
+  const size_t ld = (size_t)3 * width;
+  const unsigned ldb = (unsigned)(ld * 2);
+  char* ctrl = smem + CTRL;
+
+  for (int i = tid; i < 512; i += 512) ((unsigned*)ctrl)[i] = 0u;
+  __syncthreads();
+
+  if (wave == NCW) {
+    // ------------------------------------ loader wave ------------------------------------
+    if (dbg_mode == 2) {
+      if (lane == 0) __atomic_store_n((unsigned*)ctrl, (unsigned)ntask, __ATOMIC_RELAXED);
+      return;
+    }
+    for (int k = 0; k < ntask; ++k) {
+      if (k >= 2 && dbg_mode != 1) {
+        // buffer k&1 is free once every block of task k-2 has been computed
+        if (lds_load_u32(ctrl + 16 + (k - 2) * 4) != (unsigned)n_qb) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // task k-1 has landed: publish it before waiting
+          if (lane == 0) __atomic_store_n((unsigned*)ctrl, (unsigned)k, __ATOMIC_RELAXED);
+          unsigned spins = 0;
+          while (lds_load_u32(ctrl + 16 + (k - 2) * 4) != (unsigned)n_qb && ++spins < SPIN_LIMIT) __builtin_amdgcn_s_sleep(2);
+        }
+      }
+      asm volatile("" ::: "memory");
+      const int t = t0 + k;
+      const int crop = t / heads, head = t - crop * heads;
+      const char* tb = (const char*)(qkv + (size_t)crop * n_tok * ld + head * 64);
+      const int dst = (k & 1) * BUF;
+#pragma unroll 4
+      for (int j = 0; j < ROWS / 8; ++j) {
+        const int row = 8 * j + (lane >> 3);
+        const unsigned rb = (unsigned)min(row, n_tok - 1) * ldb;
+        const int ck = (lane & 7) ^ ((row >> 1) & 7);
+        const int cv = (lane & 7) ^ (((row >> 1) & 1) << 2);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + (size_t)width * 2 + (rb + ck * 16)),
+                                         (__attribute__((address_space(3))) void*)(smem + dst + j * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + (size_t)width * 4 + (rb + cv * 16)),
+                                         (__attribute__((address_space(3))) void*)(smem + dst + MAT + j * 1024), 16, 0, 0);
+      }
+      // task k has >= 63 DMA instructions, so "at most 63 outstanding" means every older task has landed
+      asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+      if (lane == 0) __atomic_store_n((unsigned*)ctrl, (unsigned)k, __ATOMIC_RELAXED);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __atomic_store_n((unsigned*)ctrl, (unsigned)ntask, __ATOMIC_RELAXED);
+    return;
+  }
+
+  // ------------------------------------ compute waves ------------------------------------
+  if (dbg_mode == 1) return;
+  const int r = lane & 31, h = lane >> 5;
+  char* tr = smem + 2 * BUF + wave * 2048;
+  const int tr_base = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);
+
+  // Q fragments of a block: lane (r,h) holds Q[q0+r][16*step + 8h .. +7]; loaded one block ahead
+  auto q_ptr = [&](int gg) {
+    const int kk = gg / n_qb, qq = gg - kk * n_qb;
+    const int tt = t0 + kk;
+    const int cc = tt / heads, hh = tt - cc * heads;
+    return qkv + (size_t)cc * n_tok * ld + hh * 64 + (size_t)min(qq * 32 + r, n_tok - 1) * ld + h * 8;
+  };
+  bf16x8_t qf[4];
+  {
+    const bf16_t* qp = q_ptr(min(wave, total_blocks - 1));
+#pragma unroll
+    for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qp + st * 16);
+  }
+
+  for (int g = wave; g < total_blocks; g += NCW) {
+    const int k = g / n_qb, qb = g - k * n_qb;
+    const int t = t0 + k;
+    const int crop = t / heads, head = t - crop * heads;
+    const char* Ks = smem + (k & 1) * BUF;
+    const char* Vs = Ks + MAT;
+
+    {                                                           // wait until K/V of task k are readable
+      unsigned spins = 0;
+      while (lds_load_u32(ctrl) <= (unsigned)k && ++spins < SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+    }
+
+    f32x16_t s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        bf16x8_t kf = *(const bf16x8_t*)(Ks + k_swz(kt * 32 + r, st * 2 + h));
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kt], 0, 0, 0);
+      }
+    }
+    {                                                           // next block's Q: in flight during softmax and P.V
+      const bf16_t* qp = q_ptr(min(g + NCW, total_blocks - 1));
+#pragma unroll
+      for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qp + st * 16);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (kt == NKT - 1) {
+          const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= n_tok) s[kt][e] = -INFINITY;
+        }
+        mx = fmaxf(mx, s[kt][e]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float moff = mx * scale_log2e;
+    f32x16_t o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
+    float lsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (kt < NKT - 1 || s2 == 0 || kt * 32 + 16 < n_tok) {
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            pv[j] = __builtin_amdgcn_exp2f(fmaf(s[kt][s2 * 8 + j], scale_log2e, -moff));
+            lsum += pv[j];
+          }
+          const u32x4_t pw = {cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]), cvt_pk_bf16(pv[6], pv[7])};
+          const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+          const int key0 = kt * 32 + s2 * 16 + 4 * h;
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const int i = lane & 15, qq = i >> 2, pp = i & 3, g1 = (lane >> 4) & 1;
+            const int dcol = dt * 32 + g1 * 16 + pp * 4;
+            const int ra = key0 + qq, rb = key0 + 8 + qq;
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(ra, dcol >> 3) + (dcol & 7) * 2));
+            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(rb, dcol >> 3) + (dcol & 7) * 2));
+            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+            s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, o[dt], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // every K/V read of this block has returned (the MFMAs consumed them): release the buffer share
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __atomic_fetch_add((unsigned*)(ctrl + 16 + k * 4), 1u, __ATOMIC_RELAXED);
+
+    lsum += __shfl_xor(lsum, 32);
+    const float inv = 1.0f / lsum;
+
+    // ---- O: fragment layout -> [16 q rows][64 d] bf16 image -> whole 128-B rows, two passes of 16 rows ----
+    bf16_t* obase = out + (size_t)crop * n_tok * width + head * 64 + (lane & 7) * 8;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      if ((r >> 4) == pass) {
+        const int rr = r & 15;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const uint2 pk = {pack_bf16x2(o[dt][g4 * 4 + 0] * inv, o[dt][g4 * 4 + 1] * inv),
+                              pack_bf16x2(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv)};
+            *(uint2*)(tr + rr * 128 + (((dt * 4 + g4) ^ (rr & 7)) << 4) + h * 8) = pk;
+          }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const uint4 v0 = *(const uint4*)(tr + tr_base);
+      const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
+      const int qa = qb * 32 + pass * 16 + (lane >> 3), qb2 = qa + 8;
+      if (qa < n_tok) *(uint4*)(obase + (size_t)qa * width) = v0;
+      if (qb2 < n_tok) *(uint4*)(obase + (size_t)qb2 * width) = v1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+}
+
+template <int NKT>
+hipError_t launch_attn_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
+                              hipStream_t stream) {
+  const int lds = 2 * 2 * NKT * 32 * 128 + 8 * 2048;
+  static bool attr_set = false;
+  static int n_cu = 256;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)attn_stream_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      n_cu = prop.multiProcessorCount;
+    attr_set = true;
+  }
+  const int n_tasks = n_crops * heads;
+  int grid = n_tasks < n_cu ? n_tasks : n_cu;
+  while ((n_tasks + grid - 1) / grid > 496) grid *= 2;      // per-workgroup task counters live in 2 KiB of LDS
+  const float scale_log2e = 0.125f * 1.44269504088896340736f;
+  static const int dbg = [] { const char* e = getenv("CLIPENC_ATTN_DBG"); return e ? atoi(e) : 0; }();
+  hipLaunchKernelGGL((attn_stream_kernel<NKT>), dim3(grid), dim3(512), lds, stream, qkv, out, n_tok, width, heads,
+                     scale_log2e, n_tasks, dbg);
+  return hipGetLastError();
+}
+
 template <int NKT>
 hipError_t launch_attn(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
                        hipStream_t stream) {
@@ -326,6 +576,9 @@ hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int 
   const int nkt = (n_tok + 31) / 32;
   const bf16_t* q = (const bf16_t*)qkv;
   bf16_t* o = (bf16_t*)out;
+  static const int impl = [] { const char* e = getenv("CLIPENC_ATTN_IMPL"); return e ? atoi(e) : 2; }();
+  if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8>(q, o, n_crops, n_tok, width, heads, stream);
+  if (impl == 2 && nkt == 9 && n_crops * heads >= 64) return launch_attn_stream<9>(q, o, n_crops, n_tok, width, heads, stream);
   switch (nkt) {                 // NKT must equal ceil(n_tok/32): only the last key tile is masked
     case 1: return launch_attn<1>(q, o, n_crops, n_tok, width, heads, stream);
     case 2: return launch_attn<2>(q, o, n_crops, n_tok, width, heads, stream);
