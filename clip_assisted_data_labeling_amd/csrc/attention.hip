@@ -103,7 +103,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
-    float lsum = 0.f;
+    f32x16_t lacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+    const u32x4_t ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // eight bf16 1.0
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_w);
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       {
@@ -112,12 +116,10 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__
           if (kt < NKT - 1 || s2 == 0 || kt * 32 + 16 < n_tok) {   // wave-uniform; skips an all-padding k-step
             float pv[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              pv[j] = __builtin_amdgcn_exp2f(fmaf(s[kt][s2 * 8 + j], scale_log2e, -moff));
-              lsum += pv[j];
-            }
+            for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(fmaf(s[kt][s2 * 8 + j], scale_log2e, -moff));
             const u32x4_t pw = {cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]), cvt_pk_bf16(pv[6], pv[7])};
             const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+            lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);   // row sums of the rounded weights
             // element j of lane half h is key 16*s2 + 8*(j>>2) + 4h + (j&3) of the tile
             const int key0 = kt * 32 + s2 * 16 + 4 * h;
 #pragma unroll
@@ -139,8 +141,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    lsum += __shfl_xor(lsum, 32);
-    const float inv = 1.0f / lsum;
+    const float inv = 1.0f / lacc[0];
 
     // ---- store O[q][head*64 + d]: reg group g4 holds d = dt*32 + 8*g4 + 4h + (0..3) ----
     if (q < n_tok) {
@@ -205,7 +206,12 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
-    float m_run = -INFINITY, lsum = 0.f;
+    float m_run = -INFINITY;
+    f32x16_t lacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+    const u32x4_t ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // eight bf16 1.0
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_w);
 
     for (int kt0 = 0; kt0 < nkt; kt0 += CT) {
       // ---- scores of this chunk ----
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
       const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);   // 0 on the first chunk
       m_run = mx;
       const float moff = mx * scale_log2e;
-      lsum *= alpha;
+      lacc[0] *= alpha;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -255,12 +261,10 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
             if (kt0 + c < nkt - 1 || s2 == 0 || (kt0 + c) * 32 + 16 < n_tok) {
               float pv[8];
 #pragma unroll
-              for (int j = 0; j < 8; ++j) {
-                pv[j] = __builtin_amdgcn_exp2f(fmaf(s[c][s2 * 8 + j], scale_log2e, -moff));
-                lsum += pv[j];
-              }
+              for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(fmaf(s[c][s2 * 8 + j], scale_log2e, -moff));
               const u32x4_t pw = {cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]), cvt_pk_bf16(pv[6], pv[7])};
               const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+              lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);   // row sums of the rounded weights
               const int key0 = (kt0 + c) * 32 + s2 * 16 + 4 * h;
 #pragma unroll
               for (int dt = 0; dt < 2; ++dt) {
@@ -281,8 +285,7 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    lsum += __shfl_xor(lsum, 32);
-    const float inv = 1.0f / lsum;
+    const float inv = 1.0f / lacc[0];
     if (q < n_tok) {
       bf16_t* orow = out + ((size_t)crop * n_tok + q) * width + head * 64;
 #pragma unroll
@@ -329,15 +332,18 @@ __device__ __forceinline__ unsigned lds_load_u32(const char* p) {
   return __atomic_load_n((const unsigned*)p, __ATOMIC_RELAXED);
 }
 
-template <int NKT>
-__global__ __launch_bounds__(512, 2) void attn_stream_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                             int n_tok, int width, int heads, float scale_log2e,
-                                                             int n_tasks, int dbg_mode) {
+template <int NKT, int CT, int NCW>
+__global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n_tok, int width, int heads, float scale_log2e,
+    int n_tasks, int dbg_mode) {
+  // NCW compute waves + 1 loader; keys walked in chunks of CT tiles (CT == NKT: one exact pass; CT < NKT:
+  // online softmax, fewer live score registers -> 3 waves per SIMD).
   // dbg_mode (timing experiments only, results invalid): 1 = loader alone, 2 = compute alone
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWS = NKT * 32, MAT = ROWS * 128, BUF = 2 * MAT;
-  constexpr int NCW = 7;                                        // compute waves
-  constexpr int CTRL = 2 * BUF + NCW * 2048;                    // [0]: landed, [16..]: done[k] per task (<= 496 tasks)
+  constexpr int TRB = NCW <= 7 ? 2048 : 1024;                   // wave-private O image: 16 or 8 rows x 128 B
+  constexpr int TR_ROWS = TRB / 128;
+  constexpr int CTRL = 2 * BUF + NCW * TRB;                     // [0]: landed, [16..]: done[k] per task (<= 496 tasks)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = gridDim.x, wg = blockIdx.x;
@@ -349,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(const bf16_t* __res
   const unsigned ldb = (unsigned)(ld * 2);
   char* ctrl = smem + CTRL;
 
-  for (int i = tid; i < 512; i += 512) ((unsigned*)ctrl)[i] = 0u;
+  for (int i = tid; i < 512; i += (NCW + 1) * 64) ((unsigned*)ctrl)[i] = 0u;
   __syncthreads();
 
   if (wave == NCW) {
@@ -396,7 +402,7 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(const bf16_t* __res
   // ------------------------------------ compute waves ------------------------------------
   if (dbg_mode == 1) return;
   const int r = lane & 31, h = lane >> 5;
-  char* tr = smem + 2 * BUF + wave * 2048;
+  char* tr = smem + 2 * BUF + wave * TRB;
   const int tr_base = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);
 
   // Q fragments of a block: lane (r,h) holds Q[q0+r][16*step + 8h .. +7]; loaded one block ahead
@@ -426,114 +432,145 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(const bf16_t* __res
       asm volatile("" ::: "memory");
     }
 
-    f32x16_t s[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
-#pragma unroll
-      for (int st = 0; st < 4; ++st) {
-        bf16x8_t kf = *(const bf16x8_t*)(Ks + k_swz(kt * 32 + r, st * 2 + h));
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kt], 0, 0, 0);
-      }
-    }
-    {                                                           // next block's Q: in flight during softmax and P.V
-      const bf16_t* qp = q_ptr(min(g + NCW, total_blocks - 1));
-#pragma unroll
-      for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qp + st * 16);
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        if (kt == NKT - 1) {
-          const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (key >= n_tok) s[kt][e] = -INFINITY;
-        }
-        mx = fmaxf(mx, s[kt][e]);
-      }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float moff = mx * scale_log2e;
     f32x16_t o[2];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
-    float lsum = 0.f;
+    float m_run = -INFINITY;
+    f32x16_t lacc;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+    const u32x4_t ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // eight bf16 1.0
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_w);
+
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        if (kt < NKT - 1 || s2 == 0 || kt * 32 + 16 < n_tok) {
-          float pv[8];
+    for (int kt0 = 0; kt0 < NKT; kt0 += CT) {
+      constexpr int dummy = 0; (void)dummy;
+      f32x16_t s[CT];
+      // ---- S^T tiles of this chunk: s[c][reg] = <K[32(kt0+c) + krow(reg,h)], Q[q]> ----
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            pv[j] = __builtin_amdgcn_exp2f(fmaf(s[kt][s2 * 8 + j], scale_log2e, -moff));
-            lsum += pv[j];
-          }
-          const u32x4_t pw = {cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]), cvt_pk_bf16(pv[6], pv[7])};
-          const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
-          const int key0 = kt * 32 + s2 * 16 + 4 * h;
+      for (int c = 0; c < CT; ++c) {
+        if (kt0 + c < NKT) {
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const int i = lane & 15, qq = i >> 2, pp = i & 3, g1 = (lane >> 4) & 1;
-            const int dcol = dt * 32 + g1 * 16 + pp * 4;
-            const int ra = key0 + qq, rb = key0 + 8 + qq;
-            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(ra, dcol >> 3) + (dcol & 7) * 2));
-            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(rb, dcol >> 3) + (dcol & 7) * 2));
-            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-            s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, o[dt], 0, 0, 0);
+          for (int e = 0; e < 16; ++e) s[c][e] = 0.f;
+#pragma unroll
+          for (int st = 0; st < 4; ++st) {
+            bf16x8_t kf = *(const bf16x8_t*)(Ks + k_swz((kt0 + c) * 32 + r, st * 2 + h));
+            s[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[c], 0, 0, 0);
           }
         }
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if (kt0 + CT >= NKT) {                                    // last chunk: next block's Q can start flying
+        const bf16_t* qp = q_ptr(min(g + NCW, total_blocks - 1));
+#pragma unroll
+        for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qp + st * 16);
+      }
+      // ---- mask padded keys (last tile only), chunk max ----
+      float mx = m_run;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if (kt0 + c < NKT) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            if (kt0 + c == NKT - 1) {
+              const int key = (kt0 + c) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+              if (key >= n_tok) s[c][e] = -INFINITY;
+            }
+            mx = fmaxf(mx, s[c][e]);
+          }
+        }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float moff = mx * scale_log2e;
+      if (CT < NKT) {                                           // online softmax: bring O and l to the new max
+        const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);    // 0 on the first chunk
+        m_run = mx;
+        lacc[0] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
+      }
+      // ---- P = exp2(s*c - m*c), row sum, O^T += V^T . P^T ----
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        if (kt0 + c < NKT) {
+          const int kt = kt0 + c;
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            if (kt < NKT - 1 || s2 == 0 || kt * 32 + 16 < n_tok) {   // wave-uniform; skips an all-padding k-step
+              float pv[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(fmaf(s[c][s2 * 8 + j], scale_log2e, -moff));
+              const u32x4_t pw = {cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]),
+                                  cvt_pk_bf16(pv[6], pv[7])};
+              const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+              // row sums of the ROUNDED weights on the matrix pipe: ones^T . P^T (every output row = the sum)
+              lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
+              const int key0 = kt * 32 + s2 * 16 + 4 * h;
+#pragma unroll
+              for (int dt = 0; dt < 2; ++dt) {
+                const int i = lane & 15, qq = i >> 2, pp = i & 3, g1 = (lane >> 4) & 1;
+                const int dcol = dt * 32 + g1 * 16 + pp * 4;
+                const int ra = key0 + qq, rb = key0 + 8 + qq;
+                s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(ra, dcol >> 3) + (dcol & 7) * 2));
+                s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                    (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(rb, dcol >> 3) + (dcol & 7) * 2));
+                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+                s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, o[dt], 0, 0, 0);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
     // every K/V read of this block has returned (the MFMAs consumed them): release the buffer share
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __atomic_fetch_add((unsigned*)(ctrl + 16 + k * 4), 1u, __ATOMIC_RELAXED);
 
-    lsum += __shfl_xor(lsum, 32);
-    const float inv = 1.0f / lsum;
+    const float inv = 1.0f / lacc[0];                           // the MFMA already summed both lane halves
 
-    // ---- O: fragment layout -> [16 q rows][64 d] bf16 image -> whole 128-B rows, two passes of 16 rows ----
+    // ---- O: fragment layout -> [TR_ROWS q rows][64 d] bf16 image -> whole 128-B rows ----
     bf16_t* obase = out + (size_t)crop * n_tok * width + head * 64 + (lane & 7) * 8;
+    uint2 opk[8];
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      if ((r >> 4) == pass) {
-        const int rr = r & 15;
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+      for (int g4 = 0; g4 < 4; ++g4)
+        opk[dt * 4 + g4] = uint2{cvt_pk_bf16(o[dt][g4 * 4 + 0] * inv, o[dt][g4 * 4 + 1] * inv),
+                                 cvt_pk_bf16(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv)};
 #pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const uint2 pk = {pack_bf16x2(o[dt][g4 * 4 + 0] * inv, o[dt][g4 * 4 + 1] * inv),
-                              pack_bf16x2(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv)};
-            *(uint2*)(tr + rr * 128 + (((dt * 4 + g4) ^ (rr & 7)) << 4) + h * 8) = pk;
-          }
+    for (int pass = 0; pass < 32 / TR_ROWS; ++pass) {
+      if (r / TR_ROWS == pass) {
+        const int rr = r % TR_ROWS;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) *(uint2*)(tr + rr * 128 + ((c8 ^ (rr & 7)) << 4) + h * 8) = opk[c8];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       const uint4 v0 = *(const uint4*)(tr + tr_base);
-      const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
-      const int qa = qb * 32 + pass * 16 + (lane >> 3), qb2 = qa + 8;
+      const int qa = qb * 32 + pass * TR_ROWS + (lane >> 3);
       if (qa < n_tok) *(uint4*)(obase + (size_t)qa * width) = v0;
-      if (qb2 < n_tok) *(uint4*)(obase + (size_t)qb2 * width) = v1;
+      if (TR_ROWS == 16) {
+        const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
+        if (qa + 8 < n_tok) *(uint4*)(obase + (size_t)(qa + 8) * width) = v1;
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
   }
 }
 
-template <int NKT>
+template <int NKT, int CT, int NCW>
 hipError_t launch_attn_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
                               hipStream_t stream) {
-  const int lds = 2 * 2 * NKT * 32 * 128 + 8 * 2048;
+  const int lds = 2 * 2 * NKT * 32 * 128 + NCW * (NCW <= 7 ? 2048 : 1024) + 2048;
   static bool attr_set = false;
   static int n_cu = 256;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_stream_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipError_t e = hipFuncSetAttribute((const void*)attn_stream_kernel<NKT, CT, NCW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
     int dev = 0;
     hipDeviceProp_t prop;
@@ -546,7 +583,7 @@ hipError_t launch_attn_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n
   while ((n_tasks + grid - 1) / grid > 496) grid *= 2;      // per-workgroup task counters live in 2 KiB of LDS
   const float scale_log2e = 0.125f * 1.44269504088896340736f;
   static const int dbg = [] { const char* e = getenv("CLIPENC_ATTN_DBG"); return e ? atoi(e) : 0; }();
-  hipLaunchKernelGGL((attn_stream_kernel<NKT>), dim3(grid), dim3(512), lds, stream, qkv, out, n_tok, width, heads,
+  hipLaunchKernelGGL((attn_stream_kernel<NKT, CT, NCW>), dim3(grid), dim3((NCW + 1) * 64), lds, stream, qkv, out, n_tok, width, heads,
                      scale_log2e, n_tasks, dbg);
   return hipGetLastError();
 }
@@ -577,8 +614,8 @@ hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int 
   const bf16_t* q = (const bf16_t*)qkv;
   bf16_t* o = (bf16_t*)out;
   static const int impl = [] { const char* e = getenv("CLIPENC_ATTN_IMPL"); return e ? atoi(e) : 2; }();
-  if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8>(q, o, n_crops, n_tok, width, heads, stream);
-  if (impl == 2 && nkt == 9 && n_crops * heads >= 64) return launch_attn_stream<9>(q, o, n_crops, n_tok, width, heads, stream);
+  if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8, 8, 7>(q, o, n_crops, n_tok, width, heads, stream);
+  if (impl == 2 && nkt == 9 && n_crops * heads >= 64) return launch_attn_stream<9, 9, 7>(q, o, n_crops, n_tok, width, heads, stream);
   switch (nkt) {                 // NKT must equal ceil(n_tok/32): only the last key tile is masked
     case 1: return launch_attn<1>(q, o, n_crops, n_tok, width, heads, stream);
     case 2: return launch_attn<2>(q, o, n_crops, n_tok, width, heads, stream);

@@ -9,6 +9,8 @@
 // [4 parts][256 rows][sum,sumsq] landed by LDS-DMA one tile ahead; EPI_RESID per-wave row partial sums |
 // [144K,160K) 8 wave-private 2 KiB images used to turn the MFMA fragment layout into whole 16-B row
 // chunks (and the residual the other way) one 16-row block at a time.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm.h"
 
@@ -52,7 +54,7 @@ __device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n,
   return TileId{tm * BM, tn * BN, tn};
 }
 
-template <int EPI>
+template <int EPI, int VAR>
 __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p) {
   typedef bf16x8_t frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -117,28 +119,33 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 #define LD_A(slot, half) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (slot) * STG + a_rd + ((half) * 4 + i) * 1024);
 #define MMA(half)                                                                           \
   do {                                                                                      \
-    __builtin_amdgcn_s_setprio(1);                                                          \
+    if (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
       acc[(half) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[(half) * 4 + i][j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0);                                                          \
+    if (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);                                          \
   } while (0)
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
 #define WAIT_LDS()                                                                          \
   do {                                                                                      \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
-    __builtin_amdgcn_sched_barrier(0);                                                      \
+    if (!(VAR & 4)) __builtin_amdgcn_sched_barrier(0);                                      \
   } while (0)
   // one K=32 stage = two phases; ISSUE_W / ISSUE_A are the DMA statements of the phases, VM the counted wait
 #define STAGE(slot, ISSUE_W, ISSUE_A, VM)                                                   \
   do {                                                                                      \
-    LD_W(slot) __builtin_amdgcn_sched_barrier(0); LD_A(slot, 0)                             \
-    ISSUE_W;                                                                                \
-    BARRIER(); WAIT_LDS(); MMA(0); BARRIER();                                               \
+    if (VAR & 8) { LD_A(slot, 0) __builtin_amdgcn_sched_barrier(0); LD_W(slot) }            \
+    else { LD_W(slot) __builtin_amdgcn_sched_barrier(0); LD_A(slot, 0) }                    \
+    if (!(VAR & 2)) { ISSUE_W; }                                                            \
+    BARRIER();                                                                              \
+    if (VAR & 2) { ISSUE_W; }                                                               \
+    WAIT_LDS(); MMA(0); BARRIER();                                                          \
     LD_A(slot, 1)                                                                           \
-    ISSUE_A;                                                                                \
+    if (!(VAR & 2)) { ISSUE_A; }                                                            \
     asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                  \
-    BARRIER(); WAIT_LDS(); MMA(1); BARRIER();                                               \
+    BARRIER();                                                                              \
+    if (VAR & 2) { ISSUE_A; }                                                               \
+    WAIT_LDS(); MMA(1); BARRIER();                                                          \
   } while (0)
 
   // ---- cold prologue of the first tile ----
@@ -323,12 +330,12 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   }
 }
 
-template <int EPI>
+template <int EPI, int VAR>
 hipError_t launch_persist(const GemmParams& p, hipStream_t stream) {
   static int n_cu = 0;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
     int dev = 0;
     e = hipGetDevice(&dev);
@@ -344,17 +351,26 @@ hipError_t launch_persist(const GemmParams& p, hipStream_t stream) {
   grid -= grid % 8;                           // keep tile index mod 8 == workgroup index mod 8 (XCD affinity)
   if (grid < 8) grid = 8;
   if (tiles < grid) grid = tiles;
-  hipLaunchKernelGGL((gemm_persist_kernel<EPI>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_persist_kernel<EPI, VAR>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
   return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream) {
+  static const int var = [] { const char* e = getenv("CLIPENC_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
+  if (epi == EPI_STORE_BF16) {
+    switch (var) {                            // schedule experiments (tools/gemm_sweep.py); 0 is the shipped one
+      case 1: return launch_persist<EPI_STORE_BF16, 1>(p, stream);
+      case 2: return launch_persist<EPI_STORE_BF16, 2>(p, stream);
+      case 4: return launch_persist<EPI_STORE_BF16, 4>(p, stream);
+      case 8: return launch_persist<EPI_STORE_BF16, 8>(p, stream);
+      default: return launch_persist<EPI_STORE_BF16, 0>(p, stream);
+    }
+  }
   switch (epi) {
-    case EPI_STORE_BF16: return launch_persist<EPI_STORE_BF16>(p, stream);
-    case EPI_LNFOLD: return launch_persist<EPI_LNFOLD>(p, stream);
-    case EPI_RESID: return launch_persist<EPI_RESID>(p, stream);
+    case EPI_LNFOLD: return launch_persist<EPI_LNFOLD, 0>(p, stream);
+    case EPI_RESID: return launch_persist<EPI_RESID, 0>(p, stream);
     default: return hipErrorInvalidValue;
   }
 }
