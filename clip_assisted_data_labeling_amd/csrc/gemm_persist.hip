@@ -26,6 +26,14 @@ constexpr int LDS_BYTES = RING + 32768;     // 163840
 #define LDS_PTR(off) ((__attribute__((address_space(3))) void*)(smem + (off)))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
+template <int ACT>
+__device__ __forceinline__ float act_apply_t(float u) {
+  // compile-time activation: a run-time `act` makes hipcc evaluate BOTH activations per element and select
+  if constexpr (ACT == CE_ACT_QUICK_GELU) return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * u));
+  else if constexpr (ACT == CE_ACT_GELU_ERF) return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
+  else return u;
+}
+
 __device__ __forceinline__ float act_apply(float u, int act) {
   // u * sigmoid(1.702 u) = u / (1 + 2^(-1.702*log2(e)*u)): one v_exp_f32 + one v_rcp_f32 (a full fp32 divide costs ~10 more VALU ops)
   if (act == CE_ACT_QUICK_GELU) return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * u));
@@ -78,7 +86,12 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   const int rd = frow * 64 + (((lane >> 4) ^ ((frow >> 3) << 1)) << 4);
   const int a_rd = wr * 8 * 1024 + rd;
   const int w_rd = WPART + wc * 4 * 1024 + rd;
-  const unsigned woff0 = (unsigned)(lrow * ldw_b) + lchunk16, woff1 = (unsigned)((128 + lrow) * ldw_b) + lchunk16;
+  // VAR & 16 ("direct" epilogue): W rows are permuted inside each wave's 64-row block (bit fields [5:4] <-> [3:2] of the
+  // row index) so that a lane's 4 n-tiles x 4 registers are 16 CONSECUTIVE output columns: 32 contiguous bytes per lane
+  // and row, stored/loaded with two 16-B accesses and no LDS transposition.
+  constexpr bool DIRECT = (VAR & 16) != 0;
+  const int lrow_w = DIRECT ? ((lrow & ~63) | ((lrow & 0x30) >> 2) | ((lrow & 0x0c) << 2) | (lrow & 3)) : lrow;
+  const unsigned woff0 = (unsigned)(lrow_w * ldw_b) + lchunk16, woff1 = (unsigned)((128 + lrow_w) * ldw_b) + lchunk16;
 
   // epilogue lane mapping: 16-row x 128-B image per wave, 16-B chunk index XOR row&7
   char* tr = smem + TR_OFF + w * 2048;
@@ -222,90 +235,168 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       __syncthreads();
     }
 
-    f32x4_t cs[4], bs[4];
-    if constexpr (EPI == EPI_LNFOLD) {
+    if constexpr (DIRECT) {
+      // ---- direct epilogue: lane (frow, qd) owns columns cb .. cb+15 of rows mw0 + mt*16 + frow ----
+      const int cb = cur.n0 + wc * 64 + qd * 16;
+      f32x4_t cs[4], bs[4];
+      if constexpr (EPI == EPI_LNFOLD) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) cs[nt] = *(const f32x4_t*)(p.colsum + ncol0 + nt * 16);
-    }
-    if (EPI != EPI_STORE_BF16 || p.bias) {
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(p.bias + ncol0 + nt * 16);
-    } else {
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bs[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-
-    // residual rows, 8 x 16 B per lane in flight (four 16-row blocks ahead of their use)
-    uint4 rres[8];
-#define LOAD_RES(k)                                                                           \
-  do {                                                                                        \
-    const int m_ = mw0 + (k) * 8 + row_l;                                                     \
-    rres[(k) & 7] = uint4{0, 0, 0, 0};                                                        \
-    if (m_ < p.M) rres[(k) & 7] = *(const uint4*)((const bf16_t*)p.resid + (size_t)m_ * p.ldo + gcol); \
-  } while (0)
-    if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) LOAD_RES(k);
-    }
-
-#pragma unroll
-    for (int mt = 0; mt < 8; ++mt) {
-      uint2 pk[4];
-      if constexpr (EPI == EPI_STORE_BF16) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const f32x4_t v = acc[mt][nt] + bs[nt];
-          pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        }
-      } else if constexpr (EPI == EPI_LNFOLD) {
-        const float2 t = *(const float2*)(smem + AUX_OFF + (tile_iter & 1) * 8192 + (wr * 128 + mt * 16 + frow) * 8);
-        const float mean = t.x, rstd = t.y;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          f32x4_t v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v[e] = act_apply(rstd * (acc[mt][nt][e] - mean * cs[nt][e]) + bs[nt][e], p.act);
-          pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        }
-      } else {
-        // residual rows of this 16-row block: row-major image -> fragment layout
-        *(uint4*)(tr + tr_base) = rres[(mt * 2) & 7];
-        *(uint4*)(tr + 1024 + tr_base) = rres[(mt * 2 + 1) & 7];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // cross-lane hand-off through the image
-        if (mt + 4 < 8) { LOAD_RES(mt * 2 + 8); LOAD_RES(mt * 2 + 9); }
-        float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const uint2 rr = *(const uint2*)TW_ADDR(nt);
-          f32x4_t v = acc[mt][nt] + bs[nt];
-          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-          pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          const float r0 = __uint_as_float(pk[nt].x << 16), r1 = __uint_as_float(pk[nt].x & 0xffff0000u);
-          const float r2 = __uint_as_float(pk[nt].y << 16), r3 = __uint_as_float(pk[nt].y & 0xffff0000u);
-          s += (r0 + r1) + (r2 + r3);
-          ss += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
-        }
-        if (mw0 + mt * 16 + frow >= p.M) { s = 0.f; ss = 0.f; }
-        s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
-        s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-        if (lane < 16)
-          *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane) * 8) = float2{s, ss};
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragment reads done before the image is rewritten
+        for (int nt = 0; nt < 4; ++nt) cs[nt] = *(const f32x4_t*)(p.colsum + cb + nt * 4);
       }
-      // fragment layout -> row-major image -> two 16-B-per-lane stores of 8 full rows each
+      if (EPI != EPI_STORE_BF16 || p.bias) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) *(uint2*)TW_ADDR(nt) = pk[nt];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const uint4 v0 = *(const uint4*)(tr + tr_base);
-      const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
-      const int ma = mw0 + mt * 16 + row_l, mb = ma + 8;
-      if (ma < p.M) *(uint4*)((bf16_t*)p.out + (size_t)ma * p.ldo + gcol) = v0;
-      if (mb < p.M) *(uint4*)((bf16_t*)p.out + (size_t)mb * p.ldo + gcol) = v1;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // image reads done before the next block's writes
-    }
+        for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(p.bias + cb + nt * 4);
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bs[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+      uint4 rres[8];                                   // residual: 2 x 16 B per 16-row block, four blocks ahead
+#define LOAD_RES_D(k)                                                                         \
+  do {                                                                                        \
+    const int m_ = mw0 + ((k) >> 1) * 16 + frow;                                              \
+    rres[(k) & 7] = uint4{0, 0, 0, 0};                                                        \
+    if (m_ < p.M) rres[(k) & 7] = *(const uint4*)((const bf16_t*)p.resid + (size_t)m_ * p.ldo + cb + ((k) & 1) * 8); \
+  } while (0)
+      if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) LOAD_RES_D(k);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        uint32_t w8[8];
+        if constexpr (EPI == EPI_STORE_BF16) {
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const f32x4_t v = acc[mt][nt] + bs[nt];
+            w8[nt * 2] = pack_bf16x2(v[0], v[1]); w8[nt * 2 + 1] = pack_bf16x2(v[2], v[3]);
+          }
+        } else if constexpr (EPI == EPI_LNFOLD) {
+          const float2 t = *(const float2*)(smem + AUX_OFF + (tile_iter & 1) * 8192 + (wr * 128 + mt * 16 + frow) * 8);
+          const float mean = t.x, rstd = t.y;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            f32x4_t v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = act_apply_t<((VAR >> 8) & 3) - 1>(rstd * (acc[mt][nt][e] - mean * cs[nt][e]) + bs[nt][e]);
+            w8[nt * 2] = pack_bf16x2(v[0], v[1]); w8[nt * 2 + 1] = pack_bf16x2(v[2], v[3]);
+          }
+        } else {
+          const uint4 ra = rres[(mt * 2) & 7], rb = rres[(mt * 2 + 1) & 7];
+          if (mt + 4 < 8) { LOAD_RES_D(mt * 2 + 8); LOAD_RES_D(mt * 2 + 9); }
+          const uint32_t rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+          float s = 0.f, ss = 0.f;
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            f32x4_t v = acc[mt][nt] + bs[nt];
+            v[0] += __uint_as_float(rw[nt * 2] << 16); v[1] += __uint_as_float(rw[nt * 2] & 0xffff0000u);
+            v[2] += __uint_as_float(rw[nt * 2 + 1] << 16); v[3] += __uint_as_float(rw[nt * 2 + 1] & 0xffff0000u);
+            const uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
+            w8[nt * 2] = p0; w8[nt * 2 + 1] = p1;
+            const float r0 = __uint_as_float(p0 << 16), r1 = __uint_as_float(p0 & 0xffff0000u);
+            const float r2 = __uint_as_float(p1 << 16), r3 = __uint_as_float(p1 & 0xffff0000u);
+            s += (r0 + r1) + (r2 + r3);
+            ss += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+          }
+          if (mw0 + mt * 16 + frow >= p.M) { s = 0.f; ss = 0.f; }
+          s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
+          s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+          if (lane < 16)
+            *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane) * 8) = float2{s, ss};
+        }
+        const int m = mw0 + mt * 16 + frow;
+        if (m < p.M) {
+          bf16_t* o = (bf16_t*)p.out + (size_t)m * p.ldo + cb;
+          *(uint4*)o = uint4{w8[0], w8[1], w8[2], w8[3]};
+          *(uint4*)(o + 8) = uint4{w8[4], w8[5], w8[6], w8[7]};
+        }
+      }
+    } else {
+      f32x4_t cs[4], bs[4];
+      if constexpr (EPI == EPI_LNFOLD) {
+  #pragma unroll
+        for (int nt = 0; nt < 4; ++nt) cs[nt] = *(const f32x4_t*)(p.colsum + ncol0 + nt * 16);
+      }
+      if (EPI != EPI_STORE_BF16 || p.bias) {
+  #pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(p.bias + ncol0 + nt * 16);
+      } else {
+  #pragma unroll
+        for (int nt = 0; nt < 4; ++nt) bs[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
 
+      // residual rows, 8 x 16 B per lane in flight (four 16-row blocks ahead of their use)
+      uint4 rres[8];
+  #define LOAD_RES(k)                                                                           \
+    do {                                                                                        \
+      const int m_ = mw0 + (k) * 8 + row_l;                                                     \
+      rres[(k) & 7] = uint4{0, 0, 0, 0};                                                        \
+      if (m_ < p.M) rres[(k) & 7] = *(const uint4*)((const bf16_t*)p.resid + (size_t)m_ * p.ldo + gcol); \
+    } while (0)
+      if constexpr (EPI == EPI_RESID) {
+  #pragma unroll
+        for (int k = 0; k < 8; ++k) LOAD_RES(k);
+      }
+
+  #pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        uint2 pk[4];
+        if constexpr (EPI == EPI_STORE_BF16) {
+  #pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const f32x4_t v = acc[mt][nt] + bs[nt];
+            pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          }
+        } else if constexpr (EPI == EPI_LNFOLD) {
+          const float2 t = *(const float2*)(smem + AUX_OFF + (tile_iter & 1) * 8192 + (wr * 128 + mt * 16 + frow) * 8);
+          const float mean = t.x, rstd = t.y;
+  #pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            f32x4_t v;
+  #pragma unroll
+            for (int e = 0; e < 4; ++e)
+              v[e] = act_apply_t<((VAR >> 8) & 3) - 1>(rstd * (acc[mt][nt][e] - mean * cs[nt][e]) + bs[nt][e]);
+            pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          }
+        } else {
+          // residual rows of this 16-row block: row-major image -> fragment layout
+          *(uint4*)(tr + tr_base) = rres[(mt * 2) & 7];
+          *(uint4*)(tr + 1024 + tr_base) = rres[(mt * 2 + 1) & 7];
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // cross-lane hand-off through the image
+          if (mt + 4 < 8) { LOAD_RES(mt * 2 + 8); LOAD_RES(mt * 2 + 9); }
+          float s = 0.f, ss = 0.f;
+  #pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            const uint2 rr = *(const uint2*)TW_ADDR(nt);
+            f32x4_t v = acc[mt][nt] + bs[nt];
+            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+            pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            const float r0 = __uint_as_float(pk[nt].x << 16), r1 = __uint_as_float(pk[nt].x & 0xffff0000u);
+            const float r2 = __uint_as_float(pk[nt].y << 16), r3 = __uint_as_float(pk[nt].y & 0xffff0000u);
+            s += (r0 + r1) + (r2 + r3);
+            ss += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+          }
+          if (mw0 + mt * 16 + frow >= p.M) { s = 0.f; ss = 0.f; }
+          s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
+          s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+          if (lane < 16)
+            *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane) * 8) = float2{s, ss};
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragment reads done before the image is rewritten
+        }
+        // fragment layout -> row-major image -> two 16-B-per-lane stores of 8 full rows each
+  #pragma unroll
+        for (int nt = 0; nt < 4; ++nt) *(uint2*)TW_ADDR(nt) = pk[nt];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint4 v0 = *(const uint4*)(tr + tr_base);
+        const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
+        const int ma = mw0 + mt * 16 + row_l, mb = ma + 8;
+        if (ma < p.M) *(uint4*)((bf16_t*)p.out + (size_t)ma * p.ldo + gcol) = v0;
+        if (mb < p.M) *(uint4*)((bf16_t*)p.out + (size_t)mb * p.ldo + gcol) = v1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // image reads done before the next block's writes
+      }
+
+    }
     if constexpr (EPI == EPI_RESID) {
       __syncthreads();
       if (tid < 256 && cur.m0 + tid < p.M) {
@@ -359,7 +450,7 @@ hipError_t launch_persist(const GemmParams& p, hipStream_t stream) {
 
 hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream) {
   static const int var = [] { const char* e = getenv("CLIPENC_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
-  if (epi == EPI_STORE_BF16) {
+  if (epi == EPI_STORE_BF16 && var != 0) {
     switch (var) {                            // schedule experiments (tools/gemm_sweep.py); 0 is the shipped one
       case 1: return launch_persist<EPI_STORE_BF16, 1>(p, stream);
       case 2: return launch_persist<EPI_STORE_BF16, 2>(p, stream);
@@ -368,8 +459,27 @@ hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream) 
       default: return launch_persist<EPI_STORE_BF16, 0>(p, stream);
     }
   }
+  // CLIPENC_GEMM_EPI=1 selects the "direct" epilogue (W rows permuted so a lane owns 16 consecutive columns, two 16-B
+  // stores per 16-row block, no LDS): measured equal-to-slightly-slower than the LDS-transposed whole-row stores
+  // (half-line writes cost what the LDS round trip saves), kept as an experiment switch.
+  static const int direct = [] { const char* e = getenv("CLIPENC_GEMM_EPI"); return e ? atoi(e) : 0; }();
+  if (direct) {
+    switch (epi) {
+      case EPI_STORE_BF16: return launch_persist<EPI_STORE_BF16, 16>(p, stream);
+      case EPI_LNFOLD:
+        if (p.act == CE_ACT_QUICK_GELU) return launch_persist<EPI_LNFOLD, 16 | ((CE_ACT_QUICK_GELU + 1) << 8)>(p, stream);
+        if (p.act == CE_ACT_GELU_ERF) return launch_persist<EPI_LNFOLD, 16 | ((CE_ACT_GELU_ERF + 1) << 8)>(p, stream);
+        return launch_persist<EPI_LNFOLD, 16>(p, stream);
+      case EPI_RESID: return launch_persist<EPI_RESID, 16>(p, stream);
+      default: return hipErrorInvalidValue;
+    }
+  }
   switch (epi) {
-    case EPI_LNFOLD: return launch_persist<EPI_LNFOLD, 0>(p, stream);
+    case EPI_STORE_BF16: return launch_persist<EPI_STORE_BF16, 0>(p, stream);
+    case EPI_LNFOLD:
+      if (p.act == CE_ACT_QUICK_GELU) return launch_persist<EPI_LNFOLD, (CE_ACT_QUICK_GELU + 1) << 8>(p, stream);
+      if (p.act == CE_ACT_GELU_ERF) return launch_persist<EPI_LNFOLD, (CE_ACT_GELU_ERF + 1) << 8>(p, stream);
+      return launch_persist<EPI_LNFOLD, 0>(p, stream);
     case EPI_RESID: return launch_persist<EPI_RESID, 0>(p, stream);
     default: return hipErrorInvalidValue;
   }
