@@ -27,7 +27,6 @@ MODEL = "ViT-L-14"
 IMAGES_PER_GPU = 512
 CROPS_PER_IMAGE = 4
 REG_SIZES = [4 * 768, 264, 128, 64, 1]
-DOMINANT = "gemm_nt_kernel<bf16,EPI_LNFOLD>"
 
 
 def fc_weights(seed):
@@ -69,6 +68,24 @@ def cpu_baseline(cfg, sd, Ws, bs):
             break
     return {"value": round(n_img * reps / el, 4), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{reps} x {n_img} images x 4 crops, fp32 torch CPU restatement (oracle/), {el:.1f} s"}
+
+
+def pmc_traffic(kernel_name):
+    """HBM-side bytes per launch of `kernel_name` from the latest committed rocprofv3 PMC passes
+    (profiles/*/pmc_hbm_traffic_per_kernel.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read
+    correction, written by tools/summarize_profiles.py); None when no profile has been committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_traffic_per_kernel.json")))
+    if not files:
+        return None
+    try:
+        table = json.load(open(files[-1]))
+        for k, v in table.items():
+            if kernel_name in k:
+                return round(float(v.get("bytes_per_launch", v.get("hbm_bytes", 0.0))), 1)
+    except Exception:
+        return None
+    return None
 
 
 def main():
@@ -147,6 +164,8 @@ def main():
         value = world * n_img * args.steps / elapsed
         flop_per_image = 2.0 * cfg.macs_per_crop() * CROPS_PER_IMAGE + 2.0 * sum(
             REG_SIZES[i] * REG_SIZES[i + 1] for i in range(len(REG_SIZES) - 1))
+        # dominant kernel = largest share of the step among the device kernels (names as rocprofv3 prints them)
+        DOMINANT = max((k for k in prof if not k.startswith("shape:")), key=lambda k: prof[k][0])
         d_ms, d_n, d_fl = prof[DOMINANT]
         achieved = d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
         line = {
@@ -161,12 +180,12 @@ def main():
             "end_to_end": {"tflops": round(value * flop_per_image / 1e12, 1),
                            "frac_of_bf16_peak": round(value * flop_per_image / 1e12 / (PEAK_BF16_TFLOPS * world), 4)},
             "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(DOMINANT),
                          "launches": d_n, "avg_launch_ms": round(d_ms / max(d_n, 1), 4),
                          "algorithmic_flop_per_launch": d_fl / max(d_n, 1)},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items() if not k.startswith("shape:")},
-            "gemm_shapes_tflops": {k[6:]: round(v[2] / (v[0] * 1e-3) / 1e12, 1) for k, v in prof.items()
-                                   if k.startswith("shape:") and v[0] > 0},
+            "kernels_tflops": {k.replace("shape:", ""): round(v[2] / (v[0] * 1e-3) / 1e12, 1) for k, v in prof.items()
+                               if v[0] > 0 and v[2] > 1e12},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, Ws, bs)

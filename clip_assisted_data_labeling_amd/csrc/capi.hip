@@ -63,12 +63,13 @@ struct LayerDev {
 
 }  // namespace
 
-enum { PK_PATCHIFY = 0, PK_GEMM_PATCH, PK_EMBED_LN_PRE, PK_GEMM_LNFOLD, PK_ATTENTION, PK_GEMM_RESID, PK_HEAD, PK_FCREG,
-       PK_SUB_QKV, PK_SUB_FC1, PK_SUB_OUT, PK_SUB_FC2, PK_COUNT };   // PK_SUB_*: the same launches split by shape
+// one kind per device kernel, named exactly as rocprofv3 --kernel-trace prints it (template arguments included)
+enum { PK_PATCHIFY = 0, PK_GEMM_PATCH, PK_EMBED_LN_PRE, PK_GEMM_QKV, PK_ATTENTION, PK_GEMM_RESID, PK_GEMM_FC1, PK_HEAD, PK_FCREG,
+       PK_SUB_OUT, PK_SUB_FC2, PK_COUNT };   // PK_SUB_*: the EPI_RESID launches split by shape
 static const char* const kProfileNames[PK_COUNT] = {
-    "patchify_kernel", "gemm_nt_kernel<bf16,EPI_STORE_BF16>", "embed_ln_pre_kernel", "gemm_nt_kernel<bf16,EPI_LNFOLD>",
-    "attn_kernel", "gemm_nt_kernel<bf16,EPI_RESID>", "head_kernel", "fcreg_kernel",
-    "shape:qkv(EPI_LNFOLD)", "shape:fc1(EPI_LNFOLD)", "shape:out_proj(EPI_RESID)", "shape:fc2(EPI_RESID)"};
+    "patchify_kernel<float>", "gemm_persist_kernel<1, 0>", "embed_ln_pre_kernel", "gemm_persist_kernel<2, 0>",
+    "attn_stream_kernel<9, 9, 7>", "gemm_persist_kernel<3, 0>", "gemm_persist_kernel<2, 256>", "head_kernel", "fcreg_kernel",
+    "shape:out_proj(gemm_persist_kernel<3, 0>)", "shape:fc2(gemm_persist_kernel<3, 0>)"};
 
 struct ProfRec { int kind, sub; hipEvent_t a, b; double flops; };
 
@@ -196,7 +197,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     q.A = e->x; q.lda = g.width; q.W = L.w_qkv; q.ldw = g.width; q.M = T; q.N = 3 * g.width; q.K = g.width;
     q.out = e->qkv; q.ldo = 3 * g.width; q.bias = L.b_qkv; q.colsum = L.cs_qkv;
     q.stats_in = stats_in; q.stats_in_parts = stats_parts; q.stats_ld = Tp; q.inv_width = 1.0f / g.width; q.eps = g.ln_eps; q.act = -1;
-    pf.begin(PK_GEMM_LNFOLD, 2.0 * dT * 3.0 * dD * dD, st, PK_SUB_QKV);
+    pf.begin(PK_GEMM_QKV, 2.0 * dT * 3.0 * dD * dD, st);
     HIP_TRY(ce_gemm_nt(q, CE_DT_BF16, EPI_LNFOLD, st));
     pf.end(st);
     // K4
@@ -215,7 +216,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     f.A = e->x; f.lda = g.width; f.W = L.w_fc; f.ldw = g.width; f.M = T; f.N = g.mlp_dim; f.K = g.width;
     f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
     f.stats_in = e->stats_a; f.stats_in_parts = parts; f.stats_ld = Tp; f.inv_width = 1.0f / g.width; f.eps = g.ln_eps; f.act = g.act;
-    pf.begin(PK_GEMM_LNFOLD, 2.0 * dT * dD * g.mlp_dim, st, PK_SUB_FC1);
+    pf.begin(PK_GEMM_FC1, 2.0 * dT * dD * g.mlp_dim, st);
     HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
     pf.end(st);
     // K7: x += h . Wproj^T + b
