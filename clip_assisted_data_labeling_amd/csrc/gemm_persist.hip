@@ -147,18 +147,29 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   // one K=32 stage = two phases; ISSUE_W / ISSUE_A are the DMA statements of the phases, VM the counted wait
 #define STAGE(slot, ISSUE_W, ISSUE_A, VM)                                                   \
   do {                                                                                      \
-    if (VAR & 8) { LD_A(slot, 0) __builtin_amdgcn_sched_barrier(0); LD_W(slot) }            \
-    else { LD_W(slot) __builtin_amdgcn_sched_barrier(0); LD_A(slot, 0) }                    \
-    if (!(VAR & 2)) { ISSUE_W; }                                                            \
-    BARRIER();                                                                              \
-    if (VAR & 2) { ISSUE_W; }                                                               \
-    WAIT_LDS(); MMA(0); BARRIER();                                                          \
-    LD_A(slot, 1)                                                                           \
-    if (!(VAR & 2)) { ISSUE_A; }                                                            \
-    asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                  \
-    BARRIER();                                                                              \
-    if (VAR & 2) { ISSUE_A; }                                                               \
-    WAIT_LDS(); MMA(1); BARRIER();                                                          \
+    if constexpr ((VAR & 32) != 0) {                                                        \
+      /* experiment: ONE barrier per stage, no enforced MFMA/load alternation */            \
+      LD_W(slot) LD_A(slot, 0)                                                              \
+      ISSUE_W;                                                                              \
+      WAIT_LDS(); MMA(0);                                                                   \
+      LD_A(slot, 1)                                                                         \
+      ISSUE_A;                                                                              \
+      asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                \
+      WAIT_LDS(); BARRIER(); MMA(1);                                                        \
+    } else {                                                                                \
+      if (VAR & 8) { LD_A(slot, 0) __builtin_amdgcn_sched_barrier(0); LD_W(slot) }          \
+      else { LD_W(slot) __builtin_amdgcn_sched_barrier(0); LD_A(slot, 0) }                  \
+      if (!(VAR & 2)) { ISSUE_W; }                                                          \
+      BARRIER();                                                                            \
+      if (VAR & 2) { ISSUE_W; }                                                             \
+      WAIT_LDS(); MMA(0); BARRIER();                                                        \
+      LD_A(slot, 1)                                                                         \
+      if (!(VAR & 2)) { ISSUE_A; }                                                          \
+      asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                \
+      BARRIER();                                                                            \
+      if (VAR & 2) { ISSUE_A; }                                                             \
+      WAIT_LDS(); MMA(1); BARRIER();                                                        \
+    }                                                                                       \
   } while (0)
 
   // ---- cold prologue of the first tile ----
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     frag_t fa[4], fb[4];
 
     if (p.dbg && tid == 0) p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-    if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
+    if (!(VAR & 32) && wr == 1) BARRIER();   // second wave row runs half a phase behind
 
     for (int kb = 0; kb < kend - 256; kb += 256) {
       STAGE(0, STAGE_W(2, Wblk, kb + 128), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), 6);
@@ -210,7 +221,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       STAGE(2, STAGE_W(0, Wnext, 0), STAGE_A(1, Anext, naoff0, naoff1, 64), 6);
       STAGE(3, STAGE_W(1, Wnext, 64), STAGE_A(2, Anext, naoff0, naoff1, 128), 6);
     }
-    if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
+    if (!(VAR & 32) && wr == 0) BARRIER();   // re-align the two wave rows for the epilogue
+    if (VAR & 32) BARRIER();
     if (p.dbg && tid == 0) p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime();
 
     // ------------------------------- epilogue of tile `cur` -------------------------------
@@ -456,6 +468,7 @@ hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream) 
       case 2: return launch_persist<EPI_STORE_BF16, 2>(p, stream);
       case 4: return launch_persist<EPI_STORE_BF16, 4>(p, stream);
       case 8: return launch_persist<EPI_STORE_BF16, 8>(p, stream);
+      case 32: return launch_persist<EPI_STORE_BF16, 32>(p, stream);
       default: return launch_persist<EPI_STORE_BF16, 0>(p, stream);
     }
   }

@@ -181,3 +181,57 @@ class CLIP_Encoder:
     def encode_image(self, preprocessed_images: torch.Tensor) -> torch.Tensor:
         """[n,3,R,R] -> L2-normalised [n,E] float32 on the same device (utils/embedder.py:94-100)."""
         return self.model.encode(preprocessed_images, normalize=True)
+
+
+class AestheticRegressor:
+    """The intended behaviour of /root/reference/utils/embedder.py:277-311 (defective at HEAD, SURVEY.md
+    Appendix D #3): image -> the regressor's crops -> encode -> [model][crop][E] features -> score, with
+    encode + crop selection + regressor fused in one library call (`clipenc_encode_score`) when the
+    regressor was trained on a single CLIP model.
+
+    `predict_score(pil_img)` returns `(score: float, features: Tensor[1, n_models*n_crops*E])` like the
+    reference; `predict_scores(list_of_pil)` is the batched form.
+    """
+
+    def __init__(self, model_path, device="cuda", clip_model_path=None, verbose=1):
+        from .nn_model import load_regressor
+        from .preprocess import CROP_NAMES, extract_crops
+        self.device = device
+        self._extract_crops = extract_crops
+        self._all_crops = list(CROP_NAMES)
+        self.model = load_regressor(model_path).eval()
+        if verbose:
+            print("Loaded regression model")
+            print("Aesthetic Regressor was trained on embeddings from CLIP models:")
+            print(self.model.clip_models)
+            print("Aesthetic Regressor used crops:")
+            print(self.model.crop_names)
+        unknown = [c for c in self.model.crop_names if c not in self._all_crops]
+        if unknown:
+            raise ValueError(f"regressor uses crop names this build does not produce: {unknown}")
+        self.clip_models = [CLIP_Encoder(name, clip_model_path, device=self.device) for name in self.model.clip_models]
+        self._reg = self.model.hip_regressor(self.clip_models[0].model.device)
+        self._select = [self._all_crops.index(c) for c in self.model.crop_names]
+
+    @torch.no_grad()
+    def predict_scores(self, pil_imgs):
+        n = len(pil_imgs)
+        feats = []
+        score = None
+        for enc in self.clip_models:
+            tf = enc.get_preprocess_transform()
+            crops = torch.stack([tf(c) for img in pil_imgs for c in self._extract_crops(img.convert("RGB"), self._all_crops)[0]])
+            if len(self.clip_models) == 1:
+                emb, score = enc.model.encode_score(crops, self._reg, len(self._all_crops), self._select)
+            else:
+                emb = enc.model.encode(crops).view(n, len(self._all_crops), -1)
+            feats.append(emb[:, self._select, :].reshape(n, -1))
+        features = torch.cat(feats, dim=1)
+        if score is None:
+            score = self._reg(features)
+        return score.reshape(n, -1)[:, 0], features
+
+    @torch.no_grad()
+    def predict_score(self, pil_img):
+        score, features = self.predict_scores([pil_img])
+        return float(score[0].item()), features

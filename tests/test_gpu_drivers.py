@@ -92,3 +92,36 @@ def test_embed_predict_dedup_pipeline(gpu, tmp_path):
     dedup_driver.find_near_duplicates(dargs)
     out = os.listdir(str(tmp_path / f"near_duplicates_cosine_{thr}"))
     assert any("_source_a000.jpg" in f for f in out) and any("_target_a008.pt" in f for f in out)
+
+
+def test_aesthetic_regressor_fused_single_image(gpu, tmp_path):
+    """The composition utils/embedder.py:298-311 intends: image -> crops -> encode -> [crop][E] -> score."""
+    from clip_assisted_data_labeling_amd.embedder import AestheticRegressor
+    from clip_assisted_data_labeling_amd.predict_simple import predict_images
+    cfg = vit_config.config_for(MODEL)
+    sd = vit_config.seeded_state_dict(cfg, 4)
+    sizes = [3 * cfg.embed_dim, 40, 12, 1]
+    Ws, bs = np_fc_weights(sizes, 9)
+    m = SimpleFC(sizes[0], sizes[1:-1], 1, clip_models=[MODEL], crop_names=["subcrop2", "centre_crop", "square_padded_crop"])
+    with torch.no_grad():
+        for layer, W, b in zip(m._linears(), Ws, bs):
+            layer.weight.copy_(torch.from_numpy(W)); layer.bias.copy_(torch.from_numpy(b))
+    torch.save(m, tmp_path / "reg.pth")
+    rs = np.random.RandomState(11)
+    imgs = [Image.fromarray(rs.randint(0, 256, (rs.randint(120, 260), rs.randint(120, 260), 3), dtype=np.uint8)) for _ in range(3)]
+    reg = AestheticRegressor(str(tmp_path / "reg.pth"), device="cuda", verbose=0)
+    score, feats = reg.predict_score(imgs[1])
+    assert isinstance(score, float) and feats.shape == (1, 3 * cfg.embed_dim)
+    crops, names = extract_crops(imgs[1].convert("RGB"))
+    ref = vit_oracle.encode_image(sd, cfg, torch.stack([ClipValTransform(cfg.image_size)(c) for c in crops]))
+    ref_feat = torch.cat([ref[names.index(c)] for c in m.crop_names]).numpy()[None]      # model.crop_names order
+    assert one_minus_cos(feats.cpu().view(3, -1), torch.from_numpy(ref_feat).view(3, -1)).max().item() < 1e-3
+    assert abs(score - fcreg_oracle.forward_c(Ws, bs, feats.cpu().numpy())[0, 0]) < 1e-4
+    batch_scores, _ = reg.predict_scores(imgs)
+    assert abs(float(batch_scores[1]) - score) < 1e-5
+    os.makedirs(tmp_path / "in")
+    for i, im in enumerate(imgs):
+        im.save(tmp_path / "in" / f"p{i}.png")
+    res = predict_images([str(tmp_path / "in" / f"p{i}.png") for i in range(3)], str(tmp_path / "reg.pth"), "cuda",
+                         str(tmp_path / "out"))
+    assert len(res) == 3 and len(os.listdir(tmp_path / "out")) == 3

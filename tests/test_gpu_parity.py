@@ -322,3 +322,24 @@ def test_dedup_edge_cases(gpu):
     assert c == 0
     c, p, _ = _run_dedup(gpu, torch.ones(5, 100).half(), 0.5, fp16_compare=0)   # d not a multiple of 128; all identical
     assert c == 10
+
+
+def test_dedup_larger_set_vs_oracle(gpu):
+    """6 000 x 768 with planted pairs swept across the threshold: 24 x 24 tiles, 300 upper-triangular workgroups."""
+    g = torch.Generator().manual_seed(3)
+    n, d, planted = 6000, 768, 120
+    e = torch.randn(n, d, generator=g)
+    src = torch.randperm(n - planted, generator=g)[:planted]
+    for t, s_ in enumerate(src.tolist()):
+        e[n - planted + t] = e[s_] + (0.05 + 0.4 * t / planted) * torch.randn(d, generator=g)
+    e16 = e.half()
+    thr = 0.96
+    c, p, v = _run_dedup(gpu, e16, thr)
+    op, ov = dedup_oracle.near_duplicates(e16, thr)
+    s32 = dedup_oracle.similarity_fp32(e16).numpy()
+    gold = {tuple(r) for r in op.tolist()}
+    got = {tuple(r) for r in p.tolist()}
+    assert c == len(got) and 20 < len(gold) < planted
+    for (i, j) in gold ^ got:                                  # only fp16-ulp ties at the threshold may differ
+        assert abs(s32[i, j] - thr) < 1e-3, (i, j, s32[i, j])
+    assert len(gold & got) >= len(gold) - 3
