@@ -67,9 +67,11 @@ struct LayerDev {
 enum { PK_PATCHIFY = 0, PK_GEMM_PATCH, PK_EMBED_LN_PRE, PK_GEMM_QKV, PK_ATTENTION, PK_GEMM_RESID, PK_GEMM_FC1, PK_HEAD, PK_FCREG,
        PK_SUB_OUT, PK_SUB_FC2, PK_COUNT };   // PK_SUB_*: the EPI_RESID launches split by shape
 static const char* const kProfileNames[PK_COUNT] = {
-    "patchify_kernel<float>", "gemm_persist_kernel<1, 0>", "embed_ln_pre_kernel", "gemm_persist_kernel<2, 0>",
-    "attn_stream_kernel<9, 9, 7>", "gemm_persist_kernel<3, 0>", "gemm_persist_kernel<2, 256>", "head_kernel", "fcreg_kernel",
-    "shape:out_proj(gemm_persist_kernel<3, 0>)", "shape:fc2(gemm_persist_kernel<3, 0>)"};
+    "patchify_kernel<float>", "gemm_persist_kernel<1, -1>", "embed_ln_pre_kernel", "gemm_persist_kernel<2, -1>",
+    "attn_stream_kernel<9, 9, 7>", "gemm_persist_kernel<3, -1>", "gemm_persist_kernel<2, 0>", "head_kernel", "fcreg_kernel",
+    "shape:out_proj(gemm_persist_kernel<3, -1>)", "shape:fc2(gemm_persist_kernel<3, -1>)"};
+// (template arguments: <EPI, ACT>; FC1 is <2, 0> with QuickGELU and <2, 1> with erf-GELU; the attention name is the
+//  ViT-L/14 instantiation, other token counts use attn_kernel<NKT> / attn_long_kernel<7>)
 
 struct ProfRec { int kind, sub; hipEvent_t a, b; double flops; };
 
@@ -415,7 +417,7 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
   if (kind < 0 || kind >= PK_COUNT) return fail("profile kind %d out of range", kind);
   HIP_TRY(hipSetDevice(e->device));
   e->prof.collect();
-  if (name) *name = kProfileNames[kind];
+  if (name) *name = (kind == PK_GEMM_FC1 && e->cfg.act == CLIPENC_ACT_GELU_ERF) ? "gemm_persist_kernel<2, 1>" : kProfileNames[kind];
   if (total_ms) *total_ms = e->prof.ms[kind];
   if (launches) *launches = e->prof.launches[kind];
   if (algorithmic_flops) *algorithmic_flops = e->prof.flops[kind];

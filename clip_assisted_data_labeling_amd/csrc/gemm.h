@@ -28,8 +28,6 @@ struct GemmParams {
   unsigned long long cap;
   unsigned long long* count;
   unsigned long long* dbg;       // optional [tiles][8] timing stamps (diagnostic entry point only)
-  int tile_order;                // 0: XCD-chunked + 8-tile M groups (default); 1: plain grouped; 2: XCD-chunked + 4-tile groups
-  int stagger_ns;                // spread of the first-wave start delays (set by the launcher)
 };
 
 hipError_t ce_gemm_nt(const GemmParams& p, int dtype, int epi, hipStream_t stream);

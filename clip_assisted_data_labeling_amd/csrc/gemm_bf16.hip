@@ -1,38 +1,36 @@
-// bf16/f16 "NT" GEMM for the ViT tower:  C[M,N] = A[M,K] . W[N,K]^T  with fp32 accumulation and a
-// fused epilogue.  gfx950 only: MFMA 16x16x32, LDS-DMA staging (global_load_lds_dwordx4), 8 waves.
+// bf16/f16 "NT" GEMM:  C[M,N] = A[M,K] . W[N,K]^T  with fp32 accumulation.  gfx950 only: MFMA 16x16x32,
+// LDS-DMA staging (global_load_lds_dwordx4), 8 waves.
 //
-// This kernel carries K1, K3, K5, K6, K7 of SURVEY.md §2.2 (the arithmetic open_clip performs for
-// /root/reference/utils/embedder.py:98) and, with f16 operands, K11 (the E.E^T of
-// /root/reference/_2_remove_duplicates.py:69).
+// This file holds (a) the host entry ce_gemm_nt, which validates the shape contract and routes the bf16
+// epilogues of the ViT tower (K1, K3, K5, K6, K7 of SURVEY.md §2.2) to the persistent kernel in
+// gemm_persist.hip, and (b) the one-tile-per-workgroup kernel that carries the two remaining epilogues:
+// plain fp32 output (operator-level parity tests) and, on f16 operands, the thresholded upper-triangular
+// E.E^T of the near-duplicate search (K11; /root/reference/_2_remove_duplicates.py:69-80).
 //
-// Tile: 256 x 256 x 64 per workgroup, 8 waves as 2 (M) x 4 (N), each wave owns 128 x 64 of C held
-// as acc[8 m-tiles][4 n-tiles] of 16x16 (128 fp32 VGPRs).  The MFMA is issued as
-// D = Wfrag . Afrag^T, so a lane ends up with 4 CONSECUTIVE output columns of one row
-// (row = lane&15, cols = 4*(lane>>4)+reg): epilogue loads/stores are 8 B (bf16) / 16 B (f32) per lane.
+// Tile: 256 x 256 per workgroup, 8 waves as 2 (M) x 4 (N), each wave owns 128 x 64 of C held as
+// acc[8 m-tiles][4 n-tiles] of 16x16 (128 fp32 VGPRs).  The MFMA is issued as D = Wfrag . Afrag^T, so a lane
+// ends up with 4 CONSECUTIVE output columns of one row (row = lane&15, cols = 4*(lane>>4)+reg).
 //
-// LDS (128 KiB): 2 buffers x { A rows 0-127 | A rows 128-255 | W rows 0-127 | W rows 128-255 },
-// each half-tile 128 rows x 64 k = 16 KiB.  Rows are 128 B; the 16-B chunk index is XOR-ed with
-// (row>>1)&7, which makes every ds_read_b128 of a fragment conflict-free (guide T2).  The LDS-DMA
-// writes LDS linearly (lane*16), so the swizzle is applied to the per-lane SOURCE address and to the
-// read address (guide rule 21).
+// LDS (128 KiB): 4-slot ring of K=32 stages, each A part 16 KiB | W part 16 KiB.  LDS subtile = 16 rows x
+// 64 B (1 KiB, what one LDS-DMA instruction writes); 16-B chunk c of row r sits at chunk c ^ (2*(r>>3)):
+// every ds_read_b128 fragment read is conflict-free.  The LDS-DMA writes LDS linearly (lane*16), so the
+// swizzle is applied to the per-lane SOURCE address and to the read address (guide rule 21).
 //
-// Schedule: 4 phases per K-tile, each phase = ds_read one register sub-tile + stage one half-tile,
-// s_barrier, 16 MFMAs (one 64x32 quadrant of the wave tile x K=64), s_barrier.  The two wave rows
-// (wr=0 / wr=1; they are the two waves of every SIMD) run half a phase apart, so one issues MFMAs
-// while the other issues LDS reads and DMA.  DMA stays in flight across barriers; one counted
-// s_waitcnt vmcnt per K-tile (phase 4) retires the next tile.  Ordering proof is in DESIGN.md §GEMM.
-#include <stdlib.h>
-
+// Schedule: two phases per stage, each {ds_read fragments, issue 2 DMA} s_barrier {16 MFMA} s_barrier:
+//   (a) reads W frags + A frags of m-tiles 0-3, issues the W part of stage t+2;
+//   (b) reads A frags of m-tiles 4-7, issues the A part of stage t+3, and retires stage t+1 with ONE counted
+//       vmcnt that leaves the 3 youngest parts (6 DMA) in flight.
+// The two wave rows (wr = 0 / 1: the two waves of every SIMD) run half a phase apart, so one issues MFMAs
+// while the other issues LDS reads and DMA.  A slot is re-staged >= 2 phases after its last read; a stage is
+// read >= 1 phase after the wait that retired it.
 #include "common.h"
 #include "gemm.h"
 
 namespace {
 
-constexpr int BM = 256, BN = 256, BK = 64;
-constexpr int HALF = 128 * BK * 2;          // 16384 B
-constexpr int BUF = 4 * HALF;               // 65536 B: A0 A1 W0 W1
-constexpr int AUX_OFF = 2 * BUF;            // 8 KiB behind the ring: row statistics
-constexpr int LDS_BYTES = 2 * BUF + 8192;   // 139264 B
+constexpr int BM = 256, BN = 256;
+constexpr int STG = 32768, WPART = 16384;
+constexpr int LDS_BYTES = 4 * STG;          // 131072 B
 
 #define LDS_PTR(off) ((__attribute__((address_space(3))) void*)(smem + (off)))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -51,24 +49,12 @@ template <> struct Mfma<_Float16> {
   }
 };
 
-__device__ __forceinline__ float act_apply(float u, int act) {
-  // u * sigmoid(1.702 u) = u / (1 + 2^(-1.702*log2(e)*u)): one v_exp_f32 + one v_rcp_f32 (a full fp32 divide costs ~10 more VALU ops)
-  if (act == CE_ACT_QUICK_GELU) return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * u));
-  if (act == CE_ACT_GELU_ERF) return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
-  return u;
-}
-
 // one LDS-DMA instruction: 64 lanes x 16 B -> 1 KiB of LDS at `lds_off` (wave-uniform) + lane*16
 __device__ __forceinline__ void glds16(const char* g, char* smem, int lds_off) {
   __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(lds_off), 16, 0, 0);
 }
 
-#define STAMP(i)                                                                           \
-  do {                                                                                     \
-    if (p.dbg && tid == 0) p.dbg[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); \
-  } while (0)
-
-template <typename T, int EPI, int IMPL>
+template <typename T, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
   typedef typename Mfma<T>::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -78,19 +64,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = w >> 2, wc = w & 3;
 
-  STAMP(0);
-  // ---- tile id: XCD-aware (blocks b, b+8, ... share an L2) + grouped along M ----
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
-  const int nwg = tiles_m * tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;      // bijective (guide §5)
-  }
-  constexpr int GM = 8;
   int tm, tn;
   if (EPI == EPI_THRESH) {
-    // upper-triangular tile list, row-major: row tm holds tiles tn = tm .. T-1
+    // upper-triangular tile list, row-major: row tm holds tiles tn = tm .. TT-1
     const int TT = tiles_n;
     const int b = blockIdx.x;
     int t = (int)(((2.0 * TT + 1.0) - sqrt((2.0 * TT + 1.0) * (2.0 * TT + 1.0) - 8.0 * (double)b)) * 0.5);
@@ -100,6 +77,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
     tm = t;
     tn = t + (b - (t * TT - t * (t - 1) / 2));
   } else {
+    // XCD-aware (blocks b, b+8, ... share an L2; bijective remap, guide §5) + groups of 8 tiles along M
+    const int nwg = tiles_m * tiles_n;
+    const int q = nwg >> 3, r = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    constexpr int GM = 8;
     const int group = bid / (GM * tiles_n);
     const int first_m = group * GM;
     const int gsz = min(tiles_m - first_m, GM);
@@ -108,16 +90,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
   }
   const int m0 = tm * BM, n0 = tn * BN;
 
-  // De-synchronise the CUs: every tile costs the same, so without this all 256 workgroups reach their
-  // epilogue together and the output burst (256 x 128 KiB) is HBM-write bound while the MFMAs idle.
-  // The first workgroup of each CU starts after a distinct delay spread over one tile time; later
-  // workgroups inherit the offset because a CU takes its next tile when it finishes the previous one.
-  if (p.stagger_ns > 0 && blockIdx.x < 256) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();           // 100 MHz
-    const unsigned long long wait = ((unsigned long long)((blockIdx.x * 97) & 255) * p.stagger_ns) / 2560;
-    while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-  }
-
   f32x4_t acc[8][4];
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -125,157 +97,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15;
 
-  // EPI_LNFOLD: (mean, rstd) of the tile's 256 rows from the producer's per-row partial sums.  The loads
-  // are issued here, ahead of the prologue DMA, and consumed after it (LNFOLD_FINISH) so their latency
-  // hides behind the first stages; the values are read back from LDS in the epilogue.
-  float ln_s = 0.f, ln_ss = 0.f;
-  if constexpr (EPI == EPI_LNFOLD) {
-    if (tid < 256) {
-      const int m = min(m0 + tid, p.M - 1);
-      for (int part = 0; part < p.stats_in_parts; ++part) {
-        const float2 t = *(const float2*)(p.stats_in + ((size_t)part * p.stats_ld + m) * 2);
-        ln_s += t.x; ln_ss += t.y;
-      }
-    }
-  }
-#define LNFOLD_FINISH()                                                                   \
-  if constexpr (EPI == EPI_LNFOLD) {                                                      \
-    if (tid < 256) {                                                                      \
-      const float mean = ln_s * p.inv_width;                                              \
-      const float var = fmaxf(ln_ss * p.inv_width - mean * mean, 0.f);                    \
-      *(float2*)(smem + AUX_OFF + tid * 8) = float2{mean, rsqrtf(var + p.eps)};           \
-    }                                                                                     \
-  }
-  if constexpr (IMPL == 1) {
-  // ---- LDS-DMA source offsets (per lane, relative to the tile's first row) ----
-  // instruction j of a half-tile fills LDS rows 64j + 8w + (lane>>3); LDS chunk lane&7 holds logical
-  // chunk (lane&7) ^ ((row>>1)&7), and (row>>1)&7 == 4*(w&1) + (lane>>4) for both j.
-  const int lrow = 8 * w + (lane >> 3);
-  const int lchunk = (lane & 7) ^ (4 * (w & 1) + (lane >> 4));
-  const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
-  const char* Ablk = (const char*)p.A + (size_t)m0 * lda_b;
-  const char* Wblk = (const char*)p.W + (size_t)n0 * ldw_b;
-  int aoff[4], woff[4];                      // [half*2 + j]
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int r = 64 * i + lrow;                   // row inside the 256-row tile
-    int ra = min(m0 + r, p.M - 1) - m0;      // M edge: re-read the last valid row (masked at store)
-    aoff[i] = (int)(ra * lda_b) + lchunk * 16;
-    woff[i] = (int)(r * ldw_b) + lchunk * 16;
-  }
-  const int dma_lds = w * 1024;              // + 8192 for j = 1
-
-  // ---- fragment read offsets ----
-  const int rd0 = frow * 128 + (((lane >> 4) ^ ((frow >> 1) & 7)) << 4);      // k-step 0
-  const int rd1 = rd0 ^ 64;                                                   // k-step 1 (chunk + 4)
-  const int a_base = wr * HALF;                                               // + buf*BUF + mt*2048
-  const int w_base = 2 * HALF + (wc >> 1) * HALF + (wc & 1) * 64 * 128;       // + buf*BUF + nt*2048
-
-  frag_t fa[8], fb0[4], fb1[4];
-
-#define STAGE_A(buf, half, kbyte)                                                            \
-  do {                                                                                       \
-    glds16(Ablk + (kbyte) + aoff[(half) * 2 + 0], smem, (buf) * BUF + (half) * HALF + dma_lds);          \
-    glds16(Ablk + (kbyte) + aoff[(half) * 2 + 1], smem, (buf) * BUF + (half) * HALF + 8192 + dma_lds);   \
-  } while (0)
-#define STAGE_W(buf, half, kbyte)                                                            \
-  do {                                                                                       \
-    glds16(Wblk + (kbyte) + woff[(half) * 2 + 0], smem, (buf) * BUF + 2 * HALF + (half) * HALF + dma_lds);        \
-    glds16(Wblk + (kbyte) + woff[(half) * 2 + 1], smem, (buf) * BUF + 2 * HALF + (half) * HALF + 8192 + dma_lds); \
-  } while (0)
-#define LD_A(buf, mi)                                                                        \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                            \
-    fa[i * 2 + 0] = *(const frag_t*)(smem + (buf) * BUF + a_base + ((mi) * 4 + i) * 2048 + rd0); \
-    fa[i * 2 + 1] = *(const frag_t*)(smem + (buf) * BUF + a_base + ((mi) * 4 + i) * 2048 + rd1); \
-  }
-#define LD_W(dst, buf, ni)                                                                   \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                            \
-    dst[i * 2 + 0] = *(const frag_t*)(smem + (buf) * BUF + w_base + ((ni) * 2 + i) * 2048 + rd0); \
-    dst[i * 2 + 1] = *(const frag_t*)(smem + (buf) * BUF + w_base + ((ni) * 2 + i) * 2048 + rd1); \
-  }
-#define MMA(mi, ni, fbx)                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i)                                              \
-  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
-    acc[(mi) * 4 + i][(ni) * 2 + j] = Mfma<T>::run(fbx[j * 2 + 0], fa[i * 2 + 0], acc[(mi) * 4 + i][(ni) * 2 + j]); \
-    acc[(mi) * 4 + i][(ni) * 2 + j] = Mfma<T>::run(fbx[j * 2 + 1], fa[i * 2 + 1], acc[(mi) * 4 + i][(ni) * 2 + j]); \
-  }
-#define BARRIER() asm volatile("s_barrier" ::: "memory")
-#define WAIT_LDS()                                                                           \
-  do {                                                                                       \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
-    __builtin_amdgcn_sched_barrier(0);                                                       \
-  } while (0)
-#define COMPUTE(mi, ni, fbx)                                                                 \
-  do {                                                                                       \
-    __builtin_amdgcn_s_setprio(1);                                                           \
-    MMA(mi, ni, fbx)                                                                         \
-    __builtin_amdgcn_s_setprio(0);                                                           \
-  } while (0)
-
-  const int nk = p.K / BK;                   // even (host-checked)
-
-  // ---- prologue: tile 0 (4 half-tiles) + W0 of tile 1 ----
-  STAGE_A(0, 0, 0); STAGE_A(0, 1, 0); STAGE_W(0, 0, 0); STAGE_W(0, 1, 0);
-  if (nk > 1) STAGE_W(1, 0, 128);
-  LNFOLD_FINISH()
-  if (nk > 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  BARRIER();
-  if (wr == 1) BARRIER();                    // second wave row runs half a phase behind
-
-  // One K-tile = 4 phases.  `cur` is the buffer being computed; staging targets:
-  //   ph1: W1 of tile t+1 -> buf cur^1      ph2: A0 of tile t+1 -> buf cur^1
-  //   ph3: A1 of tile t+1 -> buf cur^1      ph4: W0 of tile t+2 -> buf cur   (+ counted vmcnt)
-#define KTILE(cur, kb)                                                                       \
-  do {                                                                                       \
-    const bool has1 = (kb) + 128 < kend, has2 = (kb) + 256 < kend;                           \
-    /* phase 1 */                                                                            \
-    LD_W(fb0, cur, 0) __builtin_amdgcn_sched_barrier(0); LD_A(cur, 0)                        \
-    if (has1) STAGE_W((cur) ^ 1, 1, (kb) + 128);                                             \
-    BARRIER(); WAIT_LDS(); COMPUTE(0, 0, fb0); BARRIER();                                    \
-    /* phase 2 */                                                                            \
-    LD_W(fb1, cur, 1)                                                                        \
-    if (has1) STAGE_A((cur) ^ 1, 0, (kb) + 128);                                             \
-    BARRIER(); WAIT_LDS(); COMPUTE(0, 1, fb1); BARRIER();                                    \
-    /* phase 3 */                                                                            \
-    LD_A(cur, 1)                                                                             \
-    if (has1) STAGE_A((cur) ^ 1, 1, (kb) + 128);                                             \
-    BARRIER(); WAIT_LDS(); COMPUTE(1, 1, fb1); BARRIER();                                    \
-    /* phase 4 */                                                                            \
-    if (has2) { STAGE_W(cur, 0, (kb) + 256); asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); } \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                    \
-    BARRIER(); COMPUTE(1, 0, fb0); BARRIER();                                                \
-  } while (0)
-
-  const int kend = p.K * 2;                  // bytes along K
-  for (int kb = 0; kb < kend; kb += 256) {
-    KTILE(0, kb);
-    KTILE(1, kb + 128);
-  }
-  if (wr == 0) BARRIER();                    // re-align the two wave rows
-
-  } else {
-
-  // ================= IMPL 2: 4-slot ring of K=32 stages (A part 16 KiB | W part 16 KiB per slot) =================
-  // LDS subtile = 16 rows x 64 B (1 KiB, what one LDS-DMA instruction writes); 16-B chunk c of row r sits at
-  // chunk c ^ (2*(r>>3)) (guide "st_16x32"): every ds_read_b128 fragment read is conflict-free.
-  // Two phases per stage: (a) reads W frags + A frags of m-tiles 0-3, issues the W part of stage t+2;
-  //                       (b) reads A frags of m-tiles 4-7, issues the A part of stage t+3, and retires stage
-  //                           t+1 with ONE counted vmcnt that leaves the 3 youngest parts (6 DMA) in flight.
-  // A slot is re-staged >= 2 phases after its last read; a stage is read >= 1 phase after the wait that
-  // retired it (both with the half-phase stagger of the two wave rows taken into account: DESIGN.md).
   {
-    constexpr int STG = 32768, WPART = 16384;
     const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
     const char* Ablk = (const char*)p.A + (size_t)m0 * lda_b;
     const char* Wblk = (const char*)p.W + (size_t)n0 * ldw_b;
+    // DMA instruction j of a part fills subtile 8j + w: rows 16(8j+w) + (lane>>2); LDS chunk lane&3 holds
+    // logical chunk (lane&3) ^ (2*((lane>>5)&1))
     const int lrow = 16 * w + (lane >> 2);
     const int lchunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
     int aoff[2], woff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int r = 128 * j + lrow;
-      const int ra = min(m0 + r, p.M - 1) - m0;
+      const int ra = min(m0 + r, p.M - 1) - m0;          // M edge: re-read the last valid row (masked at store)
       aoff[j] = (int)(ra * lda_b) + lchunk * 16;
       woff[j] = (int)(r * ldw_b) + lchunk * 16;
     }
@@ -285,21 +119,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
     const int w_rd = WPART + wc * 4 * 1024 + rd;         // + slot*STG + nt*1024
     frag_t fa[4], fb[4];
 
-#define S2_STAGE_A(slot, kbyte)                                                             \
+#define STAGE_A(slot, kbyte)                                                                \
   do {                                                                                      \
     glds16(Ablk + (kbyte) + aoff[0], smem, (slot) * STG + dma_lds);                          \
     glds16(Ablk + (kbyte) + aoff[1], smem, (slot) * STG + 8192 + dma_lds);                   \
   } while (0)
-#define S2_STAGE_W(slot, kbyte)                                                             \
+#define STAGE_W(slot, kbyte)                                                                \
   do {                                                                                      \
     glds16(Wblk + (kbyte) + woff[0], smem, (slot) * STG + WPART + dma_lds);                  \
     glds16(Wblk + (kbyte) + woff[1], smem, (slot) * STG + WPART + 8192 + dma_lds);           \
   } while (0)
-#define S2_LD_W(slot)                                                                       \
-  _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (slot) * STG + w_rd + j * 1024);
-#define S2_LD_A(slot, half)                                                                 \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (slot) * STG + a_rd + ((half) * 4 + i) * 1024);
-#define S2_MMA(half)                                                                        \
+#define LD_W(slot) _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (slot) * STG + w_rd + j * 1024);
+#define LD_A(slot, half) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (slot) * STG + a_rd + ((half) * 4 + i) * 1024);
+#define MMA(half)                                                                           \
   do {                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
@@ -307,48 +139,43 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
       acc[(half) * 4 + i][j] = Mfma<T>::run(fb[j], fa[i], acc[(half) * 4 + i][j]);          \
     __builtin_amdgcn_s_setprio(0);                                                          \
   } while (0)
-#define S2_BARRIER() asm volatile("s_barrier" ::: "memory")
-#define S2_WAIT_LDS()                                                                       \
+#define BARRIER() asm volatile("s_barrier" ::: "memory")
+#define WAIT_LDS()                                                                          \
   do {                                                                                      \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
-#define S2_STAGE(slot, kb)                                                                  \
+#define STAGE(slot, kb)                                                                     \
   do {                                                                                      \
     /* phase a */                                                                           \
-    S2_LD_W(slot) __builtin_amdgcn_sched_barrier(0); S2_LD_A(slot, 0)                       \
-    if ((kb) + 128 < kend) S2_STAGE_W(((slot) + 2) & 3, (kb) + 128);                        \
-    S2_BARRIER(); S2_WAIT_LDS(); S2_MMA(0); S2_BARRIER();                                   \
+    LD_W(slot) __builtin_amdgcn_sched_barrier(0); LD_A(slot, 0)                             \
+    if ((kb) + 128 < kend) STAGE_W(((slot) + 2) & 3, (kb) + 128);                           \
+    BARRIER(); WAIT_LDS(); MMA(0); BARRIER();                                               \
     /* phase b */                                                                           \
-    S2_LD_A(slot, 1)                                                                        \
-    if ((kb) + 192 < kend) { S2_STAGE_A(((slot) + 3) & 3, (kb) + 192); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } \
+    LD_A(slot, 1)                                                                           \
+    if ((kb) + 192 < kend) { STAGE_A(((slot) + 3) & 3, (kb) + 192); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } \
     else if ((kb) + 128 < kend) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            \
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
-    S2_BARRIER(); S2_WAIT_LDS(); S2_MMA(1); S2_BARRIER();                                   \
+    BARRIER(); WAIT_LDS(); MMA(1); BARRIER();                                               \
   } while (0)
 
     const int kend = p.K * 2;                // bytes along K; one stage = 64 B; K % 128 == 0 -> >= 4 stages
-    S2_STAGE_A(0, 0); S2_STAGE_W(0, 0); S2_STAGE_A(1, 64); S2_STAGE_W(1, 64); S2_STAGE_A(2, 128);
-    LNFOLD_FINISH()
+    STAGE_A(0, 0); STAGE_W(0, 0); STAGE_A(1, 64); STAGE_W(1, 64); STAGE_A(2, 128);
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    S2_BARRIER();
-    STAMP(1);
-    if (wr == 1) S2_BARRIER();               // second wave row runs half a phase behind
+    BARRIER();
+    if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
     for (int kb = 0; kb < kend; kb += 256) {
-      S2_STAGE(0, kb);
-      S2_STAGE(1, kb + 64);
-      S2_STAGE(2, kb + 128);
-      S2_STAGE(3, kb + 192);
+      STAGE(0, kb);
+      STAGE(1, kb + 64);
+      STAGE(2, kb + 128);
+      STAGE(3, kb + 192);
     }
-    if (wr == 0) S2_BARRIER();               // re-align the two wave rows
-    STAMP(2);
-  }
+    if (wr == 0) BARRIER();                  // re-align the two wave rows
   }
 
   // ---------------------------------- epilogue ----------------------------------
-  const int q4 = (lane >> 4) * 4;
-  const int ncol0 = n0 + wc * 64 + q4;       // + nt*16
-  const int mrow0 = m0 + wr * 128 + frow;    // + mt*16
+  const int ncol0 = n0 + wc * 64 + (lane >> 4) * 4;   // + nt*16
+  const int mrow0 = m0 + wr * 128 + frow;             // + mt*16
 
   if constexpr (EPI == EPI_STORE_F32) {
 #pragma unroll
@@ -360,122 +187,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
           float* o = (float*)p.out + (size_t)m * p.ldo + ncol0 + nt * 16;
           *(f32x4_t*)o = acc[mt][nt];
         }
-      }
-    }
-  } else if constexpr (EPI == EPI_STORE_BF16 || EPI == EPI_LNFOLD || EPI == EPI_RESID) {
-    // bf16 epilogues go through a wave-private 16 KiB LDS tile (the ring is idle: every wave has passed
-    // the final barrier, so all fragment reads and all DMA writes are complete).  A lane holds 4
-    // consecutive columns of 32 different (row, column-group) pairs; written as 8-B pieces into a
-    // [128 rows][128 B] image (16-B chunk index XOR row&7) and read back as whole 16-B chunks, one
-    // store instruction covers 8 full 128-B lines instead of 16 x 32-B fragments (store-issue bound
-    // otherwise: guide T21).  The residual is loaded through the same image in the other direction.
-    char* wl = smem + w * 16384;
-    const int qd = lane >> 4;
-    const int tw_base = frow * 128 + (qd & 1) * 8;                       // + mt*2048 + swizzled chunk
-    const int tw_sw = frow & 7;
-    const int tr_base = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // + k*1024
-    const int row_l = lane >> 3;                                         // + 8k : row inside the wave tile
-    const size_t gcol = (size_t)n0 + wc * 64 + (lane & 7) * 8;
-    const int mw0 = m0 + wr * 128;
-#define TW_ADDR(mt, nt) (wl + (mt) * 2048 + tw_base + ((((nt) * 2 + (qd >> 1)) ^ tw_sw) << 4))
-
-    if constexpr (EPI == EPI_STORE_BF16) {
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          f32x4_t v = acc[mt][nt];
-          if (p.bias) { f32x4_t bb = *(const f32x4_t*)(p.bias + ncol0 + nt * 16); v += bb; }
-          *(uint2*)TW_ADDR(mt, nt) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        }
-    } else if constexpr (EPI == EPI_LNFOLD) {
-      // out = act( rstd_m * (acc - mean_m * colsum_n) + bias_n ): LayerNorm folded into the GEMM;
-      // (mean, rstd) of the tile's rows were put in LDS by the prologue.
-      const float2* mr = (const float2*)(smem + AUX_OFF);
-      f32x4_t cs[4], bs[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) {
-        cs[nt] = *(const f32x4_t*)(p.colsum + ncol0 + nt * 16);
-        bs[nt] = *(const f32x4_t*)(p.bias + ncol0 + nt * 16);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        const float2 t = mr[wr * 128 + mt * 16 + frow];
-        const float mean = t.x, rstd = t.y;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          f32x4_t v;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v[e] = act_apply(rstd * (acc[mt][nt][e] - mean * cs[nt][e]) + bs[nt][e], p.act);
-          *(uint2*)TW_ADDR(mt, nt) = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-        }
-      }
-    } else {
-      // x_new = acc + bias + resid (bf16, may alias out); also per-row (sum, sumsq) of the ROUNDED x_new
-      // over this tile's 256 columns -> stats_out[tn][m][2] for the next LayerNorm-folded GEMM.
-      float* red = (float*)(smem + AUX_OFF);             // [4 wc][256 rows][2]
-      {
-        uint4 rr[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int m = mw0 + k * 8 + row_l;
-          rr[k] = uint4{0, 0, 0, 0};
-          if (m < p.M) rr[k] = *(const uint4*)((const bf16_t*)p.resid + (size_t)m * p.ldo + gcol);
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) *(uint4*)(wl + k * 1024 + tr_base) = rr[k];
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      f32x4_t bs[4];
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(p.bias + ncol0 + nt * 16);
-      uint2 pk[8][4];
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const uint2 rr = *(const uint2*)TW_ADDR(mt, nt);
-          f32x4_t v = acc[mt][nt] + bs[nt];
-          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-          pk[mt][nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          const float r0 = __uint_as_float(pk[mt][nt].x << 16), r1 = __uint_as_float(pk[mt][nt].x & 0xffff0000u);
-          const float r2 = __uint_as_float(pk[mt][nt].y << 16), r3 = __uint_as_float(pk[mt][nt].y & 0xffff0000u);
-          s += (r0 + r1) + (r2 + r3);
-          ss += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
-        }
-        if (mrow0 + mt * 16 >= p.M) { s = 0.f; ss = 0.f; }
-        s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
-        s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-        if (lane < 16) *(float2*)(red + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane) * 2) = float2{s, ss};
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // all fragment reads of the image done before it is overwritten
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) *(uint2*)TW_ADDR(mt, nt) = pk[mt][nt];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const uint4 v = *(const uint4*)(wl + k * 1024 + tr_base);
-      const int m = mw0 + k * 8 + row_l;
-      if (m < p.M) *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + gcol) = v;
-    }
-#undef TW_ADDR
-    if constexpr (EPI == EPI_RESID) {
-      const float* red = (const float*)(smem + AUX_OFF);
-      __syncthreads();
-      if (tid < 256 && m0 + tid < p.M) {
-        float s = 0.f, ss = 0.f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float2 t = *(const float2*)(red + ((size_t)c * 256 + tid) * 2);
-          s += t.x; ss += t.y;
-        }
-        *(float2*)(p.stats_out + ((size_t)tn * p.stats_ld + m0 + tid) * 2) = float2{s, ss};
       }
     }
   } else if constexpr (EPI == EPI_THRESH) {
@@ -503,41 +214,19 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
       }
     }
   }
-  STAMP(3);
-  if (p.dbg && tid == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    p.dbg[(size_t)blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
-    p.dbg[(size_t)blockIdx.x * 8 + 5] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32) |
-                                        (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-  }
 }
 
-template <typename T, int IMPL>
-hipError_t launch_t(const GemmParams& p, int epi, hipStream_t stream) {
+template <typename T, int EPI>
+hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
   int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
-  if (epi == EPI_THRESH) { const int nt = p.N / BN; tiles = nt * (nt + 1) / 2; }
-  dim3 grid(tiles), block(512);
-#define CE_LAUNCH(E)                                                                                     \
-  case E: {                                                                                              \
-    static bool attr_set = false;                                                                        \
-    if (!attr_set) {                                                                                     \
-      hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<T, E, IMPL>,                              \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);         \
-      if (e != hipSuccess) return e;                                                                     \
-      attr_set = true;                                                                                   \
-    }                                                                                                    \
-    hipLaunchKernelGGL((gemm_nt_kernel<T, E, IMPL>), grid, block, LDS_BYTES, stream, p);                       \
-    break;                                                                                               \
+  if (EPI == EPI_THRESH) { const int nt = p.N / BN; tiles = nt * (nt + 1) / 2; }
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_set = true;
   }
-  switch (epi) {
-    CE_LAUNCH(EPI_STORE_F32)
-    CE_LAUNCH(EPI_STORE_BF16)
-    CE_LAUNCH(EPI_LNFOLD)
-    CE_LAUNCH(EPI_RESID)
-    CE_LAUNCH(EPI_THRESH)
-    default: return hipErrorInvalidValue;
-  }
-#undef CE_LAUNCH
+  hipLaunchKernelGGL((gemm_nt_kernel<T, EPI>), dim3(tiles), dim3(512), LDS_BYTES, stream, p);
   return hipGetLastError();
 }
 
@@ -551,31 +240,23 @@ hipError_t ce_gemm_nt(const GemmParams& p, int dtype, int epi, hipStream_t strea
   if (epi != EPI_THRESH && !p.out) return hipErrorInvalidValue;
   if ((size_t)255 * p.lda * 2 + 128 >= 0x7fffffffull || (size_t)255 * p.ldw * 2 + 128 >= 0x7fffffffull)
     return hipErrorInvalidValue;
-  if (epi == EPI_LNFOLD && (!p.colsum || !p.bias || !p.stats_in || p.stats_in_parts < 1)) return hipErrorInvalidValue;
-  if (epi == EPI_RESID && (!p.bias || !p.resid || !p.stats_out)) return hipErrorInvalidValue;
-  if (epi == EPI_THRESH && (!p.tri || p.M != p.N || p.A != p.W || !p.pairs || !p.vals || !p.count || p.n_valid > p.M))
+  if (epi == EPI_STORE_BF16 || epi == EPI_LNFOLD || epi == EPI_RESID) {
+    if (dtype != CE_DT_BF16) return hipErrorInvalidValue;
+    if (epi == EPI_LNFOLD && (!p.colsum || !p.bias || !p.stats_in || p.stats_in_parts < 1 || p.stats_in_parts > 4))
+      return hipErrorInvalidValue;
+    if (epi == EPI_RESID && (!p.bias || !p.resid || !p.stats_out)) return hipErrorInvalidValue;
+    if (epi != EPI_STORE_BF16 && (p.stats_ld < p.M || p.stats_ld % 256 != 0)) return hipErrorInvalidValue;
+    return ce_gemm_nt_persist(p, epi, stream);
+  }
+  if (epi == EPI_STORE_F32) {
+    if (dtype == CE_DT_BF16) return launch_t<__bf16, EPI_STORE_F32>(p, stream);
+    if (dtype == CE_DT_F16) return launch_t<_Float16, EPI_STORE_F32>(p, stream);
     return hipErrorInvalidValue;
-  static const int impl = [] { const char* e = getenv("CLIPENC_GEMM_IMPL"); return e ? atoi(e) : 3; }();
-  static const double stagger = [] { const char* e = getenv("CLIPENC_GEMM_STAGGER"); return e ? atof(e) : 1.0; }();
-  static const int order = [] { const char* e = getenv("CLIPENC_TILE_ORDER"); return e ? atoi(e) : 0; }();
-  GemmParams q = p;
-  q.tile_order = order;
-  {
-    const long tiles = (long)((p.M + BM - 1) / BM) * (p.N / BN);
-    // estimated tile time: ~0.8 us per K=32 stage + ~8 us of prologue/epilogue; only worth it with >= 4 tiles per CU
-    q.stagger_ns = (tiles >= 4 * 256 && epi != EPI_THRESH) ? (int)(stagger * (p.K / 32 * 800 + 8000)) : 0;
   }
-  if ((epi == EPI_LNFOLD || epi == EPI_RESID) && (q.stats_ld < p.M || q.stats_ld % 256 != 0)) return hipErrorInvalidValue;
-  if (impl == 3 && dtype == CE_DT_BF16 && (epi == EPI_STORE_BF16 || epi == EPI_LNFOLD || epi == EPI_RESID)) {
-    if (epi == EPI_LNFOLD && p.stats_in_parts > 4) return hipErrorInvalidValue;
-    return ce_gemm_nt_persist(q, epi, stream);
-  }
-  if (impl == 1) {
-    if (dtype == CE_DT_BF16) return launch_t<__bf16, 1>(q, epi, stream);
-    if (dtype == CE_DT_F16) return launch_t<_Float16, 1>(q, epi, stream);
-  } else {
-    if (dtype == CE_DT_BF16) return launch_t<__bf16, 2>(q, epi, stream);
-    if (dtype == CE_DT_F16) return launch_t<_Float16, 2>(q, epi, stream);
+  if (epi == EPI_THRESH) {
+    if (!p.tri || p.M != p.N || p.A != p.W || !p.pairs || !p.vals || !p.count || p.n_valid > p.M) return hipErrorInvalidValue;
+    if (dtype == CE_DT_F16) return launch_t<_Float16, EPI_THRESH>(p, stream);
+    if (dtype == CE_DT_BF16) return launch_t<__bf16, EPI_THRESH>(p, stream);
   }
   return hipErrorInvalidValue;
 }

@@ -34,12 +34,6 @@ __device__ __forceinline__ float act_apply_t(float u) {
   else return u;
 }
 
-__device__ __forceinline__ float act_apply(float u, int act) {
-  // u * sigmoid(1.702 u) = u / (1 + 2^(-1.702*log2(e)*u)): one v_exp_f32 + one v_rcp_f32 (a full fp32 divide costs ~10 more VALU ops)
-  if (act == CE_ACT_QUICK_GELU) return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * u));
-  if (act == CE_ACT_GELU_ERF) return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
-  return u;
-}
 
 // uniform base (SGPR pair) + per-lane 32-bit unsigned offset: selects the saddr form of the DMA, no 64-bit VGPR address
 __device__ __forceinline__ void glds16(const char* base, unsigned off, char* smem, int lds_off) {
@@ -48,12 +42,11 @@ __device__ __forceinline__ void glds16(const char* base, unsigned off, char* sme
 
 struct TileId { int m0, n0, tn; };
 
-__device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n, int order) {
+__device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n) {
   const int nwg = tiles_m * tiles_n;
   const int q = nwg >> 3, r = nwg & 7, xcd = idx & 7, pos = idx >> 3;
-  int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;   // XCD-aware, bijective
-  if (order == 1) bid = idx;
-  const int GM = order == 2 ? 4 : (order == 3 ? 16 : 8);
+  const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;   // XCD-aware, bijective
+  constexpr int GM = 8;
   const int group = bid / (GM * tiles_n);
   const int first_m = group * GM;
   const int gsz = min(tiles_m - first_m, GM);
@@ -62,7 +55,7 @@ __device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n,
   return TileId{tm * BM, tn * BN, tn};
 }
 
-template <int EPI, int VAR>
+template <int EPI, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p) {
   typedef bf16x8_t frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -86,12 +79,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   const int rd = frow * 64 + (((lane >> 4) ^ ((frow >> 3) << 1)) << 4);
   const int a_rd = wr * 8 * 1024 + rd;
   const int w_rd = WPART + wc * 4 * 1024 + rd;
-  // VAR & 16 ("direct" epilogue): W rows are permuted inside each wave's 64-row block (bit fields [5:4] <-> [3:2] of the
-  // row index) so that a lane's 4 n-tiles x 4 registers are 16 CONSECUTIVE output columns: 32 contiguous bytes per lane
-  // and row, stored/loaded with two 16-B accesses and no LDS transposition.
-  constexpr bool DIRECT = (VAR & 16) != 0;
-  const int lrow_w = DIRECT ? ((lrow & ~63) | ((lrow & 0x30) >> 2) | ((lrow & 0x0c) << 2) | (lrow & 3)) : lrow;
-  const unsigned woff0 = (unsigned)(lrow_w * ldw_b) + lchunk16, woff1 = (unsigned)((128 + lrow_w) * ldw_b) + lchunk16;
+  const unsigned woff0 = (unsigned)(lrow * ldw_b) + lchunk16, woff1 = (unsigned)((128 + lrow) * ldw_b) + lchunk16;
 
   // epilogue lane mapping: 16-row x 128-B image per wave, 16-B chunk index XOR row&7
   char* tr = smem + TR_OFF + w * 2048;
@@ -103,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 #define TW_ADDR(nt) (tr + tw_base + ((((nt) * 2 + (qd >> 1)) ^ tw_sw) << 4))
 
   int idx = blockIdx.x;
-  TileId cur = decode_tile(idx, tiles_m, tiles_n, p.tile_order);
+  TileId cur = decode_tile(idx, tiles_m, tiles_n);
   const char* Ablk = (const char*)p.A + (size_t)cur.m0 * lda_b;
   const char* Wblk = (const char*)p.W + (size_t)cur.n0 * ldw_b;
   unsigned aoff0 = (unsigned)((min(cur.m0 + lrow, p.M - 1) - cur.m0) * lda_b) + lchunk16;
@@ -132,44 +120,28 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 #define LD_A(slot, half) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (slot) * STG + a_rd + ((half) * 4 + i) * 1024);
 #define MMA(half)                                                                           \
   do {                                                                                      \
-    if (!(VAR & 1)) __builtin_amdgcn_s_setprio(1);                                          \
+    __builtin_amdgcn_s_setprio(1);                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
       acc[(half) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[(half) * 4 + i][j], 0, 0, 0); \
-    if (!(VAR & 1)) __builtin_amdgcn_s_setprio(0);                                          \
+    __builtin_amdgcn_s_setprio(0);                                                          \
   } while (0)
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
 #define WAIT_LDS()                                                                          \
   do {                                                                                      \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
-    if (!(VAR & 4)) __builtin_amdgcn_sched_barrier(0);                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
   // one K=32 stage = two phases; ISSUE_W / ISSUE_A are the DMA statements of the phases, VM the counted wait
 #define STAGE(slot, ISSUE_W, ISSUE_A, VM)                                                   \
   do {                                                                                      \
-    if constexpr ((VAR & 32) != 0) {                                                        \
-      /* experiment: ONE barrier per stage, no enforced MFMA/load alternation */            \
-      LD_W(slot) LD_A(slot, 0)                                                              \
-      ISSUE_W;                                                                              \
-      WAIT_LDS(); MMA(0);                                                                   \
-      LD_A(slot, 1)                                                                         \
-      ISSUE_A;                                                                              \
-      asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                \
-      WAIT_LDS(); BARRIER(); MMA(1);                                                        \
-    } else {                                                                                \
-      if (VAR & 8) { LD_A(slot, 0) __builtin_amdgcn_sched_barrier(0); LD_W(slot) }          \
-      else { LD_W(slot) __builtin_amdgcn_sched_barrier(0); LD_A(slot, 0) }                  \
-      if (!(VAR & 2)) { ISSUE_W; }                                                          \
-      BARRIER();                                                                            \
-      if (VAR & 2) { ISSUE_W; }                                                             \
-      WAIT_LDS(); MMA(0); BARRIER();                                                        \
-      LD_A(slot, 1)                                                                         \
-      if (!(VAR & 2)) { ISSUE_A; }                                                          \
-      asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                \
-      BARRIER();                                                                            \
-      if (VAR & 2) { ISSUE_A; }                                                             \
-      WAIT_LDS(); MMA(1); BARRIER();                                                        \
-    }                                                                                       \
+    LD_W(slot) __builtin_amdgcn_sched_barrier(0); LD_A(slot, 0)                             \
+    ISSUE_W;                                                                                \
+    BARRIER(); WAIT_LDS(); MMA(0); BARRIER();                                               \
+    LD_A(slot, 1)                                                                           \
+    ISSUE_A;                                                                                \
+    asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                  \
+    BARRIER(); WAIT_LDS(); MMA(1); BARRIER();                                               \
   } while (0)
 
   // ---- cold prologue of the first tile ----
@@ -190,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     frag_t fa[4], fb[4];
 
     if (p.dbg && tid == 0) p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-    if (!(VAR & 32) && wr == 1) BARRIER();   // second wave row runs half a phase behind
+    if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
     for (int kb = 0; kb < kend - 256; kb += 256) {
       STAGE(0, STAGE_W(2, Wblk, kb + 128), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), 6);
@@ -205,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     const char *Anext = Ablk, *Wnext = Wblk;
     unsigned naoff0 = aoff0, naoff1 = aoff1;
     if (has_next) {
-      nxt = decode_tile(nidx, tiles_m, tiles_n, p.tile_order);
+      nxt = decode_tile(nidx, tiles_m, tiles_n);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
       naoff0 = (unsigned)((min(nxt.m0 + lrow, p.M - 1) - nxt.m0) * lda_b) + lchunk16;
@@ -221,8 +193,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       STAGE(2, STAGE_W(0, Wnext, 0), STAGE_A(1, Anext, naoff0, naoff1, 64), 6);
       STAGE(3, STAGE_W(1, Wnext, 64), STAGE_A(2, Anext, naoff0, naoff1, 128), 6);
     }
-    if (!(VAR & 32) && wr == 0) BARRIER();   // re-align the two wave rows for the epilogue
-    if (VAR & 32) BARRIER();
+    if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
     if (p.dbg && tid == 0) p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime();
 
     // ------------------------------- epilogue of tile `cur` -------------------------------
@@ -247,168 +218,90 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       __syncthreads();
     }
 
-    if constexpr (DIRECT) {
-      // ---- direct epilogue: lane (frow, qd) owns columns cb .. cb+15 of rows mw0 + mt*16 + frow ----
-      const int cb = cur.n0 + wc * 64 + qd * 16;
-      f32x4_t cs[4], bs[4];
-      if constexpr (EPI == EPI_LNFOLD) {
+    f32x4_t cs[4], bs[4];
+    if constexpr (EPI == EPI_LNFOLD) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) cs[nt] = *(const f32x4_t*)(p.colsum + cb + nt * 4);
-      }
-      if (EPI != EPI_STORE_BF16 || p.bias) {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(p.bias + cb + nt * 4);
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bs[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      }
-      uint4 rres[8];                                   // residual: 2 x 16 B per 16-row block, four blocks ahead
-#define LOAD_RES_D(k)                                                                         \
-  do {                                                                                        \
-    const int m_ = mw0 + ((k) >> 1) * 16 + frow;                                              \
-    rres[(k) & 7] = uint4{0, 0, 0, 0};                                                        \
-    if (m_ < p.M) rres[(k) & 7] = *(const uint4*)((const bf16_t*)p.resid + (size_t)m_ * p.ldo + cb + ((k) & 1) * 8); \
-  } while (0)
-      if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) LOAD_RES_D(k);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        uint32_t w8[8];
-        if constexpr (EPI == EPI_STORE_BF16) {
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const f32x4_t v = acc[mt][nt] + bs[nt];
-            w8[nt * 2] = pack_bf16x2(v[0], v[1]); w8[nt * 2 + 1] = pack_bf16x2(v[2], v[3]);
-          }
-        } else if constexpr (EPI == EPI_LNFOLD) {
-          const float2 t = *(const float2*)(smem + AUX_OFF + (tile_iter & 1) * 8192 + (wr * 128 + mt * 16 + frow) * 8);
-          const float mean = t.x, rstd = t.y;
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            f32x4_t v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              v[e] = act_apply_t<((VAR >> 8) & 3) - 1>(rstd * (acc[mt][nt][e] - mean * cs[nt][e]) + bs[nt][e]);
-            w8[nt * 2] = pack_bf16x2(v[0], v[1]); w8[nt * 2 + 1] = pack_bf16x2(v[2], v[3]);
-          }
-        } else {
-          const uint4 ra = rres[(mt * 2) & 7], rb = rres[(mt * 2 + 1) & 7];
-          if (mt + 4 < 8) { LOAD_RES_D(mt * 2 + 8); LOAD_RES_D(mt * 2 + 9); }
-          const uint32_t rw[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-          float s = 0.f, ss = 0.f;
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            f32x4_t v = acc[mt][nt] + bs[nt];
-            v[0] += __uint_as_float(rw[nt * 2] << 16); v[1] += __uint_as_float(rw[nt * 2] & 0xffff0000u);
-            v[2] += __uint_as_float(rw[nt * 2 + 1] << 16); v[3] += __uint_as_float(rw[nt * 2 + 1] & 0xffff0000u);
-            const uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
-            w8[nt * 2] = p0; w8[nt * 2 + 1] = p1;
-            const float r0 = __uint_as_float(p0 << 16), r1 = __uint_as_float(p0 & 0xffff0000u);
-            const float r2 = __uint_as_float(p1 << 16), r3 = __uint_as_float(p1 & 0xffff0000u);
-            s += (r0 + r1) + (r2 + r3);
-            ss += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
-          }
-          if (mw0 + mt * 16 + frow >= p.M) { s = 0.f; ss = 0.f; }
-          s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
-          s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-          if (lane < 16)
-            *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane) * 8) = float2{s, ss};
-        }
-        const int m = mw0 + mt * 16 + frow;
-        if (m < p.M) {
-          bf16_t* o = (bf16_t*)p.out + (size_t)m * p.ldo + cb;
-          *(uint4*)o = uint4{w8[0], w8[1], w8[2], w8[3]};
-          *(uint4*)(o + 8) = uint4{w8[4], w8[5], w8[6], w8[7]};
-        }
-      }
-    } else {
-      f32x4_t cs[4], bs[4];
-      if constexpr (EPI == EPI_LNFOLD) {
-  #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) cs[nt] = *(const f32x4_t*)(p.colsum + ncol0 + nt * 16);
-      }
-      if (EPI != EPI_STORE_BF16 || p.bias) {
-  #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(p.bias + ncol0 + nt * 16);
-      } else {
-  #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) bs[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      }
-
-      // residual rows, 8 x 16 B per lane in flight (four 16-row blocks ahead of their use)
-      uint4 rres[8];
-  #define LOAD_RES(k)                                                                           \
-    do {                                                                                        \
-      const int m_ = mw0 + (k) * 8 + row_l;                                                     \
-      rres[(k) & 7] = uint4{0, 0, 0, 0};                                                        \
-      if (m_ < p.M) rres[(k) & 7] = *(const uint4*)((const bf16_t*)p.resid + (size_t)m_ * p.ldo + gcol); \
-    } while (0)
-      if constexpr (EPI == EPI_RESID) {
-  #pragma unroll
-        for (int k = 0; k < 8; ++k) LOAD_RES(k);
-      }
-
-  #pragma unroll
-      for (int mt = 0; mt < 8; ++mt) {
-        uint2 pk[4];
-        if constexpr (EPI == EPI_STORE_BF16) {
-  #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const f32x4_t v = acc[mt][nt] + bs[nt];
-            pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          }
-        } else if constexpr (EPI == EPI_LNFOLD) {
-          const float2 t = *(const float2*)(smem + AUX_OFF + (tile_iter & 1) * 8192 + (wr * 128 + mt * 16 + frow) * 8);
-          const float mean = t.x, rstd = t.y;
-  #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            f32x4_t v;
-  #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              v[e] = act_apply_t<((VAR >> 8) & 3) - 1>(rstd * (acc[mt][nt][e] - mean * cs[nt][e]) + bs[nt][e]);
-            pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          }
-        } else {
-          // residual rows of this 16-row block: row-major image -> fragment layout
-          *(uint4*)(tr + tr_base) = rres[(mt * 2) & 7];
-          *(uint4*)(tr + 1024 + tr_base) = rres[(mt * 2 + 1) & 7];
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // cross-lane hand-off through the image
-          if (mt + 4 < 8) { LOAD_RES(mt * 2 + 8); LOAD_RES(mt * 2 + 9); }
-          float s = 0.f, ss = 0.f;
-  #pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            const uint2 rr = *(const uint2*)TW_ADDR(nt);
-            f32x4_t v = acc[mt][nt] + bs[nt];
-            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-            pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            const float r0 = __uint_as_float(pk[nt].x << 16), r1 = __uint_as_float(pk[nt].x & 0xffff0000u);
-            const float r2 = __uint_as_float(pk[nt].y << 16), r3 = __uint_as_float(pk[nt].y & 0xffff0000u);
-            s += (r0 + r1) + (r2 + r3);
-            ss += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
-          }
-          if (mw0 + mt * 16 + frow >= p.M) { s = 0.f; ss = 0.f; }
-          s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
-          s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-          if (lane < 16)
-            *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane) * 8) = float2{s, ss};
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragment reads done before the image is rewritten
-        }
-        // fragment layout -> row-major image -> two 16-B-per-lane stores of 8 full rows each
-  #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) *(uint2*)TW_ADDR(nt) = pk[nt];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const uint4 v0 = *(const uint4*)(tr + tr_base);
-        const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
-        const int ma = mw0 + mt * 16 + row_l, mb = ma + 8;
-        if (ma < p.M) *(uint4*)((bf16_t*)p.out + (size_t)ma * p.ldo + gcol) = v0;
-        if (mb < p.M) *(uint4*)((bf16_t*)p.out + (size_t)mb * p.ldo + gcol) = v1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // image reads done before the next block's writes
-      }
-
+      for (int nt = 0; nt < 4; ++nt) cs[nt] = *(const f32x4_t*)(p.colsum + ncol0 + nt * 16);
     }
+    if (EPI != EPI_STORE_BF16 || p.bias) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(p.bias + ncol0 + nt * 16);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bs[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // residual rows, 8 x 16 B per lane in flight (four 16-row blocks ahead of their use)
+    uint4 rres[8];
+#define LOAD_RES(k)                                                                           \
+  do {                                                                                        \
+    const int m_ = mw0 + (k) * 8 + row_l;                                                     \
+    rres[(k) & 7] = uint4{0, 0, 0, 0};                                                        \
+    if (m_ < p.M) rres[(k) & 7] = *(const uint4*)((const bf16_t*)p.resid + (size_t)m_ * p.ldo + gcol); \
+  } while (0)
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) LOAD_RES(k);
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      uint2 pk[4];
+      if constexpr (EPI == EPI_STORE_BF16) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const f32x4_t v = acc[mt][nt] + bs[nt];
+          pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+      } else if constexpr (EPI == EPI_LNFOLD) {
+        const float2 t = *(const float2*)(smem + AUX_OFF + (tile_iter & 1) * 8192 + (wr * 128 + mt * 16 + frow) * 8);
+        const float mean = t.x, rstd = t.y;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          f32x4_t v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = act_apply_t<ACT>(rstd * (acc[mt][nt][e] - mean * cs[nt][e]) + bs[nt][e]);
+          pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+      } else {
+        // residual rows of this 16-row block: row-major image -> fragment layout
+        *(uint4*)(tr + tr_base) = rres[(mt * 2) & 7];
+        *(uint4*)(tr + 1024 + tr_base) = rres[(mt * 2 + 1) & 7];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // cross-lane hand-off through the image
+        if (mt + 4 < 8) { LOAD_RES(mt * 2 + 8); LOAD_RES(mt * 2 + 9); }
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const uint2 rr = *(const uint2*)TW_ADDR(nt);
+          f32x4_t v = acc[mt][nt] + bs[nt];
+          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+          pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          const float r0 = __uint_as_float(pk[nt].x << 16), r1 = __uint_as_float(pk[nt].x & 0xffff0000u);
+          const float r2 = __uint_as_float(pk[nt].y << 16), r3 = __uint_as_float(pk[nt].y & 0xffff0000u);
+          s += (r0 + r1) + (r2 + r3);
+          ss += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+        }
+        if (mw0 + mt * 16 + frow >= p.M) { s = 0.f; ss = 0.f; }
+        s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
+        s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+        if (lane < 16)
+          *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane) * 8) = float2{s, ss};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragment reads done before the image is rewritten
+      }
+      // fragment layout -> row-major image -> two 16-B-per-lane stores of 8 full rows each
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) *(uint2*)TW_ADDR(nt) = pk[nt];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const uint4 v0 = *(const uint4*)(tr + tr_base);
+      const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
+      const int ma = mw0 + mt * 16 + row_l, mb = ma + 8;
+      if (ma < p.M) *(uint4*)((bf16_t*)p.out + (size_t)ma * p.ldo + gcol) = v0;
+      if (mb < p.M) *(uint4*)((bf16_t*)p.out + (size_t)mb * p.ldo + gcol) = v1;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // image reads done before the next block's writes
+    }
+
     if constexpr (EPI == EPI_RESID) {
       __syncthreads();
       if (tid < 256 && cur.m0 + tid < p.M) {
@@ -433,12 +326,12 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   }
 }
 
-template <int EPI, int VAR>
+template <int EPI, int ACT>
 hipError_t launch_persist(const GemmParams& p, hipStream_t stream) {
   static int n_cu = 0;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return e;
     int dev = 0;
     e = hipGetDevice(&dev);
@@ -454,46 +347,20 @@ hipError_t launch_persist(const GemmParams& p, hipStream_t stream) {
   grid -= grid % 8;                           // keep tile index mod 8 == workgroup index mod 8 (XCD affinity)
   if (grid < 8) grid = 8;
   if (tiles < grid) grid = tiles;
-  hipLaunchKernelGGL((gemm_persist_kernel<EPI, VAR>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_persist_kernel<EPI, ACT>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
   return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream) {
-  static const int var = [] { const char* e = getenv("CLIPENC_GEMM_VARIANT"); return e ? atoi(e) : 0; }();
-  if (epi == EPI_STORE_BF16 && var != 0) {
-    switch (var) {                            // schedule experiments (tools/gemm_sweep.py); 0 is the shipped one
-      case 1: return launch_persist<EPI_STORE_BF16, 1>(p, stream);
-      case 2: return launch_persist<EPI_STORE_BF16, 2>(p, stream);
-      case 4: return launch_persist<EPI_STORE_BF16, 4>(p, stream);
-      case 8: return launch_persist<EPI_STORE_BF16, 8>(p, stream);
-      case 32: return launch_persist<EPI_STORE_BF16, 32>(p, stream);
-      default: return launch_persist<EPI_STORE_BF16, 0>(p, stream);
-    }
-  }
-  // CLIPENC_GEMM_EPI=1 selects the "direct" epilogue (W rows permuted so a lane owns 16 consecutive columns, two 16-B
-  // stores per 16-row block, no LDS): measured equal-to-slightly-slower than the LDS-transposed whole-row stores
-  // (half-line writes cost what the LDS round trip saves), kept as an experiment switch.
-  static const int direct = [] { const char* e = getenv("CLIPENC_GEMM_EPI"); return e ? atoi(e) : 0; }();
-  if (direct) {
-    switch (epi) {
-      case EPI_STORE_BF16: return launch_persist<EPI_STORE_BF16, 16>(p, stream);
-      case EPI_LNFOLD:
-        if (p.act == CE_ACT_QUICK_GELU) return launch_persist<EPI_LNFOLD, 16 | ((CE_ACT_QUICK_GELU + 1) << 8)>(p, stream);
-        if (p.act == CE_ACT_GELU_ERF) return launch_persist<EPI_LNFOLD, 16 | ((CE_ACT_GELU_ERF + 1) << 8)>(p, stream);
-        return launch_persist<EPI_LNFOLD, 16>(p, stream);
-      case EPI_RESID: return launch_persist<EPI_RESID, 16>(p, stream);
-      default: return hipErrorInvalidValue;
-    }
-  }
   switch (epi) {
-    case EPI_STORE_BF16: return launch_persist<EPI_STORE_BF16, 0>(p, stream);
-    case EPI_LNFOLD:
-      if (p.act == CE_ACT_QUICK_GELU) return launch_persist<EPI_LNFOLD, (CE_ACT_QUICK_GELU + 1) << 8>(p, stream);
-      if (p.act == CE_ACT_GELU_ERF) return launch_persist<EPI_LNFOLD, (CE_ACT_GELU_ERF + 1) << 8>(p, stream);
-      return launch_persist<EPI_LNFOLD, 0>(p, stream);
-    case EPI_RESID: return launch_persist<EPI_RESID, 0>(p, stream);
+    case EPI_STORE_BF16: return launch_persist<EPI_STORE_BF16, -1>(p, stream);
+    case EPI_LNFOLD:     // the activation is a template parameter: a run-time switch made hipcc evaluate both GELUs per element
+      if (p.act == CE_ACT_QUICK_GELU) return launch_persist<EPI_LNFOLD, CE_ACT_QUICK_GELU>(p, stream);
+      if (p.act == CE_ACT_GELU_ERF) return launch_persist<EPI_LNFOLD, CE_ACT_GELU_ERF>(p, stream);
+      return launch_persist<EPI_LNFOLD, -1>(p, stream);
+    case EPI_RESID: return launch_persist<EPI_RESID, -1>(p, stream);
     default: return hipErrorInvalidValue;
   }
 }
