@@ -110,11 +110,18 @@ def main():
     from clip_assisted_data_labeling_amd.embedder import HipViT
     from clip_assisted_data_labeling_amd.nn_model import HipRegressor
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_DEVICE / BENCH_BACKEND exist only to exercise the N > 1 control flow on a 1-GPU box (all ranks on one
+    # device, gloo with host staging); the real multi-GPU run uses one GPU per rank and RCCL.
+    dev_index = int(os.environ.get("BENCH_DEVICE", local_rank))
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = vit_config.ARCHS[MODEL]
     sd = vit_config.seeded_state_dict(cfg, 0)               # random-init weights of the named architecture
@@ -124,15 +131,16 @@ def main():
     n_img = args.images
     crops = synthetic_crops(n_img * CROPS_PER_IMAGE, cfg.image_size, 1234 + rank, dev)   # resident in HBM
     sel = list(range(CROPS_PER_IMAGE))
+    gdev = dev if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        emb_all = torch.empty((world * n_img, CROPS_PER_IMAGE, cfg.embed_dim), device=dev)
-        score_all = torch.empty((world * n_img, 1), device=dev)
+        emb_all = torch.empty((world * n_img, CROPS_PER_IMAGE, cfg.embed_dim), device=gdev)
+        score_all = torch.empty((world * n_img, 1), device=gdev)
 
     def step():
         emb, score = vit.encode_score(crops, reg, CROPS_PER_IMAGE, sel)
         if world > 1:                                       # the one exchange of the path: gather results
-            dist.all_gather_into_tensor(emb_all, emb)
-            dist.all_gather_into_tensor(score_all, score)
+            dist.all_gather_into_tensor(emb_all, emb.to(gdev))
+            dist.all_gather_into_tensor(score_all, score.to(gdev))
         return emb, score
 
     for _ in range(args.warmup):
@@ -152,7 +160,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=gdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     prof = vit.profile_read()

@@ -204,6 +204,35 @@ def test_encoder_577_tokens_like_vit_l_14_336(gpu):
     vit.close()
 
 
+def test_encoder_with_outlier_channels_like_real_clip(gpu):
+    """Real CLIP towers carry a few residual-stream channels that are 50-100x larger than the rest and rows whose
+    mean is far from zero (SURVEY.md §7 'precision budget'); seeded-random weights do not.  Plant both and check that
+    the LayerNorm-folded GEMMs (mean subtraction AFTER the bf16 matmul) and the bf16 residual stream still meet the
+    embedding tolerance."""
+    cfg = vit_config.ARCHS["ViT-small-test"]
+    sd = vit_config.seeded_state_dict(cfg, 8)
+    g = torch.Generator().manual_seed(0)
+    hot = torch.randperm(cfg.width, generator=g)[:3]
+    sd["ln_pre.weight"][hot] *= 60.0                      # outlier channels enter the residual stream right away
+    sd["ln_pre.bias"] += 1.5                              # every row gets a mean of ~1.5 sigma
+    sd["ln_pre.bias"][hot] += 40.0
+    for l in range(cfg.layers):
+        sd[f"transformer.resblocks.{l}.attn.out_proj.bias"][hot[0]] += 25.0
+        sd[f"transformer.resblocks.{l}.mlp.c_proj.bias"][hot[1]] -= 25.0
+    crops = synthetic_crops(6, cfg.image_size, 31)
+    taps = {}
+    ref = vit_oracle.encode_image(sd, cfg, crops, taps)
+    x_last = taps[f"block{cfg.layers - 1}"]
+    assert x_last.abs().max() > 30 * x_last.abs().median()            # the planted outliers survive to the last block
+    assert (x_last.mean(-1).abs() / x_last.std(-1)).mean() > 0.05      # and rows are not zero-mean
+    vit = HipViT(cfg, sd, gpu)
+    emb = vit.encode(crops.to(gpu)).cpu()
+    assert one_minus_cos(emb, ref).max().item() < COS_TOL
+    xl = vit.debug_run_layers(crops.to(gpu), cfg.layers).float().cpu()
+    assert one_minus_cos(xl.flatten(1), x_last.flatten(1)).max().item() < 5e-4
+    vit.close()
+
+
 def test_encoder_batch_chunk_and_dtype_invariance(gpu):
     cfg = vit_config.ARCHS["ViT-small-test"]
     sd = vit_config.seeded_state_dict(cfg, 4)
