@@ -121,6 +121,8 @@ struct clipenc_s {
   clipenc_config cfg;
   int device = 0;
   int tokens = 0, kpad = 0;
+  float pix_mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};      // OpenAI CLIP constants (utils/embedder.py:121-124)
+  float pix_std[3] = {0.26862954f, 0.26130258f, 0.27577711f};
   DevBuf weights;                                        // one slab
   bf16_t* w_conv = nullptr;                              // [width][kpad]
   float *cls = nullptr, *pos = nullptr, *ln_pre_w = nullptr, *ln_pre_b = nullptr;
@@ -178,7 +180,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
   Profiler& pf = e->prof;
   const double dT = (double)T, dD = (double)g.width;
   pf.begin(PK_PATCHIFY, 0.0, st);
-  HIP_TRY(ce_patchify(crops, in_dtype, e->a_patch, c, g.image_size, g.patch, e->kpad, st));
+  HIP_TRY(ce_patchify(crops, in_dtype, e->a_patch, c, g.image_size, g.patch, e->kpad, e->pix_mean, e->pix_std, st));
   pf.end(st);
   GemmParams p{};
   p.A = e->a_patch; p.lda = e->kpad; p.W = e->w_conv; p.ldw = e->kpad; p.M = P; p.N = g.width; p.K = e->kpad;
@@ -234,7 +236,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
 }
 
 size_t crop_bytes(const clipenc_config& g, int in_dtype) {
-  return (size_t)3 * g.image_size * g.image_size * (in_dtype == CLIPENC_IN_F32 ? 4 : 2);
+  return (size_t)3 * g.image_size * g.image_size * (in_dtype == CLIPENC_IN_F32 ? 4 : (in_dtype == CLIPENC_IN_F16 ? 2 : 1));
 }
 
 }  // namespace
@@ -361,6 +363,15 @@ int clipenc_destroy(clipenc_t e) {
   return 0;
 }
 
+int clipenc_set_pixel_norm(clipenc_t e, const float* mean3, const float* std3) {
+  if (!e || !mean3 || !std3) return fail("NULL argument");
+  for (int i = 0; i < 3; ++i) {
+    if (!(std3[i] > 0.f)) return fail("std[%d] = %g must be positive", i, std3[i]);
+    e->pix_mean[i] = mean3[i]; e->pix_std[i] = std3[i];
+  }
+  return 0;
+}
+
 int clipenc_set_chunk(clipenc_t e, int chunk_crops) {
   if (!e) return fail("NULL handle");
   if (chunk_crops < 1) return fail("chunk_crops %d < 1", chunk_crops);
@@ -383,8 +394,8 @@ int clipenc_encode(clipenc_t e, const void* crops_dev, int n_crops, int in_dtype
   if (n_crops < 0) return fail("n_crops %d < 0", n_crops);
   if (n_crops == 0) return 0;
   if (!crops_dev || !emb_dev) return fail("NULL device pointer");
-  if (in_dtype != CLIPENC_IN_F32 && in_dtype != CLIPENC_IN_F16) return fail("unknown in_dtype %d", in_dtype);
-  if (((uintptr_t)crops_dev & 3) || ((uintptr_t)emb_dev & 3)) return fail("misaligned device pointer");
+  if (in_dtype != CLIPENC_IN_F32 && in_dtype != CLIPENC_IN_F16 && in_dtype != CLIPENC_IN_U8) return fail("unknown in_dtype %d", in_dtype);
+  if ((in_dtype != CLIPENC_IN_U8 && ((uintptr_t)crops_dev & 1)) || ((uintptr_t)emb_dev & 3)) return fail("misaligned device pointer");
   HIP_TRY(hipSetDevice(e->device));
   if (int rc = ensure_workspace(e, n_crops)) return rc;
   hipStream_t st = (hipStream_t)stream;

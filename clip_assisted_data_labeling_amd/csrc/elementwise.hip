@@ -10,9 +10,21 @@ namespace {
 // zero-padded to kpad (the conv-as-GEMM operand; conv1 has stride = patch and no bias).
 // One block per (crop, gy): the 3*p input rows it touches are read in contiguous runs of p floats.
 // ---------------------------------------------------------------------------------------------
+// uint8 input (CLIPENC_IN_U8): the ToTensor + Normalize tail of the validation transform
+// (/root/reference/utils/embedder.py:90-92) is applied here, v = (u / 255 - mean_c) / std_c in fp32 with the same
+// operation order as torchvision, so the host only ships 1 byte per pixel.
+struct PixelNorm { float mean[3], std[3]; };
+
+template <typename TIN>
+__device__ __forceinline__ float load_pixel(const TIN* p, int c, const PixelNorm& nm) { return (float)*p; }
+template <>
+__device__ __forceinline__ float load_pixel<uint8_t>(const uint8_t* p, int c, const PixelNorm& nm) {
+  return ((float)*p / 255.0f - nm.mean[c]) / nm.std[c];
+}
+
 template <typename TIN>
 __global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ in, bf16_t* __restrict__ out,
-                                                       int image, int patch, int kpad) {
+                                                       int image, int patch, int kpad, PixelNorm nm) {
   const int g = image / patch;
   const int crop = blockIdx.x / g, gy = blockIdx.x % g;
   const int k_real = 3 * patch * patch;
@@ -25,7 +37,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ i
     if (k < k_real) {
       const int c = k / (patch * patch), rem = k - c * patch * patch;
       const int ky = rem / patch, kx = rem - ky * patch;
-      v = (float)src[((size_t)c * image + gy * patch + ky) * image + gx * patch + kx];
+      v = load_pixel<TIN>(src + ((size_t)c * image + gy * patch + ky) * image + gx * patch + kx, c, nm);
     }
     dst[idx] = f32_to_bf16(v);
   }
@@ -194,14 +206,17 @@ __global__ __launch_bounds__(256) void head_kernel(const bf16_t* __restrict__ x,
 }  // namespace
 
 hipError_t ce_patchify(const void* crops, int in_dtype, void* a_patch, int n_crops, int image, int patch, int kpad,
-                       hipStream_t stream) {
+                       const float* mean3, const float* std3, hipStream_t stream) {
   if (image % patch != 0 || kpad < 3 * patch * patch || n_crops < 1) return hipErrorInvalidValue;
   const int g = image / patch;
   dim3 grid(n_crops * g), block(256);
+  PixelNorm nm{{mean3[0], mean3[1], mean3[2]}, {std3[0], std3[1], std3[2]}};
   if (in_dtype == 0)
-    hipLaunchKernelGGL(patchify_kernel<float>, grid, block, 0, stream, (const float*)crops, (bf16_t*)a_patch, image, patch, kpad);
+    hipLaunchKernelGGL(patchify_kernel<float>, grid, block, 0, stream, (const float*)crops, (bf16_t*)a_patch, image, patch, kpad, nm);
   else if (in_dtype == 1)
-    hipLaunchKernelGGL(patchify_kernel<_Float16>, grid, block, 0, stream, (const _Float16*)crops, (bf16_t*)a_patch, image, patch, kpad);
+    hipLaunchKernelGGL(patchify_kernel<_Float16>, grid, block, 0, stream, (const _Float16*)crops, (bf16_t*)a_patch, image, patch, kpad, nm);
+  else if (in_dtype == 2)
+    hipLaunchKernelGGL(patchify_kernel<uint8_t>, grid, block, 0, stream, (const uint8_t*)crops, (bf16_t*)a_patch, image, patch, kpad, nm);
   else
     return hipErrorInvalidValue;
   return hipGetLastError();

@@ -8,7 +8,7 @@ hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int 
 
 // elementwise.hip
 hipError_t ce_patchify(const void* crops, int in_dtype, void* a_patch, int n_crops, int image, int patch, int kpad,
-                       hipStream_t stream);
+                       const float* mean3, const float* std3, hipStream_t stream);
 hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float* pos, const float* gamma,
                            const float* beta, void* x, float* stats, int n_crops, int n_tok, int width, float eps,
                            hipStream_t stream);

@@ -105,6 +105,10 @@ class Feature_Dataset:
         else:
             raise ValueError(f"Unknown model format: {model_name}. Expected 'Arch/Dataset'.")     # :75
         self.preprocess = self.encoder.get_preprocess_transform()
+        # the HIP encoder takes raw uint8 crops (ToTensor + Normalize fused into its first kernel): 1 byte per pixel
+        # crosses the DataLoader pipes and PCIe instead of 4
+        if getattr(self.encoder, "accepts_uint8", False) and hasattr(self.preprocess, "to_uint8"):
+            self.preprocess = self.preprocess.to_uint8
         self.num_workers = num_workers
 
     def __len__(self):

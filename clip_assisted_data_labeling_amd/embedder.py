@@ -94,6 +94,8 @@ class HipViT:
             dt = 0
         elif crops.dtype == torch.float16:
             dt = 1
+        elif crops.dtype == torch.uint8:          # raw pixels: ToTensor + Normalize happen in the patchify kernel
+            dt = 2
         else:
             crops, dt = crops.float(), 0
         return crops.contiguous(), dt
@@ -161,6 +163,8 @@ class HipViT:
 
 class CLIP_Encoder:
     """Same surface as /root/reference/utils/embedder.py:58-100."""
+
+    accepts_uint8 = True      # encode_image also takes uint8 [n,3,R,R] (output of get_preprocess_transform().to_uint8)
 
     def __init__(self, model_name, model_path=None, device=None):
         self.device = device if device else _DEVICE

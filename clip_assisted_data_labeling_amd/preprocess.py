@@ -80,7 +80,12 @@ class ClipValTransform:
         self.mean = torch.tensor(mean, dtype=torch.float32).view(3, 1, 1)
         self.std = torch.tensor(std, dtype=torch.float32).view(3, 1, 1)
 
-    def __call__(self, img: Image.Image) -> torch.Tensor:
+    def to_uint8(self, img: Image.Image) -> torch.Tensor:
+        """Resize + CenterCrop + RGB only: uint8 [3,R,R]; ToTensor + Normalize are left to the device
+        (CLIPENC_IN_U8), which computes the identical fp32 expression."""
+        return torch.from_numpy(np.asarray(self._resize_crop(img), dtype=np.uint8).copy()).permute(2, 0, 1).contiguous()
+
+    def _resize_crop(self, img: Image.Image) -> Image.Image:
         w, h = img.size
         R = self.size
         if w <= h:
@@ -90,8 +95,10 @@ class ClipValTransform:
         if (nw, nh) != (w, h):
             img = img.resize((nw, nh), Image.BICUBIC)
         img = img.crop(_center_crop_box(nw, nh, R, R))
-        img = img.convert("RGB")
-        arr = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
+        return img.convert("RGB")
+
+    def __call__(self, img: Image.Image) -> torch.Tensor:
+        arr = torch.from_numpy(np.asarray(self._resize_crop(img), dtype=np.uint8).copy()).permute(2, 0, 1).float().div_(255.0)
         return (arr - self.mean) / self.std
 
     def __repr__(self):

@@ -28,6 +28,7 @@ typedef struct fcreg_s* fcreg_t;       /* SimpleFC regressor weights on one devi
 
 #define CLIPENC_IN_F32 0               /* crops as float32 NCHW (what _1_embed_with_CLIP.py:114-115 hands over) */
 #define CLIPENC_IN_F16 1               /* crops as float16 NCHW (the reference's cuda path, utils/embedder.py:96-97) */
+#define CLIPENC_IN_U8 2                /* raw uint8 NCHW pixels after Resize+CenterCrop: ToTensor + Normalize run on the device */
 
 typedef struct clipenc_config {
   int image_size, patch, width, layers, heads, mlp_dim, embed_dim;
@@ -59,6 +60,9 @@ int clipenc_device_count(int* count);
  * (/root/reference/utils/embedder.py:66-74: open_clip.create_model_and_transforms + .to(device).eval()). */
 int clipenc_create(const clipenc_config* cfg, const clipenc_weights* weights, int device, clipenc_t* out);
 int clipenc_destroy(clipenc_t enc);
+
+/* Mean / std of the Normalize step applied to CLIPENC_IN_U8 input (defaults: the OpenAI CLIP constants). */
+int clipenc_set_pixel_norm(clipenc_t enc, const float* mean3, const float* std3);
 
 /* Crops pushed through the 24-layer chain per pass (workspace is sized for it; default 2048). */
 int clipenc_set_chunk(clipenc_t enc, int chunk_crops);

@@ -255,6 +255,23 @@ def test_encoder_batch_chunk_and_dtype_invariance(gpu):
     vit.close()
 
 
+def test_encoder_uint8_input_matches_normalised_float_input(gpu):
+    """CLIPENC_IN_U8: ToTensor + Normalize fused into the patchify kernel give the same patch operand as the
+    host transform (same fp32 expression), so the embeddings are bitwise identical."""
+    from PIL import Image
+    from clip_assisted_data_labeling_amd.preprocess import ClipValTransform
+    cfg = vit_config.ARCHS["ViT-small-test"]
+    vit = HipViT(cfg, vit_config.seeded_state_dict(cfg, 4), gpu)
+    rs = np.random.RandomState(5)
+    tf = ClipValTransform(cfg.image_size)
+    imgs = [Image.fromarray(rs.randint(0, 256, (rs.randint(100, 300), rs.randint(100, 300), 3), dtype=np.uint8)) for _ in range(5)]
+    f32 = torch.stack([tf(im) for im in imgs])
+    u8 = torch.stack([tf.to_uint8(im) for im in imgs])
+    assert u8.dtype == torch.uint8 and u8.shape == (5, 3, cfg.image_size, cfg.image_size)
+    assert torch.equal(vit.encode(u8.to(gpu)), vit.encode(f32.to(gpu)))
+    vit.close()
+
+
 def test_clip_encoder_surface_and_4crop_row_order(gpu):
     enc = CLIP_Encoder("ViT-small-test/seed4", None, device="cuda")    # positional like _1_embed_with_CLIP.py:73
     assert enc.img_resolution == 98 and enc.model_name == "ViT-small-test/seed4" and enc.device == "cuda"
