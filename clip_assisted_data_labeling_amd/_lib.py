@@ -56,6 +56,10 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p]),
     "dedup_find_pairs": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                  c_ulonglong, c_void_p, c_void_p]),
+    "preproc_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "preproc_destroy": (c_int, [c_void_p]),
+    "preproc_crops_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), c_int, c_void_p, c_void_p]),
+    "preproc_axis_tables": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), c_int, POINTER(c_int)]),
     "clipenc_profile_enable": (c_int, [c_void_p, c_int]),
     "clipenc_profile_kinds": (c_int, []),
     "clipenc_profile_read": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(ctypes.c_double), POINTER(c_longlong),

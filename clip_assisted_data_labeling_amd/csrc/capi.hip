@@ -135,6 +135,11 @@ struct clipenc_s {
   float *stats0 = nullptr, *stats_a = nullptr, *stats_b = nullptr;
 };
 
+struct preproc_s {
+  int device = 0;
+  PreprocState* st = nullptr;
+};
+
 struct fcreg_s {
   int device = 0;
   int n_layers = 0;
@@ -561,6 +566,48 @@ int clipenc_op_gemm_nt(const void* a_dev, const void* w_dev, int m, int n, int k
   p.A = a_dev; p.lda = k; p.W = w_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out_dev; p.ldo = n; p.bias = bias_dev;
   hipError_t err = ce_gemm_nt(p, dtype, epi, (hipStream_t)stream);
   if (err != hipSuccess) return fail("gemm_nt(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
+  return 0;
+}
+
+int preproc_create(int device, preproc_t* out) {
+  if (!out) return fail("preproc_create: NULL argument");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail("device %d out of range (%d visible)", device, ndev);
+  preproc_s* p = new preproc_s();
+  p->device = device;
+  p->st = ce_preproc_create();
+  *out = p;
+  return 0;
+}
+
+int preproc_destroy(preproc_t p) {
+  if (!p) return 0;
+  (void)hipSetDevice(p->device);
+  ce_preproc_destroy(p->st);
+  delete p;
+  return 0;
+}
+
+int preproc_crops_u8(preproc_t p, const uint8_t* image_dev, int height, int width, int pitch_bytes, int n_crops,
+                     const int* boxes, int out_size, uint8_t* out_dev, void* stream) {
+  if (!p) return fail("NULL handle");
+  HIP_TRY(hipSetDevice(p->device));
+  hipError_t err = ce_preproc_crops_u8(p->st, image_dev, height, width, pitch_bytes, n_crops, boxes, out_size, out_dev,
+                                       (hipStream_t)stream);
+  if (err != hipSuccess) return fail("preproc_crops_u8(%dx%d, %d crops -> %d) failed: %s", width, height, n_crops, out_size,
+                                     hipGetErrorString(err));
+  return 0;
+}
+
+int preproc_axis_tables(int in_size, int out_size, int out0, int n_out, int* bounds, int* kk, int kk_capacity, int* ksize) {
+  if (in_size < 1 || out_size < 1 || out0 < 0 || n_out < 1 || out0 + n_out > out_size || !bounds || !kk || !ksize)
+    return fail("preproc_axis_tables: bad argument");
+  std::vector<int> b, k;
+  *ksize = ce_preproc_axis_tables(in_size, out_size, out0, n_out, b, k);
+  if ((long)k.size() > kk_capacity) return fail("kk_capacity %d < %ld", kk_capacity, (long)k.size());
+  memcpy(bounds, b.data(), b.size() * sizeof(int));
+  memcpy(kk, k.data(), k.size() * sizeof(int));
   return 0;
 }
 

@@ -31,6 +31,15 @@ struct FcRegParams {
 };
 hipError_t ce_fcreg_forward(const FcRegParams& p, hipStream_t stream);
 
+// preproc.hip
+#include <vector>
+struct PreprocState;
+PreprocState* ce_preproc_create();
+void ce_preproc_destroy(PreprocState* s);
+int ce_preproc_axis_tables(int in_size, int out_size, int out0, int n_out, std::vector<int>& bounds, std::vector<int>& kk);
+hipError_t ce_preproc_crops_u8(PreprocState* s, const uint8_t* img, int H, int W, int pitch, int n_crops, const int* boxes,
+                               int R, uint8_t* out, hipStream_t stream);
+
 // dedup.hip
 hipError_t ce_dedup_normalize_f16(const void* emb_f16, void* out_f16, int n, int d, int ld_out, hipStream_t stream);
 hipError_t ce_dedup_pairs(const void* ehat_f16, int n, int d, int ld, float threshold, int fp16_compare,

@@ -52,6 +52,26 @@ class CustomImageDataset(Dataset):
             return torch.zeros(0), "", img_path, False
 
 
+class RawImageDataset(Dataset):
+    """Workers only decode: path -> uint8 [H, W, 3]; crops, resize and normalise run on the GPU (GpuCropper)."""
+
+    def __init__(self, image_paths: Sequence[str]):
+        self.image_paths = list(image_paths)
+
+    def __len__(self):
+        return len(self.image_paths)
+
+    def __getitem__(self, idx):
+        img_path = self.image_paths[idx]
+        try:
+            import numpy as np
+            arr = np.asarray(Image.open(img_path).convert("RGB"), dtype=np.uint8)
+            return torch.from_numpy(arr.copy()), "", img_path, True
+        except Exception as e:
+            print(f"Error loading or processing image {img_path}: {e}")
+            return torch.zeros(0), "", img_path, False
+
+
 def _collate(batch):
     ok = [b for b in batch if b[3]]
     bad = [b[2] for b in batch if not b[3]]
@@ -79,7 +99,8 @@ def already_embedded(feature_path: str, model_name: str) -> bool:
 
 class Feature_Dataset:
     def __init__(self, root_dir, model_name, batch_size, model_path=None, force_reencode=False,
-                 shuffle_filenames=True, num_workers=0, crop_names=None, encoder=None, device="cuda"):
+                 shuffle_filenames=True, num_workers=0, crop_names=None, encoder=None, device="cuda",
+                 gpu_preprocess=False):
         self.device = device
         self.root_dir = root_dir
         self.model_name = model_name
@@ -110,6 +131,10 @@ class Feature_Dataset:
         if getattr(self.encoder, "accepts_uint8", False) and hasattr(self.preprocess, "to_uint8"):
             self.preprocess = self.preprocess.to_uint8
         self.num_workers = num_workers
+        self.cropper = None
+        if gpu_preprocess:                                 # crop geometry + bicubic resize on the GPU (bit-exact with Pillow)
+            from .preprocess import GpuCropper
+            self.cropper = GpuCropper(self.encoder.img_resolution, self.device, self.crop_names)
 
     def __len__(self):
         return len(self.img_filepaths)
@@ -128,11 +153,15 @@ class Feature_Dataset:
         kwargs = dict(batch_size=self.batch_size, shuffle=False, num_workers=self.num_workers, collate_fn=_collate)
         if self.num_workers > 0:
             kwargs["prefetch_factor"] = 2
-        loader = DataLoader(CustomImageDataset(todo, self.crop_names, self.preprocess), **kwargs)
+        dataset = RawImageDataset(todo) if self.cropper else CustomImageDataset(todo, self.crop_names, self.preprocess)
+        loader = DataLoader(dataset, **kwargs)
         for ok, bad in loader:
             n_failed += len(bad)
             if not ok:
                 continue
+            if self.cropper:
+                made = [self.cropper(b[0]) for b in ok]
+                ok = [(crops, ",".join(names), b[2], True) for (crops, names), b in zip(made, ok)]
             counts = [b[0].shape[0] for b in ok]
             stacked = torch.cat([b[0] for b in ok], 0).to(self.device)      # [sum crops, 3, R, R], row = image-major
             features = self.encoder.encode_image(stacked).float().cpu()    # :130
@@ -170,6 +199,8 @@ def main(argv=None):
     parser.add_argument("--num_workers", type=int, default=4, help="Number of workers for the dataloader")
     parser.add_argument("--force_reencode", action="store_true", help="Force re-encoding of all images for the specified models")
     parser.add_argument("--model_path", type=str, default=None, help="Local directory (or file) holding the model weights")
+    parser.add_argument("--gpu_preprocess", action="store_true",
+                        help="Workers only decode; crops, bicubic resize and normalise run on the GPU (bit-exact with Pillow)")
     args = parser.parse_args(argv)
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
@@ -180,7 +211,7 @@ def main(argv=None):
         print(f"\n--- Processing model: {model_name} ---")
         Feature_Dataset(args.root_dir, model_name, args.batch_size, model_path=args.model_path,
                         force_reencode=args.force_reencode, num_workers=args.num_workers, crop_names=CROP_NAMES,
-                        device=device).process()
+                        device=device, gpu_preprocess=args.gpu_preprocess).process()
 
 
 if __name__ == "__main__":

@@ -107,3 +107,57 @@ class ClipValTransform:
 
 def clip_val_transform(size: int) -> ClipValTransform:
     return ClipValTransform(size)
+
+
+def crop_box_table(width: int, height: int, crop_names: Sequence[str] = CROP_NAMES):
+    """`crop_boxes` in the int[n][5] form the C ABI takes (preproc_crops_u8): kind 0 = crop box, kind 1 = square pad."""
+    rows, names = [], []
+    for name, kind, box in crop_boxes(width, height, crop_names):
+        rows.append([0, *box] if kind == "crop" else [1, box[0], box[1], box[2], 0])
+        names.append(name)
+    return rows, names
+
+
+class GpuCropper:
+    """Device-side counterpart of `extract_crops` + `ClipValTransform.to_uint8`: decoded uint8 HWC image in HBM ->
+    uint8 [n_crops, 3, R, R], bit-exact with the Pillow path (libclipenc_hip.so: preproc_crops_u8)."""
+
+    def __init__(self, size: int, device="cuda", crop_names: Sequence[str] = CROP_NAMES):
+        import ctypes
+        from . import _lib
+        self._lib_mod, self._ct = _lib, ctypes
+        self.lib = _lib.load()
+        self.size = size
+        self.crop_names = list(crop_names)
+        d = torch.device(device)
+        self.device = torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.preproc_create(self.device.index, ctypes.byref(h)), "preproc_create")
+        self.handle = h
+
+    @torch.no_grad()
+    def __call__(self, img_u8_hwc: torch.Tensor):
+        """img: uint8 [H, W, 3] (any device) -> (uint8 [n_crops, 3, R, R] on the GPU, crop names)."""
+        if img_u8_hwc.dtype != torch.uint8 or img_u8_hwc.dim() != 3 or img_u8_hwc.shape[2] != 3:
+            raise ValueError(f"expected a uint8 [H, W, 3] image, got {tuple(img_u8_hwc.shape)} {img_u8_hwc.dtype}")
+        img = img_u8_hwc.to(self.device).contiguous()
+        H, W = int(img.shape[0]), int(img.shape[1])
+        rows, names = crop_box_table(W, H, self.crop_names)
+        flat = [v for r in rows for v in r]
+        boxes = (self._ct.c_int * len(flat))(*flat)
+        out = torch.empty((len(rows), 3, self.size, self.size), dtype=torch.uint8, device=self.device)
+        self._lib_mod.check(self.lib.preproc_crops_u8(self.handle, img.data_ptr(), H, W, W * 3, len(rows), boxes, self.size,
+                                                      out.data_ptr(), self._lib_mod.current_stream_ptr(self.device)),
+                            "preproc_crops_u8")
+        return out, names
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.preproc_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -22,6 +22,7 @@ extern "C" {
 
 typedef struct clipenc_s* clipenc_t;   /* ViT image tower: weights + workspace on one device */
 typedef struct fcreg_s* fcreg_t;       /* SimpleFC regressor weights on one device */
+typedef struct preproc_s* preproc_t;   /* scratch of the crop / resize front end on one device */
 
 #define CLIPENC_ACT_QUICK_GELU 0       /* "<arch>/openai" checkpoints */
 #define CLIPENC_ACT_GELU_ERF 1
@@ -108,6 +109,23 @@ int clipenc_encode_score(clipenc_t enc, fcreg_t reg, const void* crops_dev, int 
 int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int fp16_compare,
                      void* ehat_ws_dev, long long* pairs_dev, float* vals_dev, unsigned long long capacity,
                      unsigned long long* count_dev, void* stream);
+
+/* GPU front end.  Replaces, for a decoded image that is already in HBM, the crop
+ * extraction and the Resize + CenterCrop of the validation transform that the reference runs in its DataLoader
+ * workers (/root/reference/utils/embedder.py:184-251 and :90-92; Pillow's bicubic resampler underneath):
+ *   image_dev  uint8 RGB, HWC, `pitch_bytes` per row
+ *   boxes      host int[n_crops][5] = {kind, a, b, c, d}: kind 0 = crop box (left, top, right, bottom);
+ *              kind 1 = black square canvas (side, paste_x, paste_y, -) with the image pasted on it
+ *   out_dev    uint8 [n_crops][3][out_size][out_size], bit-exact with the Pillow path; feed it to
+ *              clipenc_encode as CLIPENC_IN_U8.
+ * The call synchronises `stream` once (its pinned staging buffer is reused). */
+int preproc_create(int device, preproc_t* out);
+int preproc_destroy(preproc_t p);
+int preproc_crops_u8(preproc_t p, const uint8_t* image_dev, int height, int width, int pitch_bytes, int n_crops,
+                     const int* boxes, int out_size, uint8_t* out_dev, void* stream);
+/* Host-only: the fixed-point resampling tables of one axis (window start/length and 22-bit weights per output
+ * coordinate out0 .. out0+n_out-1), exposed so that they can be pinned against Pillow without a GPU. */
+int preproc_axis_tables(int in_size, int out_size, int out0, int n_out, int* bounds, int* kk, int kk_capacity, int* ksize);
 
 /* Per-kernel timing of the chain behind clipenc_encode / clipenc_encode_score, taken with HIP events on
  * the caller's stream (used by bench.py for the roofline line).  While enabled, every kernel launch is

@@ -47,6 +47,15 @@ def test_embed_predict_dedup_pipeline(gpu, tmp_path):
     got = torch.cat([d[c] for c in CROP_NAMES])
     assert got.shape == (4, cfg.embed_dim) and one_minus_cos(got, ref).max().item() < 1e-3
 
+    # the same store written with the GPU front end (workers only decode) is identical, file by file
+    ds2 = embed_driver.Feature_Dataset(root, MODEL, 4, shuffle_filenames=False, num_workers=0, device="cuda",
+                                       force_reencode=True, gpu_preprocess=True)
+    before = {f: torch.load(os.path.join(root, f), weights_only=True) for f in sorted(os.listdir(root)) if f.endswith(".pt")}
+    assert ds2.process() == (9, 0, 0)
+    for f, old in before.items():
+        new = torch.load(os.path.join(root, f), weights_only=True)
+        assert all(torch.equal(new[MODEL][c], old[MODEL][c]) for c in CROP_NAMES), f
+
     # regressor checkpoint in the reference's pickle format, then the predict driver
     sizes = [2 * cfg.embed_dim, 32, 16, 8, 1]
     Ws, bs = np_fc_weights(sizes, 5)
