@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2516.6      # MI355X dense bf16 MFMA: 256 CU x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
+PEAK_FP8_TFLOPS = 5033.2       # dense e4m3 on the block-scaled MFMA: 2x the bf16 rate per clock (MI355X_MICROARCH.md)
 MODEL = "ViT-L-14"
 IMAGES_PER_GPU = 512
 CROPS_PER_IMAGE = 4
@@ -96,6 +97,8 @@ def main():
     ap.add_argument("--images", type=int, default=IMAGES_PER_GPU, help="images per GPU per step (default 512)")
     ap.add_argument("--chunk", type=int, default=0, help="crops per pass through the layer chain (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
+                    help="arithmetic of the block GEMMs: bf16 = the headline (configs[1]+[2]); fp8 = configs[3] (e4m3 MFMA)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -126,7 +129,7 @@ def main():
     cfg = vit_config.ARCHS[MODEL]
     sd = vit_config.seeded_state_dict(cfg, 0)               # random-init weights of the named architecture
     Ws, bs = fc_weights(1)
-    vit = HipViT(cfg, sd, dev, chunk_crops=args.chunk or None)
+    vit = HipViT(cfg, sd, dev, chunk_crops=args.chunk or None, precision=args.dtype)
     reg = HipRegressor([torch.from_numpy(w) for w in Ws], [torch.from_numpy(b) for b in bs], 0.01, dev)
     n_img = args.images
     crops = synthetic_crops(n_img * CROPS_PER_IMAGE, cfg.image_size, 1234 + rank, dev)   # resident in HBM
@@ -176,19 +179,24 @@ def main():
         DOMINANT = max((k for k in prof if not k.startswith("shape:")), key=lambda k: prof[k][0])
         d_ms, d_n, d_fl = prof[DOMINANT]
         achieved = d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
+        fp8 = args.dtype == "fp8"
+        d_peak = PEAK_FP8_TFLOPS if "fp8" in DOMINANT else PEAK_BF16_TFLOPS
+        workload = ("BASELINE.json configs[3] on one GPU's shard: ViT-L/14 @224 encode with e4m3 MFMA block GEMMs "
+                    "(per-token x per-channel scales), bf16 attention/residual" if fp8 else
+                    "BASELINE.json configs[1]+[2]: ViT-L/14 @224 bf16 encode")
         line = {
             "metric": "images/sec (4 crops each) ViT-L/14 encode+score @ bs512",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[1]+[2]: ViT-L/14 @224 bf16 encode of {n_img} images x 4 crops per GPU "
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{workload} of {n_img} images x 4 crops per GPU "
                                    "+ fused fp32 regressor 3072-264-128-64-1, seeded random-init weights, crops resident in HBM",
                        "images_per_gpu": n_img, "crops_per_image": CROPS_PER_IMAGE, "parallelism": f"image-sharded x{world}",
                        "chunk_crops": args.chunk or 2048},
             "end_to_end": {"tflops": round(value * flop_per_image / 1e12, 1),
                            "frac_of_bf16_peak": round(value * flop_per_image / 1e12 / (PEAK_BF16_TFLOPS * world), 4)},
-            "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(DOMINANT),
+            "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": d_peak,
+                         "unit": "TFLOP/s", "frac": round(achieved / d_peak, 4), "traffic": pmc_traffic(DOMINANT),
                          "launches": d_n, "avg_launch_ms": round(d_ms / max(d_n, 1), 4),
                          "algorithmic_flop_per_launch": d_fl / max(d_n, 1)},
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 3) for k, v in prof.items() if not k.startswith("shape:")},

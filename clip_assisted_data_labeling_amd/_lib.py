@@ -46,6 +46,7 @@ SIGNATURES = {
     "clipenc_create": (c_int, [POINTER(clipenc_config), POINTER(clipenc_weights), c_int, POINTER(c_void_p)]),
     "clipenc_destroy": (c_int, [c_void_p]),
     "clipenc_set_chunk": (c_int, [c_void_p, c_int]),
+    "clipenc_set_precision": (c_int, [c_void_p, c_int]),
     "clipenc_set_pixel_norm": (c_int, [c_void_p, c_float_p, c_float_p]),
     "clipenc_get_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]),
     "clipenc_encode": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
@@ -67,6 +68,9 @@ SIGNATURES = {
     "clipenc_op_gemm_nt": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "clipenc_op_gemm_nt_stamps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "clipenc_op_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "clipenc_op_quant_rows_fp8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "clipenc_op_gemm_fp8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
+                                    c_void_p, c_void_p, c_void_p]),
     "clipenc_debug_run_layers": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 

@@ -60,16 +60,24 @@ struct LayerDev {
   bf16_t *w_qkv, *w_out, *w_fc, *w_proj;                 // bf16 [N][K]
   float *cs_qkv, *b_qkv, *b_out, *cs_fc, *b_fc, *b_proj;
 };
+struct LayerDev8 {                                       // CLIPENC_PREC_FP8: e4m3 [N][K] + per-output-channel scale [N]
+  uint8_t *w_qkv, *w_out, *w_fc, *w_proj;
+  float *s_qkv, *s_out, *s_fc, *s_proj;
+};
 
 }  // namespace
 
 // one kind per device kernel, named exactly as rocprofv3 --kernel-trace prints it (template arguments included)
 enum { PK_PATCHIFY = 0, PK_GEMM_PATCH, PK_EMBED_LN_PRE, PK_GEMM_QKV, PK_ATTENTION, PK_GEMM_RESID, PK_GEMM_FC1, PK_HEAD, PK_FCREG,
-       PK_SUB_OUT, PK_SUB_FC2, PK_COUNT };   // PK_SUB_*: the EPI_RESID launches split by shape
+       PK_SUB_OUT, PK_SUB_FC2,                // PK_SUB_*: the EPI_RESID launches split by shape
+       PK_QUANT_LN, PK_QUANT, PK_GEMM8_QKV, PK_GEMM8_FC1, PK_GEMM8_RESID, PK_SUB8_OUT, PK_SUB8_FC2, PK_COUNT };
 static const char* const kProfileNames[PK_COUNT] = {
     "patchify_kernel<float>", "gemm_persist_kernel<1, -1>", "embed_ln_pre_kernel", "gemm_persist_kernel<2, -1>",
     "attn_stream_kernel<9, 9, 7>", "gemm_persist_kernel<3, -1>", "gemm_persist_kernel<2, 0>", "head_kernel", "fcreg_kernel",
-    "shape:out_proj(gemm_persist_kernel<3, -1>)", "shape:fc2(gemm_persist_kernel<3, -1>)"};
+    "shape:out_proj(gemm_persist_kernel<3, -1>)", "shape:fc2(gemm_persist_kernel<3, -1>)",
+    "quant_rows_kernel<unsigned short, true>", "quant_rows_kernel<unsigned short, false>", "gemm_fp8_kernel<0, -1>",
+    "gemm_fp8_kernel<0, 0>", "gemm_fp8_kernel<1, -1>", "shape:out_proj(gemm_fp8_kernel<1, -1>)",
+    "shape:fc2(gemm_fp8_kernel<1, -1>)"};
 // (template arguments: <EPI, ACT>; FC1 is <2, 0> with QuickGELU and <2, 1> with erf-GELU; the attention name is the
 //  ViT-L/14 instantiation, other token counts use attn_kernel<NKT> / attn_long_kernel<7>)
 
@@ -128,6 +136,12 @@ struct clipenc_s {
   float *cls = nullptr, *pos = nullptr, *ln_pre_w = nullptr, *ln_pre_b = nullptr;
   float *ln_post_w = nullptr, *ln_post_b = nullptr, *proj = nullptr;
   std::vector<LayerDev> layers;
+  int precision = CLIPENC_PREC_BF16;
+  DevBuf weights8;                                       // fp8 copies of the block weights (made by clipenc_set_precision)
+  std::vector<LayerDev8> layers8;
+  uint8_t* a8 = nullptr;                                 // workspace: quantised GEMM operand [T][max(width, mlp_dim)]
+  float* sa8 = nullptr;                                  //            its per-token scales [T]
+  int ws_precision = -1;
   // workspace (sized for `chunk` crops)
   int chunk = 2048, ws_chunk = 0;
   DevBuf ws;
@@ -156,7 +170,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 int ensure_workspace(clipenc_s* e, int n_crops) {
   const int c = std::min(n_crops, e->chunk);
-  if (c <= e->ws_chunk) return 0;
+  if (c <= e->ws_chunk && e->ws_precision == e->precision) return 0;
   const clipenc_config& g = e->cfg;
   const size_t T = (size_t)c * e->tokens, P = (size_t)c * (e->tokens - 1);
   const size_t parts = g.width / 256;
@@ -166,13 +180,16 @@ int ensure_workspace(clipenc_s* e, int n_crops) {
   const size_t o_qkv = take(T * 3 * g.width * 2), o_at = take(T * g.width * 2), o_h = take(T * g.mlp_dim * 2);
   const size_t Tp = align_up(T, 256);
   const size_t o_s0 = take(Tp * 8), o_sa = take(parts * Tp * 8), o_sb = take(parts * Tp * 8);
+  const bool f8 = e->precision == CLIPENC_PREC_FP8;
+  const size_t o_a8 = f8 ? take(T * (size_t)std::max(g.width, g.mlp_dim)) : 0, o_sa8 = f8 ? take(T * 4) : 0;
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(e->ws.alloc(off));
   char* b = (char*)e->ws.p;
   e->a_patch = (bf16_t*)(b + o_ap); e->pe = (bf16_t*)(b + o_pe); e->x = (bf16_t*)(b + o_x);
   e->qkv = (bf16_t*)(b + o_qkv); e->attn = (bf16_t*)(b + o_at); e->hid = (bf16_t*)(b + o_h);
   e->stats0 = (float*)(b + o_s0); e->stats_a = (float*)(b + o_sa); e->stats_b = (float*)(b + o_sb);
-  e->ws_chunk = c;
+  e->a8 = f8 ? (uint8_t*)(b + o_a8) : nullptr; e->sa8 = f8 ? (float*)(b + o_sa8) : nullptr;
+  e->ws_chunk = c; e->ws_precision = e->precision;
   return 0;
 }
 
@@ -199,6 +216,44 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
   pf.end(st);
   const float* stats_in = e->stats0;
   int stats_parts = 1;
+  if (e->precision == CLIPENC_PREC_FP8) {
+    // per block: quantise the (normalised) GEMM operand row by row, run the e4m3 GEMM, scales + bias (+ act / residual)
+    // in its epilogue.  LayerNorm: gamma sits in the fp8 weights, beta in the bias (as for bf16); the statistics are
+    // computed by the quantiser itself.
+    const size_t D = g.width, Mh = g.mlp_dim;
+    auto gemm8 = [&](const uint8_t* W8, const float* sw, const float* bias, int N, int K, int act, bf16_t* out, bool resid,
+                     int kind, int sub) -> hipError_t {
+      GemmParams q{};
+      q.A = e->a8; q.lda = K; q.W = W8; q.ldw = K; q.M = T; q.N = N; q.K = K; q.out = out; q.ldo = N; q.bias = bias;
+      q.scale_a = e->sa8; q.scale_w = sw; q.act = act; q.resid = resid ? out : nullptr;
+      pf.begin(kind, 2.0 * dT * (double)N * (double)K, st, sub);
+      hipError_t err = ce_gemm_fp8(q, resid ? EPI_RESID : EPI_STORE_BF16, st);
+      pf.end(st);
+      return err;
+    };
+    auto quant = [&](const bf16_t* in, size_t K, int ln) -> hipError_t {
+      pf.begin(ln ? PK_QUANT_LN : PK_QUANT, 0.0, st);
+      hipError_t err = ce_quant_rows_fp8(in, 0, K, e->a8, K, e->sa8, T, (int)K, ln, g.ln_eps, st);
+      pf.end(st);
+      return err;
+    };
+    for (int l = 0; l < n_layers; ++l) {
+      const LayerDev& L = e->layers[l];
+      const LayerDev8& Q = e->layers8[l];
+      HIP_TRY(quant(e->x, D, 1));
+      HIP_TRY(gemm8(Q.w_qkv, Q.s_qkv, L.b_qkv, 3 * g.width, g.width, -1, e->qkv, false, PK_GEMM8_QKV, -1));
+      pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * e->tokens * dD, st);
+      HIP_TRY(ce_attention(e->qkv, e->attn, c, e->tokens, g.width, g.heads, st));
+      pf.end(st);
+      HIP_TRY(quant(e->attn, D, 0));
+      HIP_TRY(gemm8(Q.w_out, Q.s_out, L.b_out, g.width, g.width, -1, e->x, true, PK_GEMM8_RESID, PK_SUB8_OUT));
+      HIP_TRY(quant(e->x, D, 1));
+      HIP_TRY(gemm8(Q.w_fc, Q.s_fc, L.b_fc, g.mlp_dim, g.width, g.act, e->hid, false, PK_GEMM8_FC1, -1));
+      HIP_TRY(quant(e->hid, Mh, 0));
+      HIP_TRY(gemm8(Q.w_proj, Q.s_proj, L.b_proj, g.width, g.mlp_dim, -1, e->x, true, PK_GEMM8_RESID, PK_SUB8_FC2));
+    }
+    return 0;
+  }
   for (int l = 0; l < n_layers; ++l) {
     const LayerDev& L = e->layers[l];
     // K3: qkv = LN1(x) . Wqkv^T + b   (LayerNorm folded into the GEMM epilogue)
@@ -363,6 +418,7 @@ int clipenc_destroy(clipenc_t e) {
   (void)hipSetDevice(e->device);
   e->prof.release();
   e->weights.release();
+  e->weights8.release();
   e->ws.release();
   delete e;
   return 0;
@@ -374,6 +430,44 @@ int clipenc_set_pixel_norm(clipenc_t e, const float* mean3, const float* std3) {
     if (!(std3[i] > 0.f)) return fail("std[%d] = %g must be positive", i, std3[i]);
     e->pix_mean[i] = mean3[i]; e->pix_std[i] = std3[i];
   }
+  return 0;
+}
+
+int clipenc_set_precision(clipenc_t e, int precision) {
+  if (!e) return fail("NULL handle");
+  if (precision != CLIPENC_PREC_BF16 && precision != CLIPENC_PREC_FP8) return fail("unknown precision %d", precision);
+  if (precision == CLIPENC_PREC_FP8 && e->layers8.empty()) {
+    const clipenc_config& g = e->cfg;
+    if (g.mlp_dim > 4096 || g.width > 4096) return fail("fp8: rows longer than 4096 not built (width %d, mlp_dim %d)", g.width, g.mlp_dim);
+    HIP_TRY(hipSetDevice(e->device));
+    const size_t D = g.width, M = g.mlp_dim;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
+    struct LOff { size_t w[4], s[4]; };
+    std::vector<LOff> lo(g.layers);
+    const size_t rows[4] = {3 * D, D, M, D}, cols[4] = {D, D, D, M};
+    for (auto& o : lo)
+      for (int i = 0; i < 4; ++i) { o.w[i] = take(rows[i] * cols[i]); o.s[i] = take(rows[i] * 4); }
+    HIP_TRY(e->weights8.alloc(off));
+    char* db = (char*)e->weights8.p;
+    std::vector<LayerDev8> l8(g.layers);
+    for (int l = 0; l < g.layers; ++l) {
+      const LayerDev& L = e->layers[l];
+      LayerDev8& Q = l8[l];
+      Q.w_qkv = (uint8_t*)(db + lo[l].w[0]); Q.w_out = (uint8_t*)(db + lo[l].w[1]);
+      Q.w_fc = (uint8_t*)(db + lo[l].w[2]); Q.w_proj = (uint8_t*)(db + lo[l].w[3]);
+      Q.s_qkv = (float*)(db + lo[l].s[0]); Q.s_out = (float*)(db + lo[l].s[1]);
+      Q.s_fc = (float*)(db + lo[l].s[2]); Q.s_proj = (float*)(db + lo[l].s[3]);
+      const bf16_t* src[4] = {L.w_qkv, L.w_out, L.w_fc, L.w_proj};   // (gamma already folded into w_qkv / w_fc)
+      uint8_t* dst[4] = {Q.w_qkv, Q.w_out, Q.w_fc, Q.w_proj};
+      float* sc[4] = {Q.s_qkv, Q.s_out, Q.s_fc, Q.s_proj};
+      for (int i = 0; i < 4; ++i)
+        HIP_TRY(ce_quant_rows_fp8(src[i], 0, cols[i], dst[i], cols[i], sc[i], (int)rows[i], (int)cols[i], 0, 0.f, nullptr));
+    }
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    e->layers8.swap(l8);
+  }
+  e->precision = precision;
   return 0;
 }
 
@@ -433,7 +527,11 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
   if (kind < 0 || kind >= PK_COUNT) return fail("profile kind %d out of range", kind);
   HIP_TRY(hipSetDevice(e->device));
   e->prof.collect();
-  if (name) *name = (kind == PK_GEMM_FC1 && e->cfg.act == CLIPENC_ACT_GELU_ERF) ? "gemm_persist_kernel<2, 1>" : kProfileNames[kind];
+  if (name) {
+    *name = kProfileNames[kind];
+    if (e->cfg.act == CLIPENC_ACT_GELU_ERF && kind == PK_GEMM_FC1) *name = "gemm_persist_kernel<2, 1>";
+    if (e->cfg.act == CLIPENC_ACT_GELU_ERF && kind == PK_GEMM8_FC1) *name = "gemm_fp8_kernel<0, 1>";
+  }
   if (total_ms) *total_ms = e->prof.ms[kind];
   if (launches) *launches = e->prof.launches[kind];
   if (algorithmic_flops) *algorithmic_flops = e->prof.flops[kind];
@@ -566,6 +664,26 @@ int clipenc_op_gemm_nt(const void* a_dev, const void* w_dev, int m, int n, int k
   p.A = a_dev; p.lda = k; p.W = w_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out_dev; p.ldo = n; p.bias = bias_dev;
   hipError_t err = ce_gemm_nt(p, dtype, epi, (hipStream_t)stream);
   if (err != hipSuccess) return fail("gemm_nt(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
+  return 0;
+}
+
+int clipenc_op_quant_rows_fp8(const void* in_dev, int in_f32, int n_rows, int k, int ln, float eps, void* out8_dev,
+                              float* scale_dev, void* stream) {
+  if (!in_dev || !out8_dev || !scale_dev) return fail("NULL device pointer");
+  hipError_t err = ce_quant_rows_fp8(in_dev, in_f32, (size_t)k, out8_dev, (size_t)k, scale_dev, n_rows, k, ln, eps, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("quant_rows_fp8(%d,%d) failed: %s", n_rows, k, hipGetErrorString(err));
+  return 0;
+}
+
+int clipenc_op_gemm_fp8(const void* a8_dev, const void* w8_dev, int m, int n, int k, const float* scale_a_dev,
+                        const float* scale_w_dev, const float* bias_dev, int act, const void* resid_dev, void* out_dev,
+                        void* stream) {
+  if (resid_dev && act != -1) return fail("gemm_fp8: activation and residual are exclusive");
+  GemmParams p{};
+  p.A = a8_dev; p.lda = k; p.W = w8_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out_dev; p.ldo = n; p.bias = bias_dev;
+  p.scale_a = scale_a_dev; p.scale_w = scale_w_dev; p.act = act; p.resid = resid_dev;
+  hipError_t err = ce_gemm_fp8(p, resid_dev ? EPI_RESID : EPI_STORE_BF16, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("gemm_fp8(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
   return 0;
 }
 

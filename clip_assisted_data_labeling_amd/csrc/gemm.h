@@ -27,8 +27,12 @@ struct GemmParams {
   float* vals;                   // [cap]
   unsigned long long cap;
   unsigned long long* count;
+  // fp8 path (gemm_fp8.hip): out = acc * scale_a[m] * scale_w[n] + bias[n]
+  const float* scale_a;          // [M] per-token activation scale
+  const float* scale_w;          // [N] per-output-channel weight scale
   unsigned long long* dbg;       // optional [tiles][8] timing stamps (diagnostic entry point only)
 };
 
 hipError_t ce_gemm_nt(const GemmParams& p, int dtype, int epi, hipStream_t stream);
+hipError_t ce_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);           // fp8 e4m3 operands; EPI_STORE_BF16 / EPI_RESID
 hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream);   // bf16; EPI_STORE_BF16 / LNFOLD / RESID

@@ -15,6 +15,10 @@ hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float*
 hipError_t ce_head(const void* x, const float* gamma, const float* beta, const float* proj, float* emb, int n_crops,
                    int n_tok, int width, int embed, float eps, int normalize, hipStream_t stream);
 
+// quant_fp8.hip
+hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out8, size_t ld_out, float* scale, int n_rows,
+                             int K, int ln, float eps, hipStream_t stream);
+
 // fcreg.hip
 #define CE_FC_MAX_LAYERS 8
 #define CE_FC_MAX_SEG 16

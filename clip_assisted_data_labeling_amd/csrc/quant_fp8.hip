@@ -1,0 +1,117 @@
+// Row quantisation to OCP fp8 e4m3 for the fp8 GEMM path (BASELINE.json configs[3]):
+//   out8[row][k] = e4m3( f(in[row][k]) * 448 / absmax_row ),   scale[row] = absmax_row / 448
+// with f = identity (weights, attention output, MLP hidden) or the LayerNorm normalisation (x - mean) * rstd WITHOUT
+// the affine part: gamma is folded into the weight rows and beta into the bias at create time, exactly as for the
+// bf16 path, so the quantised operand is the unit-variance row.  One wave per row, 16 B per lane and access;
+// v_cvt_pk_fp8_f32 does not saturate (1000 -> NaN, tools/probes/fp8probe2.hip), so values are clamped to +-448 first.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int QMAXC = 8;                     // row length <= 4096 elements
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+template <typename TIN> __device__ __forceinline__ void load8(const TIN* p, float (&v)[8]);
+template <> __device__ __forceinline__ void load8<bf16_t>(const bf16_t* p, float (&v)[8]) {
+  const uint4 raw = *(const uint4*)p;
+  v[0] = __uint_as_float(raw.x << 16); v[1] = __uint_as_float(raw.x & 0xffff0000u);
+  v[2] = __uint_as_float(raw.y << 16); v[3] = __uint_as_float(raw.y & 0xffff0000u);
+  v[4] = __uint_as_float(raw.z << 16); v[5] = __uint_as_float(raw.z & 0xffff0000u);
+  v[6] = __uint_as_float(raw.w << 16); v[7] = __uint_as_float(raw.w & 0xffff0000u);
+}
+template <> __device__ __forceinline__ void load8<float>(const float* p, float (&v)[8]) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+template <typename TIN, bool LN>
+__global__ __launch_bounds__(256) void quant_rows_kernel(const TIN* __restrict__ in, size_t ld_in, uint8_t* __restrict__ out,
+                                                         size_t ld_out, float* __restrict__ scale, int n_rows, int K, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const TIN* src = in + (size_t)row * ld_in;
+  float v[QMAXC][8];
+  float s = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < QMAXC; ++ci) {
+    const int c = ci * 512 + lane * 8;
+    if (c < K) {
+      load8<TIN>(src + c, v[ci]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[ci][j];
+    }
+  }
+  if constexpr (LN) {
+    const float mean = wave_sum(s) / (float)K;
+    float ss = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < QMAXC; ++ci)
+      if (ci * 512 + lane * 8 < K) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { v[ci][j] -= mean; ss += v[ci][j] * v[ci][j]; }
+      }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)K + eps);
+#pragma unroll
+    for (int ci = 0; ci < QMAXC; ++ci)
+      if (ci * 512 + lane * 8 < K) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[ci][j] *= rstd;
+      }
+  }
+  float amax = 0.f;
+#pragma unroll
+  for (int ci = 0; ci < QMAXC; ++ci)
+    if (ci * 512 + lane * 8 < K) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[ci][j]));
+    }
+  amax = wave_max(amax);
+  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+  const float inv = amax > 0.f ? 448.0f / amax : 0.f;
+  uint8_t* dst = out + (size_t)row * ld_out;
+#pragma unroll
+  for (int ci = 0; ci < QMAXC; ++ci) {
+    const int c = ci * 512 + lane * 8;
+    if (c < K) {
+      float q[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) q[j] = fminf(fmaxf(v[ci][j] * inv, -448.0f), 448.0f);
+      int w0 = 0, w1 = 0;
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false);
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
+      *(uint2*)(dst + c) = uint2{(uint32_t)w0, (uint32_t)w1};
+    }
+  }
+  if (lane == 0) scale[row] = sc;
+}
+
+}  // namespace
+
+// in: bf16 (in_f32 == 0) or fp32 rows of K elements (K % 8 == 0, K <= 4096); ln != 0 normalises each row first.
+hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out8, size_t ld_out, float* scale, int n_rows,
+                             int K, int ln, float eps, hipStream_t stream) {
+  if (n_rows < 1 || K < 8 || K % 8 != 0 || K > QMAXC * 512 || ld_in < (size_t)K || ld_out < (size_t)K) return hipErrorInvalidValue;
+  dim3 grid((n_rows + 3) / 4), block(256);
+  if (in_f32) {
+    if (ln) hipLaunchKernelGGL((quant_rows_kernel<float, true>), grid, block, 0, stream, (const float*)in, ld_in, (uint8_t*)out8, ld_out, scale, n_rows, K, eps);
+    else hipLaunchKernelGGL((quant_rows_kernel<float, false>), grid, block, 0, stream, (const float*)in, ld_in, (uint8_t*)out8, ld_out, scale, n_rows, K, eps);
+  } else {
+    if (ln) hipLaunchKernelGGL((quant_rows_kernel<bf16_t, true>), grid, block, 0, stream, (const bf16_t*)in, ld_in, (uint8_t*)out8, ld_out, scale, n_rows, K, eps);
+    else hipLaunchKernelGGL((quant_rows_kernel<bf16_t, false>), grid, block, 0, stream, (const bf16_t*)in, ld_in, (uint8_t*)out8, ld_out, scale, n_rows, K, eps);
+  }
+  return hipGetLastError();
+}

@@ -65,7 +65,10 @@ class _WeightPack:
 class HipViT:
     """Owner of one `clipenc_t` handle (weights + workspace on one GPU)."""
 
-    def __init__(self, cfg: ViTConfig, state_dict: Dict[str, torch.Tensor], device="cuda", chunk_crops: Optional[int] = None):
+    PRECISIONS = {"bf16": 0, "fp8": 1}
+
+    def __init__(self, cfg: ViTConfig, state_dict: Dict[str, torch.Tensor], device="cuda", chunk_crops: Optional[int] = None,
+                 precision: str = "bf16"):
         self.lib = _lib.load()
         self.cfg = cfg
         self.device_index = _device_index(device)
@@ -80,6 +83,16 @@ class HipViT:
         self.handle = h
         if chunk_crops:
             self.set_chunk(chunk_crops)
+        self.precision = "bf16"
+        if precision != "bf16":
+            self.set_precision(precision)
+
+    def set_precision(self, precision: str) -> None:
+        """"bf16" (default) or "fp8" (e4m3 block GEMMs, BASELINE.json configs[3]); switchable at any time."""
+        if precision not in self.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(self.PRECISIONS)}, got {precision!r}")
+        _lib.check(self.lib.clipenc_set_precision(self.handle, self.PRECISIONS[precision]), "clipenc_set_precision")
+        self.precision = precision
 
     def set_chunk(self, chunk_crops: int) -> None:
         _lib.check(self.lib.clipenc_set_chunk(self.handle, int(chunk_crops)), "clipenc_set_chunk")
@@ -166,14 +179,14 @@ class CLIP_Encoder:
 
     accepts_uint8 = True      # encode_image also takes uint8 [n,3,R,R] (output of get_preprocess_transform().to_uint8)
 
-    def __init__(self, model_name, model_path=None, device=None):
+    def __init__(self, model_name, model_path=None, device=None, precision="bf16"):
         self.device = device if device else _DEVICE
-        self.precision = "bf16"                      # the reference runs fp16 on cuda (:61); this build bf16 MFMA
+        self.precision = precision                   # the reference runs fp16 on cuda (:61); here bf16 MFMA, or "fp8"
         self.model_name = model_name
         self.model_architecture, self.pretrained_dataset = self.model_name.split("/", 2)   # :63
         print(f"Loading CLIP model {self.model_name}...")
         self.config = config_for(model_name)
-        self.model = HipViT(self.config, load_weights(model_name, model_path), self.device)
+        self.model = HipViT(self.config, load_weights(model_name, model_path), self.device, precision=precision)
         self.preprocess = clip_val_transform(self.config.image_size)
         self.img_resolution = self.config.image_size                                       # :76-85
         print(f"CLIP model {self.model_name} with img_resolution {self.img_resolution} loaded on {self.device}!")

@@ -65,6 +65,17 @@ int clipenc_destroy(clipenc_t enc);
 /* Mean / std of the Normalize step applied to CLIPENC_IN_U8 input (defaults: the OpenAI CLIP constants). */
 int clipenc_set_pixel_norm(clipenc_t enc, const float* mean3, const float* std3);
 
+/* Arithmetic of the four per-block GEMMs (QKV, attention out, FC1, FC2) — BASELINE.json configs[1] vs configs[3].
+ * BF16 (default): bf16 MFMA, LayerNorm folded into the GEMM epilogue.
+ * FP8: OCP e4m3 operands on the block-scaled MFMA (unit hardware scales) with per-token activation scales and
+ *      per-output-channel weight scales applied in the epilogue, fp32 accumulation; attention, LayerNorm statistics,
+ *      residual stream, patch embedding and head stay as in BF16.  The first switch quantises the handle's weights on
+ *      the device.  open_clip has no such mode (the reference runs fp32/fp16 autocast, utils/embedder.py:94-97); the
+ *      measured deviation from the fp32 oracle is stated in DESIGN.md and bounded by tests/test_gpu_fp8.py. */
+#define CLIPENC_PREC_BF16 0
+#define CLIPENC_PREC_FP8 1
+int clipenc_set_precision(clipenc_t enc, int precision);
+
 /* Crops pushed through the 24-layer chain per pass (workspace is sized for it; default 2048). */
 int clipenc_set_chunk(clipenc_t enc, int chunk_crops);
 int clipenc_get_info(clipenc_t enc, int* tokens, int* embed_dim, int* chunk_crops, size_t* workspace_bytes);
@@ -145,6 +156,15 @@ int clipenc_profile_read(clipenc_t enc, int kind, const char** name, double* tot
 /* out[M][N] = A[M][K] . W[N][K]^T (+ bias[N]); A, W 16-bit row-major; N % 256 == 0, K % 128 == 0 */
 int clipenc_op_gemm_nt(const void* a_dev, const void* w_dev, int m, int n, int k, int dtype, int epi,
                        const float* bias_dev, void* out_dev, void* stream);
+/* Row quantisation to e4m3: out8[r][k] = fp8(f(in[r][k]) * 448 / absmax_r), scale[r] = absmax_r / 448, f = identity or
+ * (ln != 0) the LayerNorm normalisation without affine.  in: bf16 (in_f32 == 0) or fp32 [n_rows][k]; k % 8 == 0, k <= 4096 */
+int clipenc_op_quant_rows_fp8(const void* in_dev, int in_f32, int n_rows, int k, int ln, float eps, void* out8_dev,
+                              float* scale_dev, void* stream);
+/* out_bf16[M][N] = act((A8[M][K] . W8[N][K]^T) * scale_a[M] * scale_w[N] + bias[N]) (+ resid_bf16[M][N] when given,
+ * act must be -1 then; resid may alias out);  N % 256 == 0, K % 256 == 0;  act: -1 none, 0 QuickGELU, 1 erf-GELU */
+int clipenc_op_gemm_fp8(const void* a8_dev, const void* w8_dev, int m, int n, int k, const float* scale_a_dev,
+                        const float* scale_w_dev, const float* bias_dev, int act, const void* resid_dev, void* out_dev,
+                        void* stream);
 /* Diagnostic: bf16-store GEMM that also writes, per workgroup, 100 MHz timestamps
  * {entry, prologue done, main loop done, stores issued, stores retired, hw id} into stamps_dev[tiles][8]. */
 int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n, int k, void* out_dev,

@@ -1,0 +1,210 @@
+"""fp8 (OCP e4m3) block GEMMs — BASELINE.json configs[3].  The row quantiser and the fp8 GEMM are pinned on their own
+against torch's float8_e4m3fn arithmetic; the whole encoder in CLIPENC_PREC_FP8 is held to the same 1e-3 cosine bound
+against the fp32 oracle as the bf16 path."""
+import pytest
+import torch
+
+from clip_assisted_data_labeling_amd import _lib, vit_config
+from clip_assisted_data_labeling_amd.embedder import HipViT
+from oracle import vit_oracle
+from tests.helpers import one_minus_cos, synthetic_crops
+
+pytestmark = pytest.mark.gpu
+
+COS_TOL = 1e-3
+F8 = torch.float8_e4m3fn
+
+
+def _stream(dev):
+    return _lib.current_stream_ptr(dev)
+
+
+def _quant(gpu, x, ln=False, eps=1e-5):
+    lib = _lib.load()
+    n, k = x.shape
+    out = torch.full((n, k), 0x7f, dtype=torch.uint8, device=gpu)           # 0x7f = NaN in e4m3fn
+    sc = torch.full((n,), float("nan"), dtype=torch.float32, device=gpu)
+    _lib.check(lib.clipenc_op_quant_rows_fp8(x.data_ptr(), 1 if x.dtype == torch.float32 else 0, n, k, 1 if ln else 0,
+                                             eps, out.data_ptr(), sc.data_ptr(), _stream(gpu)), "quant")
+    torch.cuda.synchronize()
+    return out, sc
+
+
+def _gemm8(gpu, a8, w8, sa, sw, bias, act=-1, resid=None):
+    lib = _lib.load()
+    m, k = a8.shape
+    n = w8.shape[0]
+    out = resid.clone() if resid is not None else torch.full((m, n), float("nan"), device=gpu, dtype=torch.bfloat16)
+    _lib.check(lib.clipenc_op_gemm_fp8(a8.data_ptr(), w8.data_ptr(), m, n, k, sa.data_ptr(), sw.data_ptr(), bias.data_ptr(),
+                                       act, out.data_ptr() if resid is not None else None, out.data_ptr(), _stream(gpu)),
+               "gemm_fp8")
+    torch.cuda.synchronize()
+    return out
+
+
+def _deq(u8):
+    return u8.view(F8).float()
+
+
+# ------------------------------------------------------------------------------------------ quantiser
+@pytest.mark.parametrize("n,k,dtype", [(1, 256, torch.bfloat16), (1029, 1024, torch.bfloat16), (517, 4096, torch.bfloat16),
+                                       (64, 768, torch.float32), (3, 8, torch.float32)])
+def test_quant_rows_matches_torch_e4m3(gpu, n, k, dtype):
+    g = torch.Generator().manual_seed(n + k)
+    x = (torch.randn(n, k, generator=g) * torch.logspace(-3, 3, n).view(n, 1)).to(dtype)
+    x[0, :4] = torch.tensor([0.0, -0.0, 1e-30, -1e-30]).to(dtype)
+    q, sc = _quant(gpu, x.to(gpu))
+    xf = x.float()
+    amax = xf.abs().amax(dim=1)
+    assert torch.equal(sc.cpu(), amax * (1.0 / 448.0))
+    ref = (xf * (448.0 / amax).view(n, 1)).clamp(-448, 448).to(F8)           # RNE, same as v_cvt_pk_fp8_f32
+    got = q.cpu().view(F8)
+    assert not torch.isnan(got.float()).any()
+    # the device evaluates 448/absmax with its own fp32 division; where x * inv lands within an ulp of a rounding
+    # boundary the code may differ by one step from torch's -- nowhere else
+    diff = (q.cpu().to(torch.int16) - ref.view(torch.uint8).to(torch.int16)).abs()
+    assert diff.max().item() <= 1 and (diff != 0).float().mean().item() < 1e-3, (diff.max(), (diff != 0).sum())
+    # every row uses the full range: its absmax element maps to +-448
+    assert torch.equal(got.float().abs().amax(dim=1), torch.full((n,), 448.0))
+
+
+def test_quant_rows_zero_row_and_layernorm(gpu):
+    x = torch.zeros(4, 512, dtype=torch.bfloat16)
+    x[1] = 3.0                                                              # constant row: LN -> 0
+    x[2] = torch.randn(512).to(torch.bfloat16)
+    x[3] = (torch.randn(512) * 50 + 20).to(torch.bfloat16)
+    q, sc = _quant(gpu, x.to(gpu))
+    assert torch.equal(q[0].cpu(), torch.zeros(512, dtype=torch.uint8)) and sc[0].item() == 1.0
+    q, sc = _quant(gpu, x.to(gpu), ln=True, eps=1e-5)
+    xf = x.float()
+    xhat = (xf - xf.mean(1, keepdim=True)) * torch.rsqrt(xf.var(1, unbiased=False, keepdim=True) + 1e-5)
+    deq = _deq(q.cpu()) * sc.cpu().view(4, 1)
+    assert torch.isfinite(deq).all()
+    # e4m3 keeps 3 mantissa bits: relative error <= 2^-4 of the element, plus the subnormal floor of the row
+    err = (deq - xhat).abs()
+    bound = xhat.abs() * 2.0 ** -4 + xhat.abs().amax(1, keepdim=True) * 2.0 ** -9 / 448 * 2 + 1e-6
+    assert (err <= bound).all()
+    assert deq[0].abs().max().item() == 0.0 and deq[1].abs().max().item() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------ fp8 GEMM
+def _rand8(m, k, g):
+    x = torch.randn(m, k, generator=g)
+    amax = x.abs().amax(1, keepdim=True)
+    return (x * (448.0 / amax)).to(F8).view(torch.uint8), (amax / 448.0).flatten()
+
+
+@pytest.mark.parametrize("m,n,k", [(256, 256, 256), (1, 256, 256), (255, 512, 512), (1285, 768, 1024), (4099, 1024, 4096),
+                                   (2056, 3072, 1024)])
+def test_gemm_fp8_matches_torch(gpu, m, n, k):
+    g = torch.Generator().manual_seed(m + 3 * n + 7 * k)
+    a8, sa = _rand8(m, k, g)
+    w8, sw = _rand8(n, k, g)
+    bias = torch.randn(n, generator=g)
+    scale = sa.double().view(m, 1) * sw.double().view(1, n)
+    ref = (_deq(a8).double() @ _deq(w8).double().t()) * scale + bias.double()
+    mag = (_deq(a8).double().abs() @ _deq(w8).double().abs().t()) * scale          # sum_k |a||w|
+    out = _gemm8(gpu, a8.to(gpu), w8.to(gpu), sa.to(gpu), sw.to(gpu), bias.to(gpu)).float().cpu()
+    assert torch.isfinite(out).all()
+    # final bf16 rounding (half an ulp = 2^-8 relative at most) + the accumulation error of the f8f6f4 MFMA, which is
+    # NOT an IEEE fp32 sum: measured <= 4e-6 * sum|a||w| on gfx950 (tools/diag_fp8.py; fp32 would give 3e-8)
+    tol = ref.abs() * (2.0 ** -8 * 1.001) + 1e-5 * mag + 1e-6
+    assert ((out.double() - ref).abs() <= tol).all()
+
+
+def test_gemm_fp8_is_not_transposed_or_permuted(gpu):
+    m, n, k = 512, 256, 512
+    a = torch.zeros(m, k)
+    a[torch.arange(m), (torch.arange(m) * 37) % k] = 1.0                     # one-hot rows pick single W columns
+    w = ((torch.arange(n).view(n, 1) * 5 + torch.arange(k).view(1, k) * 3) % 17).float() - 8.0   # exact in e4m3
+    ones_m, ones_n, zb = torch.ones(m), torch.ones(n), torch.zeros(n)
+    out = _gemm8(gpu, a.to(F8).view(torch.uint8).to(gpu), w.to(F8).view(torch.uint8).to(gpu), ones_m.to(gpu), ones_n.to(gpu),
+                 zb.to(gpu)).float().cpu()
+    assert torch.equal(out, a @ w.t())
+
+
+@pytest.mark.parametrize("act", [0, 1])
+def test_gemm_fp8_activation_and_residual(gpu, act):
+    m, n, k = 771, 512, 256
+    g = torch.Generator().manual_seed(act)
+    a8, sa = _rand8(m, k, g)
+    w8, sw = _rand8(n, k, g)
+    bias = torch.randn(n, generator=g)
+    lin = (_deq(a8) @ _deq(w8).t()) * sa.view(m, 1) * sw.view(1, n) + bias
+    acc_tol = 2e-5 * (_deq(a8).abs() @ _deq(w8).abs().t()) * sa.view(m, 1) * sw.view(1, n)   # MFMA accumulation, see above
+    ref = lin * torch.sigmoid(1.702 * lin) if act == 0 else torch.nn.functional.gelu(lin)
+    out = _gemm8(gpu, a8.to(gpu), w8.to(gpu), sa.to(gpu), sw.to(gpu), bias.to(gpu), act=act).float().cpu()
+    assert ((out - ref).abs() <= ref.abs() * 2.0 ** -7 + 2e-3 + 1.2 * acc_tol).all()
+    resid = torch.randn(m, n, generator=g).to(torch.bfloat16)
+    out = _gemm8(gpu, a8.to(gpu), w8.to(gpu), sa.to(gpu), sw.to(gpu), bias.to(gpu), resid=resid.to(gpu)).float().cpu()
+    ref = lin + resid.float()
+    assert ((out - ref).abs() <= ref.abs() * 2.0 ** -8 * 1.001 + 1e-5 + acc_tol).all()
+
+
+def test_gemm_fp8_rejects_bad_shapes(gpu):
+    lib = _lib.load()
+    z = torch.zeros(1 << 20, dtype=torch.uint8, device=gpu)
+    f = torch.zeros(4096, dtype=torch.float32, device=gpu)
+    for (m, n, k) in [(256, 128, 256), (256, 256, 128), (256, 256, 320), (0, 256, 256)]:
+        rc = lib.clipenc_op_gemm_fp8(z.data_ptr(), z.data_ptr(), m, n, k, f.data_ptr(), f.data_ptr(), f.data_ptr(), -1, None,
+                                     z.data_ptr(), _stream(gpu))
+        assert rc != 0, (m, n, k)
+    rc = lib.clipenc_op_gemm_fp8(z.data_ptr(), z.data_ptr(), 256, 256, 256, f.data_ptr(), f.data_ptr(), f.data_ptr(), 0,
+                                 z.data_ptr(), z.data_ptr(), _stream(gpu))
+    assert rc != 0                                                           # activation + residual
+
+
+# ------------------------------------------------------------------------------------------ encoder in fp8
+@pytest.mark.parametrize("arch", ["ViT-tiny-test", "ViT-small-test", "ViT-B-32"])
+def test_encoder_fp8_within_tolerance_of_oracle(gpu, arch):
+    cfg = vit_config.ARCHS[arch]
+    sd = vit_config.seeded_state_dict(cfg, 3)
+    crops = synthetic_crops(8, cfg.image_size, 12)
+    ref = vit_oracle.encode_image(sd, cfg, crops)
+    vit = HipViT(cfg, sd, gpu)
+    bf = vit.encode(crops.to(gpu)).cpu()
+    vit.set_precision("fp8")
+    f8 = vit.encode(crops.to(gpu))
+    assert torch.equal(f8, vit.encode(crops.to(gpu)))                        # deterministic
+    f8 = f8.cpu()
+    assert not torch.equal(f8, bf)                                           # the fp8 kernels did run
+    omc = one_minus_cos(f8, ref)
+    assert omc.max().item() < COS_TOL, omc
+    vit.set_precision("bf16")
+    assert torch.equal(vit.encode(crops.to(gpu)).cpu(), bf)                  # and switching back restores bf16 exactly
+    vit.close()
+
+
+def test_encoder_fp8_chunk_and_row_invariance(gpu):
+    cfg = vit_config.ARCHS["ViT-small-test"]
+    vit = HipViT(cfg, vit_config.seeded_state_dict(cfg, 4), gpu, precision="fp8")
+    crops = synthetic_crops(37, cfg.image_size, 5).to(gpu)
+    crops[5] = crops[20]
+    e = vit.encode(crops)
+    assert torch.equal(e[5], e[20])                  # per-token scales: a crop's embedding does not depend on its batch
+    vit.set_chunk(16)
+    assert one_minus_cos(e.cpu(), vit.encode(crops).cpu()).max().item() < 1e-6
+    vit.close()
+
+
+def test_encoder_fp8_with_outlier_channels(gpu):
+    """Same planted outliers as the bf16 test (test_gpu_parity.py): a few residual channels 60x larger than the rest.
+    Per-token scaling puts those on the top of the e4m3 range and the floating-point format keeps 3 mantissa bits for
+    the small channels down to 2^-15 of the row maximum."""
+    cfg = vit_config.ARCHS["ViT-small-test"]
+    sd = vit_config.seeded_state_dict(cfg, 8)
+    g = torch.Generator().manual_seed(0)
+    hot = torch.randperm(cfg.width, generator=g)[:3]
+    sd["ln_pre.weight"][hot] *= 60.0
+    sd["ln_pre.bias"] += 1.5
+    sd["ln_pre.bias"][hot] += 40.0
+    for l in range(cfg.layers):
+        sd[f"transformer.resblocks.{l}.attn.out_proj.bias"][hot[0]] += 25.0
+        sd[f"transformer.resblocks.{l}.mlp.c_proj.bias"][hot[1]] -= 25.0
+    crops = synthetic_crops(6, cfg.image_size, 31)
+    ref = vit_oracle.encode_image(sd, cfg, crops)
+    vit = HipViT(cfg, sd, gpu, precision="fp8")
+    omc = one_minus_cos(vit.encode(crops.to(gpu)).cpu(), ref)
+    print("fp8 outlier 1-cos:", omc)
+    assert omc.max().item() < COS_TOL, omc
+    vit.close()

@@ -32,6 +32,22 @@ def test_vit_l14_matches_fp32_oracle(vit_l14, gpu):
     assert (got - ref).abs().max().item() < 0.02
 
 
+def test_vit_l14_fp8_matches_fp32_oracle(vit_l14, gpu):
+    """BASELINE.json configs[3]: e4m3 block GEMMs, held to the same embedding tolerance as bf16."""
+    cfg, sd, vit = vit_l14
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    crops = synthetic_crops(6, 224, 77)
+    ref = vit_oracle.encode_image(sd, cfg, crops)
+    vit.set_precision("fp8")
+    try:
+        got = vit.encode(crops.to(gpu)).cpu()
+    finally:
+        vit.set_precision("bf16")
+    omc = one_minus_cos(got, ref)
+    print("ViT-L/14 fp8 1-cos vs fp32 oracle:", omc)
+    assert omc.max().item() < 1e-3, omc
+
+
 def test_vit_l14_properties_at_batch_size(vit_l14, gpu):
     cfg, _, vit = vit_l14
     n = 512                                         # 128 images x 4 crops; 131 584 token rows, 514 M-tiles
