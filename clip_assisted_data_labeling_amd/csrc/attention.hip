@@ -20,6 +20,15 @@
 
 namespace {
 
+// CLIPENC_PREC_FP8: O can be stored as e4m3 with a static per-channel scale (out_inv[c] = 1/scale, folded into the
+// out-projection's weight columns): 4 values -> one dword
+__device__ __forceinline__ int pack_fp8x4(float a, float b, float c, float d) {
+  int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(a, -448.0f, 448.0f), __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f), w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(c, -448.0f, 448.0f), __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f), w, true);
+  return w;
+}
+
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
@@ -33,7 +42,8 @@ __device__ __forceinline__ int v_swz(int row, int chunk) { return row * 128 + ((
 
 template <int NKT>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                      int n_tok, int width, int heads, float scale_log2e) {
+                                                      int n_tok, int width, int heads, float scale_log2e,
+                                                     const float* __restrict__ out_inv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWS = NKT * 32;
   char* Ks = smem;
@@ -144,7 +154,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__
     const float inv = 1.0f / lacc[0];
 
     // ---- store O[q][head*64 + d]: reg group g4 holds d = dt*32 + 8*g4 + 4h + (0..3) ----
-    if (q < n_tok) {
+    if (q < n_tok && out_inv) {
+      uint8_t* orow = (uint8_t*)out + ((size_t)crop * n_tok + q) * width + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int col = dt * 32 + g4 * 8 + h * 4;
+          const f32x4_t is = *(const f32x4_t*)(out_inv + head * 64 + col);
+          *(int*)(orow + col) = pack_fp8x4(o[dt][g4 * 4 + 0] * inv * is[0], o[dt][g4 * 4 + 1] * inv * is[1],
+                                           o[dt][g4 * 4 + 2] * inv * is[2], o[dt][g4 * 4 + 3] * inv * is[3]);
+        }
+    } else if (q < n_tok) {
       bf16_t* orow = out + ((size_t)crop * n_tok + q) * width + head * 64;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -168,7 +189,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__
 // ---------------------------------------------------------------------------------------------
 template <int CT>
 __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                           int n_tok, int width, int heads, float scale_log2e, int nkt) {
+                                                           int n_tok, int width, int heads, float scale_log2e, int nkt,
+                                                           const float* __restrict__ out_inv) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int rows = nkt * 32;
   char* Ks = smem;
@@ -286,7 +308,18 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
       }
     }
     const float inv = 1.0f / lacc[0];
-    if (q < n_tok) {
+    if (q < n_tok && out_inv) {
+      uint8_t* orow = (uint8_t*)out + ((size_t)crop * n_tok + q) * width + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int col = dt * 32 + g4 * 8 + h * 4;
+          const f32x4_t is = *(const f32x4_t*)(out_inv + head * 64 + col);
+          *(int*)(orow + col) = pack_fp8x4(o[dt][g4 * 4 + 0] * inv * is[0], o[dt][g4 * 4 + 1] * inv * is[1],
+                                           o[dt][g4 * 4 + 2] * inv * is[2], o[dt][g4 * 4 + 3] * inv * is[3]);
+        }
+    } else if (q < n_tok) {
       bf16_t* orow = out + ((size_t)crop * n_tok + q) * width + head * 64;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
@@ -301,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
 }
 
 hipError_t launch_attn_long(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
-                            hipStream_t stream) {
+                            const float* out_inv, hipStream_t stream) {
   constexpr int CT = 7;
   const int nkt = (n_tok + 31) / 32;
   const int lds = nkt * 32 * 128 * 2;
@@ -310,7 +343,7 @@ hipError_t launch_attn_long(const bf16_t* qkv, bf16_t* out, int n_crops, int n_t
   if (e != hipSuccess) return e;
   const float scale_log2e = 0.125f * 1.44269504088896340736f;
   hipLaunchKernelGGL((attn_long_kernel<CT>), dim3(n_crops * heads), dim3(512), lds, stream, qkv, out, n_tok, width,
-                     heads, scale_log2e, nkt);
+                     heads, scale_log2e, nkt, out_inv);
   return hipGetLastError();
 }
 
@@ -335,7 +368,7 @@ __device__ __forceinline__ unsigned lds_load_u32(const char* p) {
 template <int NKT, int CT, int NCW>
 __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n_tok, int width, int heads, float scale_log2e,
-    int n_tasks, int dbg_mode) {
+    int n_tasks, int dbg_mode, const float* __restrict__ out_inv) {
   // NCW compute waves + 1 loader; keys walked in chunks of CT tiles (CT == NKT: one exact pass; CT < NKT:
   // online softmax, fewer live score registers -> 3 waves per SIMD).
   // dbg_mode (timing experiments only, results invalid): 1 = loader alone, 2 = compute alone
@@ -534,6 +567,36 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
 
     const float inv = 1.0f / lacc[0];                           // the MFMA already summed both lane halves
 
+    if (out_inv) {
+      // ---- O as e4m3: fragment layout -> [TR_ROWS q rows][80-B pitch] image -> whole 64-B rows ----
+      uint8_t* obase8 = (uint8_t*)out + (size_t)crop * n_tok * width + head * 64 + (lane & 3) * 16;
+      int opk8[8];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4_t is = *(const f32x4_t*)(out_inv + head * 64 + dt * 32 + g4 * 8 + h * 4);
+          opk8[dt * 4 + g4] = pack_fp8x4(o[dt][g4 * 4 + 0] * inv * is[0], o[dt][g4 * 4 + 1] * inv * is[1],
+                                         o[dt][g4 * 4 + 2] * inv * is[2], o[dt][g4 * 4 + 3] * inv * is[3]);
+        }
+#pragma unroll
+      for (int pass = 0; pass < 32 / TR_ROWS; ++pass) {
+        if (r / TR_ROWS == pass) {
+          const int rr = r % TR_ROWS;
+#pragma unroll
+          for (int c8 = 0; c8 < 8; ++c8) *(int*)(tr + rr * 80 + c8 * 8 + h * 4) = opk8[c8];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int row = lane >> 2;
+        if (row < TR_ROWS) {
+          const uint4 v0 = *(const uint4*)(tr + row * 80 + (lane & 3) * 16);
+          const int qa = qb * 32 + pass * TR_ROWS + row;
+          if (qa < n_tok) *(uint4*)(obase8 + (size_t)qa * width) = v0;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      continue;
+    }
     // ---- O: fragment layout -> [TR_ROWS q rows][64 d] bf16 image -> whole 128-B rows ----
     bf16_t* obase = out + (size_t)crop * n_tok * width + head * 64 + (lane & 7) * 8;
     uint2 opk[8];
@@ -565,7 +628,7 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
 
 template <int NKT, int CT, int NCW>
 hipError_t launch_attn_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
-                              hipStream_t stream) {
+                              const float* out_inv, hipStream_t stream) {
   const int lds = 2 * 2 * NKT * 32 * 128 + NCW * (NCW <= 7 ? 2048 : 1024) + 2048;
   static bool attr_set = false;
   static int n_cu = 256;
@@ -584,13 +647,13 @@ hipError_t launch_attn_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n
   const float scale_log2e = 0.125f * 1.44269504088896340736f;
   static const int dbg = [] { const char* e = getenv("CLIPENC_ATTN_DBG"); return e ? atoi(e) : 0; }();
   hipLaunchKernelGGL((attn_stream_kernel<NKT, CT, NCW>), dim3(grid), dim3((NCW + 1) * 64), lds, stream, qkv, out, n_tok, width, heads,
-                     scale_log2e, n_tasks, dbg);
+                     scale_log2e, n_tasks, dbg, out_inv);
   return hipGetLastError();
 }
 
 template <int NKT>
 hipError_t launch_attn(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
-                       hipStream_t stream) {
+                       const float* out_inv, hipStream_t stream) {
   const int lds = NKT * 32 * 128 * 2;
   static bool attr_set = false;
   if (!attr_set) {
@@ -600,32 +663,33 @@ hipError_t launch_attn(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, i
   }
   const float scale_log2e = 0.125f * 1.44269504088896340736f;   // 64^-0.5 * log2(e)
   hipLaunchKernelGGL((attn_kernel<NKT>), dim3(n_crops * heads), dim3(256), lds, stream, qkv, out, n_tok, width,
-                     heads, scale_log2e);
+                     heads, scale_log2e, out_inv);
   return hipGetLastError();
 }
 
 }  // namespace
 
-// qkv: [n_crops*n_tok][3*width] bf16 ([q|k|v], head = 64-wide slice); out: [n_crops*n_tok][width] bf16
+// qkv: [n_crops*n_tok][3*width] bf16 ([q|k|v], head = 64-wide slice); out: [n_crops*n_tok][width] bf16, or, when
+// out_inv != NULL, e4m3 bytes: out8[t][c] = fp8(O[t][c] * out_inv[c])
 hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int width, int heads,
-                        hipStream_t stream) {
+                        const float* out_inv, hipStream_t stream) {
   if (width != heads * 64 || n_tok < 1 || n_crops < 1) return hipErrorInvalidValue;
   const int nkt = (n_tok + 31) / 32;
   const bf16_t* q = (const bf16_t*)qkv;
   bf16_t* o = (bf16_t*)out;
   static const int impl = [] { const char* e = getenv("CLIPENC_ATTN_IMPL"); return e ? atoi(e) : 2; }();
-  if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8, 8, 7>(q, o, n_crops, n_tok, width, heads, stream);
-  if (impl == 2 && nkt == 9 && n_crops * heads >= 64) return launch_attn_stream<9, 9, 7>(q, o, n_crops, n_tok, width, heads, stream);
+  if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8, 8, 7>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
+  if (impl == 2 && nkt == 9 && n_crops * heads >= 64) return launch_attn_stream<9, 9, 7>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
   switch (nkt) {                 // NKT must equal ceil(n_tok/32): only the last key tile is masked
-    case 1: return launch_attn<1>(q, o, n_crops, n_tok, width, heads, stream);
-    case 2: return launch_attn<2>(q, o, n_crops, n_tok, width, heads, stream);
-    case 3: return launch_attn<3>(q, o, n_crops, n_tok, width, heads, stream);
-    case 4: return launch_attn<4>(q, o, n_crops, n_tok, width, heads, stream);
-    case 5: return launch_attn<5>(q, o, n_crops, n_tok, width, heads, stream);
-    case 6: return launch_attn<6>(q, o, n_crops, n_tok, width, heads, stream);
-    case 7: return launch_attn<7>(q, o, n_crops, n_tok, width, heads, stream);
-    case 8: return launch_attn<8>(q, o, n_crops, n_tok, width, heads, stream);
-    case 9: return launch_attn<9>(q, o, n_crops, n_tok, width, heads, stream);
-    default: return launch_attn_long(q, o, n_crops, n_tok, width, heads, stream);   // up to 640 tokens (K, V of one head in LDS)
+    case 1: return launch_attn<1>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
+    case 2: return launch_attn<2>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
+    case 3: return launch_attn<3>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
+    case 4: return launch_attn<4>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
+    case 5: return launch_attn<5>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
+    case 6: return launch_attn<6>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
+    case 7: return launch_attn<7>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
+    case 8: return launch_attn<8>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
+    case 9: return launch_attn<9>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
+    default: return launch_attn_long(q, o, n_crops, n_tok, width, heads, out_inv, stream);   // up to 640 tokens (K, V of one head in LDS)
   }
 }

@@ -63,6 +63,8 @@ struct LayerDev {
 struct LayerDev8 {                                       // CLIPENC_PREC_FP8: e4m3 [N][K] + per-output-channel scale [N]
   uint8_t *w_qkv, *w_out, *w_fc, *w_proj;
   float *s_qkv, *s_out, *s_fc, *s_proj;
+  float* is_hid;                                         // [mlp_dim] 1 / static scale of the MLP hidden columns (folded into w_proj)
+  float* is_attn;                                        // [width]   1 / static scale of the attention output (folded into w_out)
 };
 
 }  // namespace
@@ -76,7 +78,7 @@ static const char* const kProfileNames[PK_COUNT] = {
     "attn_stream_kernel<9, 9, 7>", "gemm_persist_kernel<3, -1>", "gemm_persist_kernel<2, 0>", "head_kernel", "fcreg_kernel",
     "shape:out_proj(gemm_persist_kernel<3, -1>)", "shape:fc2(gemm_persist_kernel<3, -1>)",
     "quant_rows_kernel<unsigned short, true>", "quant_rows_kernel<unsigned short, false>", "gemm_fp8_kernel<0, -1>",
-    "gemm_fp8_kernel<0, 0>", "gemm_fp8_kernel<1, -1>", "shape:out_proj(gemm_fp8_kernel<1, -1>)",
+    "gemm_fp8_kernel<2, 0>", "gemm_fp8_kernel<1, -1>", "shape:out_proj(gemm_fp8_kernel<1, -1>)",
     "shape:fc2(gemm_fp8_kernel<1, -1>)"};
 // (template arguments: <EPI, ACT>; FC1 is <2, 0> with QuickGELU and <2, 1> with erf-GELU; the attention name is the
 //  ViT-L/14 instantiation, other token counts use attn_kernel<NKT> / attn_long_kernel<7>)
@@ -139,7 +141,8 @@ struct clipenc_s {
   int precision = CLIPENC_PREC_BF16;
   DevBuf weights8;                                       // fp8 copies of the block weights (made by clipenc_set_precision)
   std::vector<LayerDev8> layers8;
-  uint8_t* a8 = nullptr;                                 // workspace: quantised GEMM operand [T][max(width, mlp_dim)]
+  uint8_t* a8 = nullptr;                                 // workspace: quantised GEMM operand [T][width] (the e4m3 MLP hidden
+                                                         // [T][mlp_dim] lives in the bf16 `hid` buffer)
   float* sa8 = nullptr;                                  //            its per-token scales [T]
   int ws_precision = -1;
   // workspace (sized for `chunk` crops)
@@ -181,7 +184,7 @@ int ensure_workspace(clipenc_s* e, int n_crops) {
   const size_t Tp = align_up(T, 256);
   const size_t o_s0 = take(Tp * 8), o_sa = take(parts * Tp * 8), o_sb = take(parts * Tp * 8);
   const bool f8 = e->precision == CLIPENC_PREC_FP8;
-  const size_t o_a8 = f8 ? take(T * (size_t)std::max(g.width, g.mlp_dim)) : 0, o_sa8 = f8 ? take(T * 4) : 0;
+  const size_t o_a8 = f8 ? take(T * (size_t)g.width) : 0, o_sa8 = f8 ? take(T * 4) : 0;
   HIP_TRY(hipSetDevice(e->device));
   HIP_TRY(e->ws.alloc(off));
   char* b = (char*)e->ws.p;
@@ -220,14 +223,16 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     // per block: quantise the (normalised) GEMM operand row by row, run the e4m3 GEMM, scales + bias (+ act / residual)
     // in its epilogue.  LayerNorm: gamma sits in the fp8 weights, beta in the bias (as for bf16); the statistics are
     // computed by the quantiser itself.
-    const size_t D = g.width, Mh = g.mlp_dim;
-    auto gemm8 = [&](const uint8_t* W8, const float* sw, const float* bias, int N, int K, int act, bf16_t* out, bool resid,
-                     int kind, int sub) -> hipError_t {
+    const size_t D = g.width;
+    uint8_t* h8 = (uint8_t*)e->hid;
+    // A8: operand rows (per-token scales sa, or NULL when its columns carry static scales folded into W8)
+    auto gemm8 = [&](const uint8_t* A8, const float* sa, const uint8_t* W8, const float* sw, const float* bias, int N, int K,
+                     int act, void* out, int epi, const float* out_inv, int kind, int sub) -> hipError_t {
       GemmParams q{};
-      q.A = e->a8; q.lda = K; q.W = W8; q.ldw = K; q.M = T; q.N = N; q.K = K; q.out = out; q.ldo = N; q.bias = bias;
-      q.scale_a = e->sa8; q.scale_w = sw; q.act = act; q.resid = resid ? out : nullptr;
+      q.A = A8; q.lda = K; q.W = W8; q.ldw = K; q.M = T; q.N = N; q.K = K; q.out = out; q.ldo = N; q.bias = bias;
+      q.scale_a = sa; q.scale_w = sw; q.act = act; q.resid = epi == EPI_RESID ? out : nullptr; q.out_inv_scale = out_inv;
       pf.begin(kind, 2.0 * dT * (double)N * (double)K, st, sub);
-      hipError_t err = ce_gemm_fp8(q, resid ? EPI_RESID : EPI_STORE_BF16, st);
+      hipError_t err = ce_gemm_fp8(q, epi, st);
       pf.end(st);
       return err;
     };
@@ -241,16 +246,16 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       const LayerDev& L = e->layers[l];
       const LayerDev8& Q = e->layers8[l];
       HIP_TRY(quant(e->x, D, 1));
-      HIP_TRY(gemm8(Q.w_qkv, Q.s_qkv, L.b_qkv, 3 * g.width, g.width, -1, e->qkv, false, PK_GEMM8_QKV, -1));
+      HIP_TRY(gemm8(e->a8, e->sa8, Q.w_qkv, Q.s_qkv, L.b_qkv, 3 * g.width, g.width, -1, e->qkv, EPI_STORE_BF16, nullptr, PK_GEMM8_QKV, -1));
       pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * e->tokens * dD, st);
-      HIP_TRY(ce_attention(e->qkv, e->attn, c, e->tokens, g.width, g.heads, st));
+      // attention writes O as e4m3 directly (static per-channel scale from the V rows of w_qkv, folded into w_out)
+      HIP_TRY(ce_attention(e->qkv, e->a8, c, e->tokens, g.width, g.heads, Q.is_attn, st));
       pf.end(st);
-      HIP_TRY(quant(e->attn, D, 0));
-      HIP_TRY(gemm8(Q.w_out, Q.s_out, L.b_out, g.width, g.width, -1, e->x, true, PK_GEMM8_RESID, PK_SUB8_OUT));
+      HIP_TRY(gemm8(e->a8, nullptr, Q.w_out, Q.s_out, L.b_out, g.width, g.width, -1, e->x, EPI_RESID, nullptr, PK_GEMM8_RESID, PK_SUB8_OUT));
       HIP_TRY(quant(e->x, D, 1));
-      HIP_TRY(gemm8(Q.w_fc, Q.s_fc, L.b_fc, g.mlp_dim, g.width, g.act, e->hid, false, PK_GEMM8_FC1, -1));
-      HIP_TRY(quant(e->hid, Mh, 0));
-      HIP_TRY(gemm8(Q.w_proj, Q.s_proj, L.b_proj, g.width, g.mlp_dim, -1, e->x, true, PK_GEMM8_RESID, PK_SUB8_FC2));
+      // FC1 writes the hidden activations as e4m3 directly (static per-column scale, folded into w_proj): no bf16 round trip
+      HIP_TRY(gemm8(e->a8, e->sa8, Q.w_fc, Q.s_fc, L.b_fc, g.mlp_dim, g.width, g.act, h8, EPI_STORE_FP8, Q.is_hid, PK_GEMM8_FC1, -1));
+      HIP_TRY(gemm8(h8, nullptr, Q.w_proj, Q.s_proj, L.b_proj, g.width, g.mlp_dim, -1, e->x, EPI_RESID, nullptr, PK_GEMM8_RESID, PK_SUB8_FC2));
     }
     return 0;
   }
@@ -266,7 +271,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     pf.end(st);
     // K4
     pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * e->tokens * dD, st);
-    HIP_TRY(ce_attention(e->qkv, e->attn, c, e->tokens, g.width, g.heads, st));
+    HIP_TRY(ce_attention(e->qkv, e->attn, c, e->tokens, g.width, g.heads, nullptr, st));
     pf.end(st);
     // K5: x += attn . Wo^T + bo
     GemmParams o{};
@@ -443,12 +448,20 @@ int clipenc_set_precision(clipenc_t e, int precision) {
     const size_t D = g.width, M = g.mlp_dim;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
-    struct LOff { size_t w[4], s[4]; };
+    struct LOff { size_t w[4], s[4], is_hid, is_attn; };
     std::vector<LOff> lo(g.layers);
     const size_t rows[4] = {3 * D, D, M, D}, cols[4] = {D, D, D, M};
-    for (auto& o : lo)
+    for (auto& o : lo) {
       for (int i = 0; i < 4; ++i) { o.w[i] = take(rows[i] * cols[i]); o.s[i] = take(rows[i] * 4); }
+      o.is_hid = take(M * 4); o.is_attn = take(D * 4);
+    }
     HIP_TRY(e->weights8.alloc(off));
+    DevBuf tmp;                                            // [mlp_dim] static scales + fp32 [width][mlp_dim] folded w_proj
+    const size_t o_fold = align_up(std::max(M, D) * 4, 256);
+    struct Guard { DevBuf& b; ~Guard() { b.release(); } } tmp_guard{tmp};
+    HIP_TRY(tmp.alloc(o_fold + D * std::max(M, D) * 4));
+    float* s_hid = (float*)tmp.p;
+    float* folded = (float*)((char*)tmp.p + o_fold);
     char* db = (char*)e->weights8.p;
     std::vector<LayerDev8> l8(g.layers);
     for (int l = 0; l < g.layers; ++l) {
@@ -461,8 +474,18 @@ int clipenc_set_precision(clipenc_t e, int precision) {
       const bf16_t* src[4] = {L.w_qkv, L.w_out, L.w_fc, L.w_proj};   // (gamma already folded into w_qkv / w_fc)
       uint8_t* dst[4] = {Q.w_qkv, Q.w_out, Q.w_fc, Q.w_proj};
       float* sc[4] = {Q.s_qkv, Q.s_out, Q.s_fc, Q.s_proj};
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 3; i += 2)
         HIP_TRY(ce_quant_rows_fp8(src[i], 0, cols[i], dst[i], cols[i], sc[i], (int)rows[i], (int)cols[i], 0, 0.f, nullptr));
+      // attention output: a softmax-weighted mean of V rows, so the bound of the V third of the LN-folded w_qkv holds for it
+      Q.is_attn = (float*)(db + lo[l].is_attn);
+      HIP_TRY(ce_static_scale(L.w_qkv + 2 * D * D, L.b_qkv + 2 * D, (int)D, (int)D, s_hid, Q.is_attn, nullptr));
+      HIP_TRY(ce_scale_cols(L.w_out, s_hid, folded, (int)D, (int)D, nullptr));
+      HIP_TRY(ce_quant_rows_fp8(folded, 1, D, Q.w_out, D, Q.s_out, (int)D, (int)D, 0, 0.f, nullptr));
+      // MLP hidden: static column scales from the LN-folded FC1 rows; their product with w_proj's columns is what gets quantised
+      Q.is_hid = (float*)(db + lo[l].is_hid);
+      HIP_TRY(ce_static_scale(L.w_fc, L.b_fc, (int)M, (int)D, s_hid, Q.is_hid, nullptr));
+      HIP_TRY(ce_scale_cols(L.w_proj, s_hid, folded, (int)D, (int)M, nullptr));
+      HIP_TRY(ce_quant_rows_fp8(folded, 1, M, Q.w_proj, M, Q.s_proj, (int)D, (int)M, 0, 0.f, nullptr));
     }
     HIP_TRY(hipStreamSynchronize(nullptr));
     e->layers8.swap(l8);
@@ -530,7 +553,7 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
   if (name) {
     *name = kProfileNames[kind];
     if (e->cfg.act == CLIPENC_ACT_GELU_ERF && kind == PK_GEMM_FC1) *name = "gemm_persist_kernel<2, 1>";
-    if (e->cfg.act == CLIPENC_ACT_GELU_ERF && kind == PK_GEMM8_FC1) *name = "gemm_fp8_kernel<0, 1>";
+    if (e->cfg.act == CLIPENC_ACT_GELU_ERF && kind == PK_GEMM8_FC1) *name = "gemm_fp8_kernel<2, 1>";
   }
   if (total_ms) *total_ms = e->prof.ms[kind];
   if (launches) *launches = e->prof.launches[kind];
@@ -687,6 +710,17 @@ int clipenc_op_gemm_fp8(const void* a8_dev, const void* w8_dev, int m, int n, in
   return 0;
 }
 
+int clipenc_op_gemm_fp8_q(const void* a8_dev, const void* w8_dev, int m, int n, int k, const float* scale_a_dev,
+                          const float* scale_w_dev, const float* bias_dev, int act, const float* out_inv_scale_dev,
+                          void* out8_dev, void* stream) {
+  GemmParams p{};
+  p.A = a8_dev; p.lda = k; p.W = w8_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out8_dev; p.ldo = n; p.bias = bias_dev;
+  p.scale_a = scale_a_dev; p.scale_w = scale_w_dev; p.act = act; p.out_inv_scale = out_inv_scale_dev;
+  hipError_t err = ce_gemm_fp8(p, EPI_STORE_FP8, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("gemm_fp8_q(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
+  return 0;
+}
+
 int preproc_create(int device, preproc_t* out) {
   if (!out) return fail("preproc_create: NULL argument");
   int ndev = 0;
@@ -740,8 +774,16 @@ int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n
 }
 
 int clipenc_op_attention(const void* qkv_dev, void* out_dev, int n_crops, int n_tok, int width, int heads, void* stream) {
-  hipError_t err = ce_attention(qkv_dev, out_dev, n_crops, n_tok, width, heads, (hipStream_t)stream);
+  hipError_t err = ce_attention(qkv_dev, out_dev, n_crops, n_tok, width, heads, nullptr, (hipStream_t)stream);
   if (err != hipSuccess) return fail("attention(%d crops, %d tok) failed: %s", n_crops, n_tok, hipGetErrorString(err));
+  return 0;
+}
+
+int clipenc_op_attention_q(const void* qkv_dev, void* out8_dev, int n_crops, int n_tok, int width, int heads,
+                           const float* out_inv_scale_dev, void* stream) {
+  if (!out_inv_scale_dev) return fail("attention_q: NULL out_inv_scale");
+  hipError_t err = ce_attention(qkv_dev, out8_dev, n_crops, n_tok, width, heads, out_inv_scale_dev, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("attention_q(%d crops, %d tok) failed: %s", n_crops, n_tok, hipGetErrorString(err));
   return 0;
 }
 

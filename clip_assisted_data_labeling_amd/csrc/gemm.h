@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 
 enum { CE_DT_BF16 = 0, CE_DT_F16 = 1 };
-enum { EPI_STORE_F32 = 0, EPI_STORE_BF16 = 1, EPI_LNFOLD = 2, EPI_RESID = 3, EPI_THRESH = 4 };
+enum { EPI_STORE_F32 = 0, EPI_STORE_BF16 = 1, EPI_LNFOLD = 2, EPI_RESID = 3, EPI_THRESH = 4, EPI_STORE_FP8 = 5 };
 
 struct GemmParams {
   const void* A; int lda;        // [M][lda] 16-bit elements, K-contiguous
@@ -28,11 +28,12 @@ struct GemmParams {
   unsigned long long cap;
   unsigned long long* count;
   // fp8 path (gemm_fp8.hip): out = acc * scale_a[m] * scale_w[n] + bias[n]
-  const float* scale_a;          // [M] per-token activation scale
+  const float* scale_a;          // [M] per-token activation scale (NULL: 1)
   const float* scale_w;          // [N] per-output-channel weight scale
+  const float* out_inv_scale;    // [N] EPI_STORE_FP8: out8[m][n] = e4m3(value * out_inv_scale[n])  (static per-column scale)
   unsigned long long* dbg;       // optional [tiles][8] timing stamps (diagnostic entry point only)
 };
 
 hipError_t ce_gemm_nt(const GemmParams& p, int dtype, int epi, hipStream_t stream);
-hipError_t ce_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);           // fp8 e4m3 operands; EPI_STORE_BF16 / EPI_RESID
+hipError_t ce_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);           // fp8 e4m3 operands; EPI_STORE_BF16 / EPI_RESID / EPI_STORE_FP8
 hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream);   // bf16; EPI_STORE_BF16 / LNFOLD / RESID

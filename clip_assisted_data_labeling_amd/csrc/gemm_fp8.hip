@@ -52,7 +52,8 @@ __device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n)
   return TileId{tm * BM, tn * BN};
 }
 
-// EPI: 0 = scale + bias (+ activation) -> bf16;  1 = scale + bias + residual (bf16, in place) -> bf16
+// EPI: 0 = scale + bias (+ activation) -> bf16;  1 = scale + bias + residual (bf16, in place) -> bf16;
+//      2 = scale + bias (+ activation), then * out_inv_scale[n] -> e4m3 (the next GEMM's operand, no bf16 round trip)
 template <int EPI, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     // pass 1 (keeps registers low): acc <- acc * sw[n] + bias[n] / sa[m], so that pass 2 only multiplies by sa[m]
     float sa[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) sa[mt] = p.scale_a[min(mw0 + mt * 32 + r32, p.M - 1)];
+    for (int mt = 0; mt < 4; ++mt) sa[mt] = p.scale_a ? p.scale_a[min(mw0 + mt * 32 + r32, p.M - 1)] : 1.0f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const int n = nb + (c >> 2) * 32 + (c & 3) * 8 + h * 4;
@@ -229,6 +230,39 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       for (int k = 0; k < 4; ++k) LOAD_RES(k);
     }
 
+    if constexpr (EPI == 2) {
+      // fp8 image: [32 rows][80 B pitch] per wave (64 data bytes; the pitch keeps the dword writes 2-way conflicted at most),
+      // the wave's 64 inverse output scales behind it
+      float* isc = (float*)(tr + 2560);
+      isc[lane] = p.out_inv_scale[nb + lane];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int nt = c >> 2, g = c & 3;
+          const int col = nt * 32 + g * 8 + h * 4;
+          const f32x4_t is = *(const f32x4_t*)(isc + col);
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            v[e] = __builtin_amdgcn_fmed3f(act_apply_t<ACT>(acc[mt][nt][g * 4 + e] * sa[mt]) * is[e], -448.0f, 448.0f);
+          int wd = 0;
+          wd = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], wd, false);
+          wd = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], wd, true);
+          *(int*)(tr + r32 * 80 + col) = wd;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int row = k * 16 + (lane >> 2);
+          const uint4 v = *(const uint4*)(tr + row * 80 + (lane & 3) * 16);
+          const int m = mw0 + mt * 32 + row;
+          if (m < p.M) *(uint4*)((char*)p.out + (size_t)m * p.ldo + nb + (lane & 3) * 16) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+    } else {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
       if constexpr (EPI == 1) {
@@ -270,6 +304,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // image reads done before the next block's writes
     }
+    }
 #undef LOAD_RES
 
     if (!has_next) {
@@ -306,16 +341,23 @@ hipError_t launch_fp8(const GemmParams& p, hipStream_t stream) {
 }  // namespace
 
 // A: fp8 [M][lda] (bytes), W: fp8 [N][ldw]; out bf16 [M][ldo]; scale_a [M], scale_w [N], bias [N] fp32.
-// epi: EPI_STORE_BF16 (scale + bias + p.act) or EPI_RESID (scale + bias + bf16 residual, may alias out).
+// epi: EPI_STORE_BF16 (scale + bias + p.act), EPI_RESID (scale + bias + bf16 residual, may alias out) or
+// EPI_STORE_FP8 (as STORE_BF16, then e4m3(value * out_inv_scale[n]) into out [M][ldo] BYTES).  scale_a NULL = 1.
 hipError_t ce_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream) {
   if (p.M < 1 || p.N < BN || p.N % BN != 0 || p.K < 256 || p.K % 256 != 0) return hipErrorInvalidValue;
   if (p.lda % 16 != 0 || p.ldw % 16 != 0 || p.lda < p.K || p.ldw < p.K) return hipErrorInvalidValue;
   if (((uintptr_t)p.A | (uintptr_t)p.W | (uintptr_t)p.out) & 15) return hipErrorInvalidValue;
-  if (!p.out || !p.scale_a || !p.scale_w || !p.bias) return hipErrorInvalidValue;
+  if (!p.out || !p.scale_w || !p.bias) return hipErrorInvalidValue;
   if ((size_t)255 * p.lda + 64 >= 0x7fffffffull || (size_t)255 * p.ldw + 64 >= 0x7fffffffull) return hipErrorInvalidValue;
   if (epi == EPI_RESID) {
     if (!p.resid) return hipErrorInvalidValue;
     return launch_fp8<1, -1>(p, stream);
+  }
+  if (epi == EPI_STORE_FP8) {
+    if (!p.out_inv_scale) return hipErrorInvalidValue;
+    if (p.act == CE_ACT_QUICK_GELU) return launch_fp8<2, CE_ACT_QUICK_GELU>(p, stream);
+    if (p.act == CE_ACT_GELU_ERF) return launch_fp8<2, CE_ACT_GELU_ERF>(p, stream);
+    return launch_fp8<2, -1>(p, stream);
   }
   if (epi != EPI_STORE_BF16) return hipErrorInvalidValue;
   if (p.act == CE_ACT_QUICK_GELU) return launch_fp8<0, CE_ACT_QUICK_GELU>(p, stream);

@@ -4,7 +4,8 @@
 #include <stdint.h>
 
 // attention.hip
-hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int width, int heads, hipStream_t stream);
+hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int width, int heads, const float* out_inv,
+                        hipStream_t stream);   // out_inv != NULL: out is e4m3 [T][width] = fp8(O * out_inv[c])
 
 // elementwise.hip
 hipError_t ce_patchify(const void* crops, int in_dtype, void* a_patch, int n_crops, int image, int patch, int kpad,
@@ -18,6 +19,8 @@ hipError_t ce_head(const void* x, const float* gamma, const float* beta, const f
 // quant_fp8.hip
 hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out8, size_t ld_out, float* scale, int n_rows,
                              int K, int ln, float eps, hipStream_t stream);
+hipError_t ce_static_scale(const void* W_bf16, const float* bias, int N, int K, float* s, float* inv_s, hipStream_t stream);
+hipError_t ce_scale_cols(const void* W_bf16, const float* s, float* out_f32, int N, int K, hipStream_t stream);
 
 // fcreg.hip
 #define CE_FC_MAX_LAYERS 8

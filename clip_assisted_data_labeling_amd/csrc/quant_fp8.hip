@@ -99,7 +99,60 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const TIN* __restrict__
   if (lane == 0) scale[row] = sc;
 }
 
+// Static (data-free) output scale of a LayerNorm-fed linear layer, from the Cauchy-Schwarz bound
+//   |LN(x) . w'_n + b'_n| <= sqrt(K) * ||w'_n||_2 + |b'_n|      (||LN(x) without affine||_2 <= sqrt(K))
+// widened by 1.07 for the e4m3 rounding of both operands and by a 1.2 margin:  s[n] = bound / 448 * 1.2, inv_s = 1/s.
+// |act(u)| <= |u| for both GELUs, and a softmax-weighted mean of such values obeys the same bound, so
+// e4m3(value * inv_s[n]) can never overflow.  One wave per row.
+__global__ __launch_bounds__(256) void static_scale_kernel(const bf16_t* __restrict__ W, const float* __restrict__ bias, int N,
+                                                           int K, float* __restrict__ s, float* __restrict__ inv_s) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float ss = 0.f;
+  for (int c = lane * 8; c < K; c += 512) {
+    float v[8];
+    load8<bf16_t>(W + (size_t)n * K + c, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ss += v[j] * v[j];
+  }
+  ss = wave_sum(ss);
+  if (lane == 0) {
+    const float bound = 1.2f * (1.07f * sqrtf((float)K) * sqrtf(ss) + fabsf(bias[n])) * (1.0f / 448.0f);
+    const float sc = bound > 1e-30f ? bound : 1.0f;
+    s[n] = sc;
+    inv_s[n] = 1.0f / sc;
+  }
+}
+
+// out[n][k] = W[n][k] * s[k]  (fp32): the static scale of the operand's columns folded into the consuming weight
+__global__ __launch_bounds__(256) void scale_cols_kernel(const bf16_t* __restrict__ W, const float* __restrict__ s,
+                                                         float* __restrict__ out, size_t total, int K) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+  if (i >= total) return;
+  float v[8];
+  load8<bf16_t>(W + i, v);
+  const int k = (int)(i % (size_t)K);
+  const float4 s0 = *(const float4*)(s + k), s1 = *(const float4*)(s + k + 4);
+  *(float4*)(out + i) = float4{v[0] * s0.x, v[1] * s0.y, v[2] * s0.z, v[3] * s0.w};
+  *(float4*)(out + i + 4) = float4{v[4] * s1.x, v[5] * s1.y, v[6] * s1.z, v[7] * s1.w};
+}
+
 }  // namespace
+
+hipError_t ce_static_scale(const void* W_bf16, const float* bias, int N, int K, float* s, float* inv_s, hipStream_t stream) {
+  if (N < 1 || K < 8 || K % 8 != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(static_scale_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const bf16_t*)W_bf16, bias, N, K, s, inv_s);
+  return hipGetLastError();
+}
+
+hipError_t ce_scale_cols(const void* W_bf16, const float* s, float* out_f32, int N, int K, hipStream_t stream) {
+  if (N < 1 || K < 8 || K % 8 != 0) return hipErrorInvalidValue;
+  const size_t total = (size_t)N * K;
+  hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)W_bf16, s,
+                     out_f32, total, K);
+  return hipGetLastError();
+}
 
 // in: bf16 (in_f32 == 0) or fp32 rows of K elements (K % 8 == 0, K <= 4096); ln != 0 normalises each row first.
 hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out8, size_t ld_out, float* scale, int n_rows,

@@ -165,6 +165,12 @@ int clipenc_op_quant_rows_fp8(const void* in_dev, int in_f32, int n_rows, int k,
 int clipenc_op_gemm_fp8(const void* a8_dev, const void* w8_dev, int m, int n, int k, const float* scale_a_dev,
                         const float* scale_w_dev, const float* bias_dev, int act, const void* resid_dev, void* out_dev,
                         void* stream);
+/* Same product, stored as e4m3: out8[M][N] = fp8(act(... + bias[N]) * out_inv_scale[N]) — how FC1 hands the MLP hidden
+ * activations to FC2 in CLIPENC_PREC_FP8 (static per-column scale, folded into FC2's weight columns).  scale_a_dev may be
+ * NULL (= 1) here and in clipenc_op_gemm_fp8. */
+int clipenc_op_gemm_fp8_q(const void* a8_dev, const void* w8_dev, int m, int n, int k, const float* scale_a_dev,
+                          const float* scale_w_dev, const float* bias_dev, int act, const float* out_inv_scale_dev,
+                          void* out8_dev, void* stream);
 /* Diagnostic: bf16-store GEMM that also writes, per workgroup, 100 MHz timestamps
  * {entry, prologue done, main loop done, stores issued, stores retired, hw id} into stamps_dev[tiles][8]. */
 int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n, int k, void* out_dev,
@@ -172,6 +178,9 @@ int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n
 /* qkv bf16 [n_crops*n_tok][3*width] -> out bf16 [n_crops*n_tok][width]; head dim 64, n_tok <= 640 */
 int clipenc_op_attention(const void* qkv_dev, void* out_dev, int n_crops, int n_tok, int width, int heads,
                          void* stream);
+/* Same, stored as e4m3 with a static per-channel scale: out8[t][c] = fp8(O[t][c] * out_inv_scale[c]) (CLIPENC_PREC_FP8) */
+int clipenc_op_attention_q(const void* qkv_dev, void* out8_dev, int n_crops, int n_tok, int width, int heads,
+                           const float* out_inv_scale_dev, void* stream);
 /* Residual stream after `layer` blocks (layer = 0: after ln_pre) of the LAST clipenc_encode chunk:
  * copies bf16 [n_rows][width] from the handle's workspace into out_dev (test hook). */
 int clipenc_debug_run_layers(clipenc_t enc, const void* crops_dev, int n_crops, int in_dtype, int n_layers,

@@ -141,6 +141,30 @@ def test_gemm_fp8_activation_and_residual(gpu, act):
     assert ((out - ref).abs() <= ref.abs() * 2.0 ** -8 * 1.001 + 1e-5 + acc_tol).all()
 
 
+@pytest.mark.parametrize("m,n,k,act", [(771, 512, 256, 0), (300, 256, 1024, 1), (2056, 1024, 512, -1)])
+def test_gemm_fp8_e4m3_output_with_static_column_scales(gpu, m, n, k, act):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(m + act)
+    a8, sa = _rand8(m, k, g)
+    w8, sw = _rand8(n, k, g)
+    bias = torch.randn(n, generator=g)
+    lin = (_deq(a8).double() @ _deq(w8).double().t()) * sa.double().view(m, 1) * sw.double().view(1, n) + bias.double()
+    val = lin * torch.sigmoid(1.702 * lin) if act == 0 else (torch.nn.functional.gelu(lin) if act == 1 else lin)
+    inv_s = (448.0 / (val.abs().amax(0) * torch.linspace(0.5, 40.0, n, dtype=torch.float64))).float()   # some columns saturate
+    out = torch.full((m, n), 0x7f, dtype=torch.uint8, device=gpu)
+    dev = [t.to(gpu) for t in (a8, w8, sa, sw, bias, inv_s)]                  # keep the device copies alive across the call
+    _lib.check(lib.clipenc_op_gemm_fp8_q(dev[0].data_ptr(), dev[1].data_ptr(), m, n, k, dev[2].data_ptr(), dev[3].data_ptr(),
+                                         dev[4].data_ptr(), act, dev[5].data_ptr(), out.data_ptr(), _stream(gpu)), "gemm_fp8_q")
+    torch.cuda.synchronize()
+    got = _deq(out.cpu()).double()
+    assert not torch.isnan(got).any()
+    want = (val * inv_s.double()).clamp(-448, 448)
+    # e4m3 rounding: half an ulp = 2^-4 relative for normals, 2^-10 absolute below 2^-6; plus the fp32/MFMA noise upstream
+    tol = want.abs() * 2.0 ** -4 * 1.02 + 2.0 ** -10 * 1.02 + 1e-4 * inv_s.double() * (k ** 0.5)
+    assert ((got - want).abs() <= tol).all()
+    assert (got.abs().amax(0)[: n // 100 + 1] == 448.0).all()                  # the columns scaled past 448 saturate, no NaN
+
+
 def test_gemm_fp8_rejects_bad_shapes(gpu):
     lib = _lib.load()
     z = torch.zeros(1 << 20, dtype=torch.uint8, device=gpu)
@@ -152,6 +176,30 @@ def test_gemm_fp8_rejects_bad_shapes(gpu):
     rc = lib.clipenc_op_gemm_fp8(z.data_ptr(), z.data_ptr(), 256, 256, 256, f.data_ptr(), f.data_ptr(), f.data_ptr(), 0,
                                  z.data_ptr(), z.data_ptr(), _stream(gpu))
     assert rc != 0                                                           # activation + residual
+
+
+# ------------------------------------------------------------------------------------------ attention with e4m3 output
+@pytest.mark.parametrize("n_crops,n_tok,heads", [(2, 50, 12), (3, 257, 16), (8, 257, 16), (20, 250, 4), (2, 577, 16)])
+def test_attention_e4m3_output_with_static_channel_scales(gpu, n_crops, n_tok, heads):
+    lib = _lib.load()
+    width = heads * 64
+    g = torch.Generator().manual_seed(n_tok + heads)
+    qkv = (torch.randn(n_crops * n_tok, 3 * width, generator=g) * 1.5).to(torch.bfloat16)
+    q, k, v = qkv.float().view(n_crops, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(n_crops * n_tok, width)
+    inv_s = (448.0 / (ref.abs().amax(0) * torch.linspace(0.8, 30.0, width))).float()      # the first channels saturate
+    out = torch.full((n_crops * n_tok, width), 0x7f, dtype=torch.uint8, device=gpu)
+    qkv_dev, inv_dev = qkv.to(gpu), inv_s.to(gpu)
+    _lib.check(lib.clipenc_op_attention_q(qkv_dev.data_ptr(), out.data_ptr(), n_crops, n_tok, width, heads, inv_dev.data_ptr(),
+                                          _stream(gpu)), "attention_q")
+    torch.cuda.synchronize()
+    got = _deq(out.cpu())
+    assert not torch.isnan(got).any()
+    want = (ref * inv_s).clamp(-448, 448)
+    # e4m3 rounding (2^-4 relative / 2^-10 absolute) on top of the bf16-P attention error (0.03 absolute before scaling)
+    tol = want.abs() * 2.0 ** -4 * 1.02 + 2.0 ** -10 * 1.02 + 0.03 * inv_s
+    assert ((got - want).abs() <= tol).all()
+    assert one_minus_cos(got / inv_s, ref.clamp(-448 / inv_s, 448 / inv_s)).max().item() < 2e-3
 
 
 # ------------------------------------------------------------------------------------------ encoder in fp8

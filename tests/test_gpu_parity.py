@@ -94,7 +94,8 @@ def test_attention_matches_fp32_reference(gpu, n_crops, n_tok, heads):
     g = torch.Generator().manual_seed(n_tok)
     qkv = (torch.randn(n_crops * n_tok, 3 * width, generator=g) * 1.5).to(torch.bfloat16)
     out = torch.full((n_crops * n_tok, width), float("nan"), dtype=torch.bfloat16, device=gpu)
-    _lib.check(lib.clipenc_op_attention(qkv.to(gpu).data_ptr(), out.data_ptr(), n_crops, n_tok, width, heads, _stream(gpu)),
+    qkv_dev = qkv.to(gpu)
+    _lib.check(lib.clipenc_op_attention(qkv_dev.data_ptr(), out.data_ptr(), n_crops, n_tok, width, heads, _stream(gpu)),
                "attention")
     torch.cuda.synchronize()
     q, k, v = qkv.float().view(n_crops, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
