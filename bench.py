@@ -79,13 +79,13 @@ def pmc_traffic(kernel_name):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_traffic_per_kernel.json")))
     if not files:
         return None
-    try:
-        table = json.load(open(files[-1]))
-        for k, v in table.items():
-            if kernel_name in k:
-                return round(float(v.get("bytes_per_launch", v.get("hbm_bytes", 0.0))), 1)
-    except Exception:
-        return None
+    for path in reversed(files):                      # newest round first; bf16 and fp8 runs are summarised separately
+        try:
+            for k, v in json.load(open(path)).items():
+                if kernel_name in k:
+                    return round(float(v.get("bytes_per_launch", v.get("hbm_bytes", 0.0))), 1)
+        except Exception:
+            continue
     return None
 
 

@@ -11,7 +11,7 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_long, c_longlong, c_size_t, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libclipenc_hip.so")
+LIB_PATH = os.environ.get("CLIPENC_LIB_PATH", os.path.join(_HERE, "libclipenc_hip.so"))   # env: developer A/B builds
 
 c_float_p = POINTER(c_float)
 c_float_pp = POINTER(c_float_p)
