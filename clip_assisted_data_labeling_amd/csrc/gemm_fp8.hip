@@ -33,8 +33,14 @@ __device__ __forceinline__ float act_apply_t(float u) {
   else return u;
 }
 
+// One LDS-DMA piece: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to 1 KiB of LDS at lds_off.
+// Inline asm on purpose: behind the builtin, LLVM's waitcnt pass treats every later ds_read as possibly aliasing the
+// pieces in flight and puts `s_waitcnt vmcnt(0)` in front of the fragment reads of EVERY phase -- a full drain of the
+// prefetch ring twice per stage (it did so in this kernel; the ring's correctness is the hand-placed counted waits).
+// (m0 is written; nothing else in this file uses it.)
 __device__ __forceinline__ void glds16(const char* base, unsigned off, char* smem, int lds_off) {
-  __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + off), LDS_PTR(lds_off), 16, 0, 0);
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(lds_off));
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_addr) : "memory");
 }
 
 struct TileId { int m0, n0; };
