@@ -161,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     frag_t fa[4], fb[4];
 
-    if (p.dbg && tid == 0) p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+    if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 4] = __builtin_amdgcn_s_memtime(); }
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
     for (int kb = 0; kb < kend - 256; kb += 256) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       STAGE(3, STAGE_W(1, Wnext, 64), STAGE_A(2, Anext, naoff0, naoff1, 128), 6);
     }
     if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
-    if (p.dbg && tid == 0) p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+    if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 5] = __builtin_amdgcn_s_memtime(); }
 
     // ------------------------------- epilogue of tile `cur` -------------------------------
     const int q4 = qd * 4;

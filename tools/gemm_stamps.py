@@ -7,12 +7,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from clip_assisted_data_labeling_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda", 0); st = _lib.current_stream_ptr(dev)
 M = 131584
-for (N, K) in ((1024, 1024), (1024, 4096), (4096, 1024)):
-    a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = torch.randn(N, K, device=dev).to(torch.bfloat16)
+for (N, K, kind) in ((1024, 1024, "random"), (1024, 4096, "random"), (4096, 1024, "random"), (1024, 4096, "zeros")):
+    if kind == "random":
+        a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = torch.randn(N, K, device=dev).to(torch.bfloat16)
+    else:
+        a = torch.zeros(M, K, device=dev, dtype=torch.bfloat16); w = torch.zeros(N, K, device=dev, dtype=torch.bfloat16)
     o = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
     tiles = ((M + 255) // 256) * (N // 256)
     stamps = torch.zeros(tiles, 8, dtype=torch.int64, device=dev)
-    for _ in range(3):
+    for _ in range(40):                              # long enough for the clock to settle under this load
         lib.clipenc_op_gemm_nt_stamps(a.data_ptr(), w.data_ptr(), M, N, K, o.data_ptr(), stamps.data_ptr(), st)
     torch.cuda.synchronize()
     s = stamps.cpu().numpy().astype(np.int64)
@@ -30,6 +33,9 @@ for (N, K) in ((1024, 1024), (1024, 4096), (4096, 1024)):
         gaps += [v[i + 1][0] - v[i][2] for i in range(len(v) - 1)]
     span = t[:, 2].max() - t[:, 0].min()
     ideal = 2.0 * 256 * 256 * K / (2516.6e12 / 256) * 1e6
+    cyc = (s[:, 5] - s[:, 4]).astype(np.float64)       # shader cycles of the main loop (s_memtime)
+    ghz = np.median(cyc / np.maximum(main, 1e-9)) / 1e3
+    print(f"   [{kind}] main loop: {np.median(cyc) / (K / 32):.0f} shader cycles per K=32 stage (1024 = MFMA-bound) at {ghz:.2f} GHz")
     print(f"N={N} K={K}: {tiles} tiles on {len(per_wg)} WGs, span {span:.1f} us = {2.0*M*N*K/span/1e6:.0f} TF/s; per tile (median us): "
           f"main loop {np.median(main):.2f} (first tile of a WG {np.median(first_main):.2f}, later {np.median(later_main):.2f}; "
           f"MFMA-ideal {ideal:.2f})  epilogue until stores issued {np.median(epi):.2f}  stores->next main loop {np.median(gaps):.2f}")
