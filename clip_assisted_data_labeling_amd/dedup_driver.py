@@ -19,7 +19,30 @@ import torch
 from . import _lib
 
 
+def _packed_paths_and_embeddings(args, crop_to_use):
+    """Same chunks as below, read from the packed shards (embed_driver --packed_store): one gather per sub-directory."""
+    from .packed_store import PackedStore, image_key
+    store = PackedStore(args.packed_store)
+    if args.clip_model_to_use is None:
+        args.clip_model_to_use = store.models()[0]
+        print(f"\n ----> args.clip_model_to_use was not specified, defaulting to first found one: {args.clip_model_to_use} \n")
+    keys, data, crop_names = store.load(args.clip_model_to_use)
+    pos = {k: i for i, k in enumerate(keys)}
+    c = crop_names.index(crop_to_use)
+    for subdir, _, files in os.walk(args.root_dir):
+        stems = sorted(os.path.splitext(f)[0] for f in files if f.endswith(".jpg"))
+        rows = [(s, pos.get(image_key(os.path.join(subdir, s), args.root_dir), -1)) for s in stems]
+        rows = [(s, r) for s, r in rows if r >= 0]
+        for b0 in range(0, len(rows), args.chunk_size):
+            part = rows[b0:b0 + args.chunk_size]
+            emb = torch.from_numpy(np.asarray(data[[r for _, r in part], c, :])).to(torch.float16)      # :38
+            yield [os.path.join(subdir, s + ".jpg") for s, _ in part], list(emb)
+
+
 def get_paths_and_embeddings(args, crop_to_use):
+    if getattr(args, "packed_store", None):
+        yield from _packed_paths_and_embeddings(args, crop_to_use)
+        return
     for subdir, _, files in os.walk(args.root_dir):
         stems = {}
         for f in files:
@@ -117,6 +140,8 @@ def main(argv=None):
     parser.add_argument("--clip_model_to_use", type=str, default=None, help="Which CLIP model to use, if None, use the first one found")
     parser.add_argument("--chunk_size", type=int, default=1000000, help="Images compared at once (the HIP kernel never builds the N x N matrix)")
     parser.add_argument("--test", action="store_true", help="Test the script without doing anything")
+    parser.add_argument("--packed_store", type=str, default=None,
+                        help="Read embeddings from the packed shards in this directory (written by embed_driver --packed_store)")
     find_near_duplicates(parser.parse_args(argv))
 
 

@@ -10,7 +10,9 @@ utils/image_features.py are not produced (never consumed: _4_train_model.py:274)
 
 Differences that matter for speed: the resume check happens BEFORE images are decoded, per image
 rather than per batch; with torch.distributed initialised, each rank embeds a contiguous shard of the
-sorted file list (clip_assisted_data_labeling_amd/sharding.py) on its own GPU.
+sorted file list (clip_assisted_data_labeling_amd/sharding.py) on its own GPU.  With `--packed_store DIR` the
+embeddings go to a few large append-only shards instead of one pickle per image (packed_store.py; `python -m
+clip_assisted_data_labeling_amd.packed_store export` recreates the per-image `.pt` files).
 """
 from __future__ import annotations
 
@@ -100,8 +102,9 @@ def already_embedded(feature_path: str, model_name: str) -> bool:
 class Feature_Dataset:
     def __init__(self, root_dir, model_name, batch_size, model_path=None, force_reencode=False,
                  shuffle_filenames=True, num_workers=0, crop_names=None, encoder=None, device="cuda",
-                 gpu_preprocess=False):
+                 gpu_preprocess=False, packed_store=None):
         self.device = device
+        self.packed_store = packed_store
         self.root_dir = root_dir
         self.model_name = model_name
         self.force_reencode = force_reencode
@@ -144,9 +147,18 @@ class Feature_Dataset:
         n_embedded, n_skipped, n_failed = 0, 0, 0
         print(f"Embedding dataset of {len(self.img_filepaths)} images using {self.model_name}...")
         todo = []
+        writer, done_keys = None, set()
+        if self.packed_store:
+            from .packed_store import PackedStore, PackedStoreWriter, image_key
+            if not self.force_reencode:
+                done_keys = PackedStore(self.packed_store).keys(self.model_name)
+            rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
         for p in self.img_filepaths:                       # resume check first: nothing is decoded for done images
-            fp = os.path.splitext(p)[0] + ".pt"
-            if not self.force_reencode and already_embedded(fp, self.model_name):
+            if self.packed_store:
+                done = image_key(p, self.root_dir) in done_keys
+            else:
+                done = not self.force_reencode and already_embedded(os.path.splitext(p)[0] + ".pt", self.model_name)
+            if done:
                 n_skipped += 1
             else:
                 todo.append(p)
@@ -165,6 +177,15 @@ class Feature_Dataset:
             counts = [b[0].shape[0] for b in ok]
             stacked = torch.cat([b[0] for b in ok], 0).to(self.device)      # [sum crops, 3, R, R], row = image-major
             features = self.encoder.encode_image(stacked).float().cpu()    # :130
+            if self.packed_store:                          # one sequential write per batch instead of one pickle per image
+                if any(n != len(self.crop_names) for n in counts):
+                    raise RuntimeError("packed store needs every image to carry all crops " + str(self.crop_names))
+                if writer is None:
+                    writer = PackedStoreWriter(self.packed_store, self.model_name, self.crop_names, features.shape[-1], rank)
+                writer.append([image_key(b[2], self.root_dir) for b in ok],
+                              features.view(len(ok), len(self.crop_names), features.shape[-1]))
+                n_embedded += len(ok)
+                continue
             row = 0
             for (crops, names, img_path, _), n in zip(ok, counts):
                 feature_save_path = os.path.splitext(img_path)[0] + ".pt"
@@ -184,6 +205,8 @@ class Feature_Dataset:
                 except Exception as e:
                     print(f"Error saving features to {feature_save_path}: {e}")
                 n_embedded += 1
+        if writer is not None:
+            writer.close()
         print("\n--- Feature encoding done! ---\n")
         print(f"Embedded {n_embedded} images ({n_skipped} images were already embedded, {n_failed} unreadable). "
               f"Features saved with model key '{self.model_name}'.")
@@ -201,6 +224,8 @@ def main(argv=None):
     parser.add_argument("--model_path", type=str, default=None, help="Local directory (or file) holding the model weights")
     parser.add_argument("--gpu_preprocess", action="store_true",
                         help="Workers only decode; crops, bicubic resize and normalise run on the GPU (bit-exact with Pillow)")
+    parser.add_argument("--packed_store", type=str, default=None,
+                        help="Write embeddings to packed shards in this directory instead of one .pt per image")
     args = parser.parse_args(argv)
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
@@ -211,7 +236,7 @@ def main(argv=None):
         print(f"\n--- Processing model: {model_name} ---")
         Feature_Dataset(args.root_dir, model_name, args.batch_size, model_path=args.model_path,
                         force_reencode=args.force_reencode, num_workers=args.num_workers, crop_names=CROP_NAMES,
-                        device=device, gpu_preprocess=args.gpu_preprocess).process()
+                        device=device, gpu_preprocess=args.gpu_preprocess, packed_store=args.packed_store).process()
 
 
 if __name__ == "__main__":

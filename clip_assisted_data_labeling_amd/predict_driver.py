@@ -83,15 +83,32 @@ def predict_labels(args, device="cuda"):
 
     n_predictions = 0
     rng = np.random
+    store = None
+    if getattr(args, "packed_store", None):                 # features from the packed shards: no per-image torch.load
+        from .packed_store import PackedStore, image_key
+        store = PackedStore(args.packed_store)
+        store_root = getattr(args, "store_root", None) or args.root_dir
     for b0 in range(0, len(img_files), args.batch_size):
         uuids, img_paths, feats = [], [], []
-        for uuid in img_files[b0:b0 + args.batch_size]:
-            try:
-                feats.append(assemble_features(os.path.join(args.root_dir, uuid + ".pt"), clip_models, model.crop_names))
-                uuids.append(uuid)
-                img_paths.append(os.path.join(args.root_dir, uuid + ".jpg"))
-            except Exception as e:                          # :84-86: skip the sample
-                print(f"WARNING: {str(e)} for {uuid}, skipping this sample..")
+        batch = img_files[b0:b0 + args.batch_size]
+        if store is not None:
+            keys = [image_key(os.path.join(args.root_dir, u), store_root) for u in batch]
+            found, mat = store.features(clip_models, model.crop_names, keys)
+            for u, ok in zip(batch, found):
+                if ok:
+                    uuids.append(u)
+                    img_paths.append(os.path.join(args.root_dir, u + ".jpg"))
+                else:
+                    print(f"WARNING: no packed embedding for {u}, skipping this sample..")
+            feats = list(torch.from_numpy(np.ascontiguousarray(mat)))
+        else:
+            for uuid in batch:
+                try:
+                    feats.append(assemble_features(os.path.join(args.root_dir, uuid + ".pt"), clip_models, model.crop_names))
+                    uuids.append(uuid)
+                    img_paths.append(os.path.join(args.root_dir, uuid + ".jpg"))
+                except Exception as e:                      # :84-86: skip the sample
+                    print(f"WARNING: {str(e)} for {uuid}, skipping this sample..")
         if not uuids:
             continue
         features = torch.stack(feats)
@@ -131,8 +148,11 @@ def main(argv=None):
     parser.add_argument("--copy_imgs_fraction", type=float, default=0.01,
                         help="Fraction of images to copy to the _predicted_scores directory with prepended prediction score")
     parser.add_argument("--num_workers", type=int, default=4, help="(kept for CLI compatibility)")
+    parser.add_argument("--packed_store", type=str, default=None,
+                        help="Read embeddings from the packed shards in this directory (written by embed_driver --packed_store)")
     args = parser.parse_args(argv)
     top = args.root_dir
+    args.store_root = top                                  # packed keys are relative to the top-level dataset root
     for root, _, files in os.walk(top):                    # :204-210
         if any(f.endswith(".jpg") for f in files) and "_predicted_scores" not in root:
             args.root_dir = root

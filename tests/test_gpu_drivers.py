@@ -103,6 +103,50 @@ def test_embed_predict_dedup_pipeline(gpu, tmp_path):
     assert any("_source_a000.jpg" in f for f in out) and any("_target_a008.pt" in f for f in out)
 
 
+def test_pipeline_through_packed_store_equals_pt_pipeline(gpu, tmp_path):
+    """embed --packed_store -> predict / dedup reading the shards == the per-image .pt pipeline, value for value."""
+    from clip_assisted_data_labeling_amd.packed_store import PackedStore, export_pt
+    root, root_pt = str(tmp_path / "imgs"), str(tmp_path / "ref" / "imgs")
+    _dataset(root, 9)
+    import shutil
+    os.makedirs(tmp_path / "ref")
+    shutil.copytree(root, root_pt)
+    sd = str(tmp_path / "store")
+    assert embed_driver.Feature_Dataset(root, MODEL, 4, shuffle_filenames=False, num_workers=0, device="cuda",
+                                        packed_store=sd).process() == (9, 0, 0)
+    assert embed_driver.Feature_Dataset(root_pt, MODEL, 4, shuffle_filenames=False, num_workers=0, device="cuda").process() == (9, 0, 0)
+    keys, data, crops = PackedStore(sd).load(MODEL)
+    assert sorted(keys) == [f"a{i:03d}" for i in range(9)] and crops == CROP_NAMES
+    for k, row in zip(keys, np.asarray(data)):
+        d = torch.load(os.path.join(root_pt, k + ".pt"), weights_only=True)[MODEL]
+        assert torch.equal(torch.from_numpy(row.copy()), torch.cat([d[c] for c in CROP_NAMES]))     # bitwise
+
+    cfg = vit_config.config_for(MODEL)
+    sizes = [2 * cfg.embed_dim, 32, 16, 8, 1]
+    Ws, bs = np_fc_weights(sizes, 5)
+    m = SimpleFC(sizes[0], sizes[1:-1], 1, clip_models=[MODEL], crop_names=["centre_crop", "subcrop1"], dropout_prob=0.3)
+    with torch.no_grad():
+        for layer, W, b in zip(m._linears(), Ws, bs):
+            layer.weight.copy_(torch.from_numpy(W)); layer.bias.copy_(torch.from_numpy(b))
+    torch.save(m, tmp_path / "reg.pth")
+    common = dict(model_file=str(tmp_path / "reg.pth"), batch_size=4, copy_imgs_fraction=0.0, num_workers=0)
+    predict_driver.predict_labels(types.SimpleNamespace(root_dir=root, packed_store=sd, store_root=root, **common))
+    predict_driver.predict_labels(types.SimpleNamespace(root_dir=root_pt, **common))
+    a = pd.read_csv(str(tmp_path / "imgs.csv")).sort_values("uuid")
+    b = pd.read_csv(str(tmp_path / "ref" / "imgs.csv")).sort_values("uuid")
+    assert list(a.uuid) == list(b.uuid) and np.array_equal(a.predicted_label.values, b.predicted_label.values)
+
+    common = dict(threshold=0.999, mode="copy", clip_model_to_use=None, chunk_size=10000, test=True)
+    fa = dedup_driver.find_near_duplicates(types.SimpleNamespace(root_dir=root, packed_store=sd, **common))
+    fb = dedup_driver.find_near_duplicates(types.SimpleNamespace(root_dir=root_pt, **common))
+    assert [(os.path.basename(x), os.path.basename(y), v) for x, y, v in fa] == \
+           [(os.path.basename(x), os.path.basename(y), v) for x, y, v in fb]
+    assert ("a000.jpg", "a008.jpg") in [(os.path.basename(x), os.path.basename(y)) for x, y, _ in fa]
+    assert export_pt(sd, root) == 9                         # and the reference's own scripts can still read the result
+    assert torch.equal(torch.load(os.path.join(root, "a004.pt"), weights_only=True)[MODEL]["subcrop2"],
+                       torch.load(os.path.join(root_pt, "a004.pt"), weights_only=True)[MODEL]["subcrop2"])
+
+
 def test_aesthetic_regressor_fused_single_image(gpu, tmp_path):
     """The composition utils/embedder.py:298-311 intends: image -> crops -> encode -> [crop][E] -> score."""
     from clip_assisted_data_labeling_amd.embedder import AestheticRegressor
