@@ -680,6 +680,27 @@ int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int
   return 0;
 }
 
+int simsearch_distances(const void* emb_dev, int emb_f16, long n, int d, long row_stride, const float* query_dev,
+                        int measure, float* dist_dev, void* stream) {
+  if (!emb_dev || !query_dev || !dist_dev) return fail("simsearch_distances: NULL device pointer");
+  if (n < 0) return fail("simsearch_distances: n %ld < 0", n);
+  if (n == 0) return 0;
+  if (measure != SIMSEARCH_L2 && measure != SIMSEARCH_COSINE) return fail("Similarity measure %d not implemented!", measure);
+  hipError_t err = ce_simsearch_distances(emb_dev, emb_f16, n, d, row_stride, query_dev, measure, dist_dev, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("simsearch_distances(%ld x %d) failed: %s", n, d, hipGetErrorString(err));
+  return 0;
+}
+
+size_t simsearch_topn_workspace(long n, int top_n) { return (n < 1 || top_n < 1) ? 256 : ce_topn_workspace_bytes(n, top_n); }
+
+int simsearch_topn(const float* dist_dev, long n, int top_n, long long* idx_out_dev, float* val_out_dev, void* ws_dev,
+                   size_t ws_bytes, void* stream) {
+  if (!dist_dev || !idx_out_dev || !val_out_dev || !ws_dev) return fail("simsearch_topn: NULL device pointer");
+  hipError_t err = ce_topn_smallest(dist_dev, n, top_n, idx_out_dev, val_out_dev, ws_dev, ws_bytes, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("simsearch_topn(n=%ld, top_n=%d) failed: %s", n, top_n, hipGetErrorString(err));
+  return 0;
+}
+
 int clipenc_op_gemm_nt(const void* a_dev, const void* w_dev, int m, int n, int k, int dtype, int epi,
                        const float* bias_dev, void* out_dev, void* stream) {
   if (epi != CLIPENC_EPI_STORE_F32 && epi != CLIPENC_EPI_STORE_BF16) return fail("epi %d not exposed", epi);

@@ -22,6 +22,13 @@ hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out
 hipError_t ce_static_scale(const void* W_bf16, const float* bias, int N, int K, float* s, float* inv_s, hipStream_t stream);
 hipError_t ce_scale_cols(const void* W_bf16, const float* s, float* out_f32, int N, int K, hipStream_t stream);
 
+// simsearch.hip
+hipError_t ce_simsearch_distances(const void* emb, int emb_f16, long n, int d, long row_stride, const float* query, int measure,
+                                  float* out, hipStream_t stream);
+size_t ce_topn_workspace_bytes(long n, int top_n);
+hipError_t ce_topn_smallest(const float* dist, long n, int top_n, long long* out_i, float* out_v, void* ws, size_t ws_bytes,
+                            hipStream_t stream);
+
 // fcreg.hip
 #define CE_FC_MAX_LAYERS 8
 #define CE_FC_MAX_SEG 16

@@ -121,6 +121,26 @@ int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int
                      void* ehat_ws_dev, long long* pairs_dev, float* vals_dev, unsigned long long capacity,
                      unsigned long long* count_dev, void* stream);
 
+/* Replaces the per-file loop of find_similar_imgs (/root/reference/tools/find_similar_imgs.py:96-137): the distance of
+ * every stored embedding row to one query (the mean context embedding, :62) and the top_n closest.
+ *   emb_dev     [n] rows of d elements, float32 (emb_f16 == 0) or float16, consecutive rows row_stride elements apart
+ *               (pass the [n][crops][E] store with row_stride = crops*E and the pointer advanced to the crop)
+ *   query_dev   float32 [d]
+ *   measure     SIMSEARCH_L2: || q - e + 1e-6 ||_2 (torch pairwise_distance, :92); SIMSEARCH_COSINE: (1 - cos)/2 with the
+ *               1e-8 clamp of torch cosine_similarity on each norm (:90)
+ *   dist_dev    float32 [n] out
+ * simsearch_topn: indices / values of the top_n smallest distances, ascending, equal distances by lower index (the
+ * reference keeps the earlier file on ties, :83), NaN = +inf; when n < top_n the tail is (-1, +inf).
+ * ws_dev: scratch of simsearch_topn_workspace(n, top_n) bytes. */
+#define SIMSEARCH_L2 0
+#define SIMSEARCH_COSINE 1
+int simsearch_distances(const void* emb_dev, int emb_f16, long n, int d, long row_stride, const float* query_dev,
+                        int measure, float* dist_dev, void* stream);
+size_t simsearch_topn_workspace(long n, int top_n);
+int simsearch_topn(const float* dist_dev, long n, int top_n, long long* idx_out_dev, float* val_out_dev, void* ws_dev,
+                   size_t ws_bytes, void* stream);
+
+
 /* GPU front end.  Replaces, for a decoded image that is already in HBM, the crop
  * extraction and the Resize + CenterCrop of the validation transform that the reference runs in its DataLoader
  * workers (/root/reference/utils/embedder.py:184-251 and :90-92; Pillow's bicubic resampler underneath):

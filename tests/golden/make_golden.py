@@ -13,6 +13,8 @@ What is pinned against what:
   encoder_*.npz          oracle/vit_oracle.py outputs on seeded weights, after asserting agreement with
                          transformers.CLIPVisionModelWithProjection (independent implementation; the
                          reference has no vectors at the open_clip boundary).
+  simsearch_small.npz    the reference's `compute_distance` and `topN` (/root/reference/tools/find_similar_imgs.py)
+                         on a seeded embedding set: l2 and cosine distances, the top-N set it keeps.
 None of the reference's source travels: only arrays are written.
 """
 import os
@@ -131,6 +133,37 @@ def make_dedup():
     print("dedup_planted:", pairs.shape[0], "pairs reported by the reference")
 
 
+def make_simsearch():
+    import importlib.util
+    from oracle import simsearch_oracle
+    spec = importlib.util.spec_from_file_location("ref_similar", os.path.join(REF, "tools/find_similar_imgs.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    g = torch.Generator().manual_seed(11)
+    n, d, top = 500, 96, 12
+    emb = torch.randn(n, d, generator=g)
+    emb = emb / emb.norm(dim=-1, keepdim=True)
+    emb[7] = emb[3]                                        # an exact tie
+    emb[100] = 0.0                                         # a zero row: cosine's eps clamp
+    ctx = emb[torch.randperm(n, generator=g)[:9]] + 0.05 * torch.randn(9, d, generator=g)
+    query = ctx.mean(0)                                    # create_context_embedding: mean of the context rows
+    out = {"emb": emb.numpy(), "query": query.numpy(), "top_n": top}
+    for measure in ("l2", "cosine"):
+        dist = torch.stack([ref.compute_distance(query, emb[i], measure) for i in range(n)])
+        topn = ref.topN(top)
+        for i in range(n):
+            topn.update(dist[i], i)                        # the reference feeds file paths; indices stand in for them
+        kept = sorted(int(i) for i in topn.best_img_paths)
+        od = simsearch_oracle.distances(emb.numpy(), query.numpy(), measure)
+        assert np.abs(od - dist.numpy()).max() <= 2e-7, np.abs(od - dist.numpy()).max()
+        oi, _ = simsearch_oracle.top_n(dist.numpy(), top)
+        assert sorted(oi.tolist()) == kept, (sorted(oi.tolist()), kept)
+        out[f"dist_{measure}"] = dist.numpy().astype(np.float32)
+        out[f"kept_{measure}"] = np.array(kept, dtype=np.int64)
+    np.savez_compressed(os.path.join(HERE, "simsearch_small.npz"), **out)
+    print("simsearch_small: oracle == reference compute_distance/topN for l2 and cosine")
+
+
 def make_encoder(arch, n_crops, seed, in_seed):
     from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
     cfg = vit_config.ARCHS[arch]
@@ -192,6 +225,7 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     make_regressor()
     make_dedup()
+    make_simsearch()
     make_encoder("ViT-tiny-test", 6, seed=3, in_seed=4)
     make_encoder("ViT-small-test", 5, seed=1, in_seed=2)
     make_encoder("ViT-B-32", 8, seed=0, in_seed=1234)
