@@ -68,6 +68,8 @@ SIGNATURES = {
     "clipenc_op_gemm_nt": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "clipenc_op_gemm_nt_stamps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "clipenc_op_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "preproc_crops_u8_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                       POINTER(c_int), POINTER(c_int), c_int, c_void_p, c_void_p]),
     "simsearch_distances": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_int, c_void_p, c_void_p]),
     "simsearch_topn_workspace": (c_size_t, [c_long, c_int]),
     "simsearch_topn": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

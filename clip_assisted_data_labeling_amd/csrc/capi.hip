@@ -773,6 +773,17 @@ int preproc_crops_u8(preproc_t p, const uint8_t* image_dev, int height, int widt
   return 0;
 }
 
+int preproc_crops_u8_batch(preproc_t p, int n_images, const uint8_t* const* images_dev, const int* heights, const int* widths,
+                           const int* pitches_bytes, const int* crops_per_image, const int* boxes, int out_size, uint8_t* out_dev,
+                           void* stream) {
+  if (!p || !p->st) return fail("NULL handle");
+  HIP_TRY(hipSetDevice(p->device));
+  hipError_t err = ce_preproc_crops_u8_batch(p->st, n_images, images_dev, heights, widths, pitches_bytes, crops_per_image, boxes,
+                                             out_size, out_dev, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("preproc_crops_u8_batch(%d images -> %d) failed: %s", n_images, out_size, hipGetErrorString(err));
+  return 0;
+}
+
 int preproc_axis_tables(int in_size, int out_size, int out0, int n_out, int* bounds, int* kk, int kk_capacity, int* ksize) {
   if (in_size < 1 || out_size < 1 || out0 < 0 || n_out < 1 || out0 + n_out > out_size || !bounds || !kk || !ksize)
     return fail("preproc_axis_tables: bad argument");

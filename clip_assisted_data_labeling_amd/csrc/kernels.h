@@ -51,6 +51,9 @@ struct PreprocState;
 PreprocState* ce_preproc_create();
 void ce_preproc_destroy(PreprocState* s);
 int ce_preproc_axis_tables(int in_size, int out_size, int out0, int n_out, std::vector<int>& bounds, std::vector<int>& kk);
+hipError_t ce_preproc_crops_u8_batch(PreprocState* s, int n_images, const uint8_t* const* imgs, const int* Hs, const int* Ws,
+                                     const int* pitches, const int* crops_per_image, const int* boxes, int R, uint8_t* out,
+                                     hipStream_t stream);
 hipError_t ce_preproc_crops_u8(PreprocState* s, const uint8_t* img, int H, int W, int pitch, int n_crops, const int* boxes,
                                int R, uint8_t* out, hipStream_t stream);
 

@@ -74,6 +74,13 @@ class RawImageDataset(Dataset):
             return torch.zeros(0), "", img_path, False
 
 
+class _Shape:
+    """Stands in for a crop tensor once it has been sent to the GPU: only `.shape[0]` (its crop count) is still needed."""
+
+    def __init__(self, n):
+        self.shape = (n,)
+
+
 def _collate(batch):
     ok = [b for b in batch if b[3]]
     bad = [b[2] for b in batch if not b[3]]
@@ -162,32 +169,34 @@ class Feature_Dataset:
                 n_skipped += 1
             else:
                 todo.append(p)
-        kwargs = dict(batch_size=self.batch_size, shuffle=False, num_workers=self.num_workers, collate_fn=_collate)
+        # A DataLoader worker produces one whole loader batch by itself, so the loader batch is a fraction of the encode
+        # batch: all workers then decode images of the SAME encode batch in parallel and the first one is complete after
+        # batch_size / num_workers decodes instead of batch_size.
+        loader_bs = self.batch_size if self.num_workers <= 1 else max(4, -(-self.batch_size // self.num_workers))
+        kwargs = dict(batch_size=loader_bs, shuffle=False, num_workers=self.num_workers, collate_fn=_collate)
         if self.num_workers > 0:
-            kwargs["prefetch_factor"] = 2
+            kwargs["prefetch_factor"] = 4
         dataset = RawImageDataset(todo) if self.cropper else CustomImageDataset(todo, self.crop_names, self.preprocess)
-        loader = DataLoader(dataset, **kwargs)
-        for ok, bad in loader:
-            n_failed += len(bad)
-            if not ok:
-                continue
-            if self.cropper:
-                made = [self.cropper(b[0]) for b in ok]
-                ok = [(crops, ",".join(names), b[2], True) for (crops, names), b in zip(made, ok)]
-            counts = [b[0].shape[0] for b in ok]
-            stacked = torch.cat([b[0] for b in ok], 0).to(self.device)      # [sum crops, 3, R, R], row = image-major
-            features = self.encoder.encode_image(stacked).float().cpu()    # :130
+        on_gpu = torch.device(self.device).type == "cuda" and torch.cuda.is_available()
+        # decoded images reach the main process in page-locked memory (the loader's pin thread copies them there in the
+        # background), so the per-image upload is an asynchronous DMA instead of a 0.6 ms synchronous pageable copy
+        loader = DataLoader(dataset, pin_memory=on_gpu, **kwargs)
+
+        def finish(batch, features):
+            """Host side of one batch: embeddings [sum crops, E] (CPU fp32) -> the store."""
+            nonlocal writer, n_embedded
+            counts = [b[0].shape[0] for b in batch]
             if self.packed_store:                          # one sequential write per batch instead of one pickle per image
                 if any(n != len(self.crop_names) for n in counts):
                     raise RuntimeError("packed store needs every image to carry all crops " + str(self.crop_names))
                 if writer is None:
                     writer = PackedStoreWriter(self.packed_store, self.model_name, self.crop_names, features.shape[-1], rank)
-                writer.append([image_key(b[2], self.root_dir) for b in ok],
-                              features.view(len(ok), len(self.crop_names), features.shape[-1]))
-                n_embedded += len(ok)
-                continue
+                writer.append([image_key(b[2], self.root_dir) for b in batch],
+                              features.view(len(batch), len(self.crop_names), features.shape[-1]))
+                n_embedded += len(batch)
+                return
             row = 0
-            for (crops, names, img_path, _), n in zip(ok, counts):
+            for (crops, names, img_path, _), n in zip(batch, counts):
                 feature_save_path = os.path.splitext(img_path)[0] + ".pt"
                 final = {}
                 if os.path.exists(feature_save_path) and not self.force_reencode:
@@ -205,6 +214,49 @@ class Feature_Dataset:
                 except Exception as e:
                     print(f"Error saving features to {feature_save_path}: {e}")
                 n_embedded += 1
+
+        # Two-deep pipeline on the GPU: while batch i is being encoded (kernel launches are asynchronous), the host
+        # decodes / crops batch i+1 and writes batch i-1 to the store; the only waits are on that older batch's copy event.
+        pending = None                                     # (batch meta, pinned host tensor, event)
+
+        def encode_batches():
+            """loader batches regrouped into encode batches of `batch_size` images"""
+            nonlocal n_failed
+            acc = []
+            for ok_part, bad in loader:
+                n_failed += len(bad)
+                acc.extend(ok_part)
+                while len(acc) >= self.batch_size:
+                    yield acc[:self.batch_size]
+                    acc = acc[self.batch_size:]
+            if acc:
+                yield acc
+
+        for ok in encode_batches():
+            if self.cropper:
+                # all images of the batch go through the GPU front end in three launches (crop geometry on the host,
+                # uploads from page-locked memory are asynchronous)
+                stacked, names_all = self.cropper.batch([b[0] for b in ok])
+                per = [len(n) for n in names_all]
+                ok = [(_Shape(k), ",".join(n), b[2], True) for k, n, b in zip(per, names_all, ok)]
+            else:
+                stacked = torch.cat([b[0] for b in ok], 0).to(self.device, non_blocking=True)   # [sum crops, 3, R, R], row = image-major
+            features = self.encoder.encode_image(stacked).float()                            # :130
+            counts_only = [(_Shape(b[0].shape[0]), b[1], b[2], b[3]) for b in ok]           # the crop tensors are not kept: only their counts
+            if on_gpu:
+                host = torch.empty(features.shape, dtype=torch.float32, pin_memory=True)
+                host.copy_(features, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                if pending is not None:
+                    pending[2].synchronize()
+                    finish(pending[0], pending[1])
+                pending = (counts_only, host, ev)
+            else:
+                finish(counts_only, features.cpu())
+        if pending is not None:
+            pending[2].synchronize()
+            finish(pending[0], pending[1])
         if writer is not None:
             writer.close()
         print("\n--- Feature encoding done! ---\n")

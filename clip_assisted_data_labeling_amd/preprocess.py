@@ -140,7 +140,7 @@ class GpuCropper:
         """img: uint8 [H, W, 3] (any device) -> (uint8 [n_crops, 3, R, R] on the GPU, crop names)."""
         if img_u8_hwc.dtype != torch.uint8 or img_u8_hwc.dim() != 3 or img_u8_hwc.shape[2] != 3:
             raise ValueError(f"expected a uint8 [H, W, 3] image, got {tuple(img_u8_hwc.shape)} {img_u8_hwc.dtype}")
-        img = img_u8_hwc.to(self.device).contiguous()
+        img = img_u8_hwc.to(self.device, non_blocking=True).contiguous()
         H, W = int(img.shape[0]), int(img.shape[1])
         rows, names = crop_box_table(W, H, self.crop_names)
         flat = [v for r in rows for v in r]
@@ -150,6 +150,35 @@ class GpuCropper:
                                                       out.data_ptr(), self._lib_mod.current_stream_ptr(self.device)),
                             "preproc_crops_u8")
         return out, names
+
+    @torch.no_grad()
+    def batch(self, images: Sequence[torch.Tensor]):
+        """Several decoded images at once (three kernel launches for all of them): list of uint8 [H, W, 3] ->
+        (uint8 [total crops, 3, R, R] on the GPU in image-major order, list of crop-name lists)."""
+        ct = self._ct
+        dev_imgs, boxes, counts, names_all = [], [], [], []
+        for im in images:
+            if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3:
+                raise ValueError(f"expected a uint8 [H, W, 3] image, got {tuple(im.shape)} {im.dtype}")
+            d = im.to(self.device, non_blocking=True).contiguous()
+            rows, names = crop_box_table(int(d.shape[1]), int(d.shape[0]), self.crop_names)
+            dev_imgs.append(d)
+            boxes.extend(v for r in rows for v in r)
+            counts.append(len(rows))
+            names_all.append(names)
+        n, total = len(dev_imgs), sum(counts)
+        out = torch.empty((total, 3, self.size, self.size), dtype=torch.uint8, device=self.device)
+        if total == 0:
+            return out, names_all
+        ptrs = (ct.c_void_p * n)(*[d.data_ptr() for d in dev_imgs])
+        Hs = (ct.c_int * n)(*[int(d.shape[0]) for d in dev_imgs])
+        Ws = (ct.c_int * n)(*[int(d.shape[1]) for d in dev_imgs])
+        Ps = (ct.c_int * n)(*[int(d.shape[1]) * 3 for d in dev_imgs])
+        Cs = (ct.c_int * n)(*counts)
+        Bx = (ct.c_int * len(boxes))(*boxes)
+        self._lib_mod.check(self.lib.preproc_crops_u8_batch(self.handle, n, ptrs, Hs, Ws, Ps, Cs, Bx, self.size, out.data_ptr(),
+                                                            self._lib_mod.current_stream_ptr(self.device)), "preproc_crops_u8_batch")
+        return out, names_all
 
     def close(self):
         if getattr(self, "handle", None):

@@ -149,11 +149,19 @@ int simsearch_topn(const float* dist_dev, long n, int top_n, long long* idx_out_
  *              kind 1 = black square canvas (side, paste_x, paste_y, -) with the image pasted on it
  *   out_dev    uint8 [n_crops][3][out_size][out_size], bit-exact with the Pillow path; feed it to
  *              clipenc_encode as CLIPENC_IN_U8.
- * The call synchronises `stream` once (its pinned staging buffer is reused). */
+ * n_crops <= 32.  Asynchronous: three launches on `stream` (coefficient tables, horizontal pass, vertical pass), no host
+ * synchronisation; a handle's scratch is reused by its next call, so use one stream at a time per handle. */
 int preproc_create(int device, preproc_t* out);
 int preproc_destroy(preproc_t p);
 int preproc_crops_u8(preproc_t p, const uint8_t* image_dev, int height, int width, int pitch_bytes, int n_crops,
                      const int* boxes, int out_size, uint8_t* out_dev, void* stream);
+/* The same for a whole batch in three launches (the per-image call costs three launches per image, which on a GPU busy
+ * with the encoder's persistent kernels means three waits for free CUs per image): image i = images_dev[i]
+ * (host array of device pointers) of heights[i] x widths[i], contributes crops_per_image[i] consecutive rows of `boxes`
+ * and of out_dev; at most 65535 crops per call. */
+int preproc_crops_u8_batch(preproc_t p, int n_images, const uint8_t* const* images_dev, const int* heights, const int* widths,
+                           const int* pitches_bytes, const int* crops_per_image, const int* boxes, int out_size,
+                           uint8_t* out_dev, void* stream);
 /* Host-only: the fixed-point resampling tables of one axis (window start/length and 22-bit weights per output
  * coordinate out0 .. out0+n_out-1), exposed so that they can be pinned against Pillow without a GPU. */
 int preproc_axis_tables(int in_size, int out_size, int out0, int n_out, int* bounds, int* kk, int kk_capacity, int* ksize);

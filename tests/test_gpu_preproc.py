@@ -42,3 +42,19 @@ def test_gpu_front_end_feeds_encoder_identically(gpu):
     with pytest.raises(ValueError):
         cropper(torch.zeros(10, 10, 4, dtype=torch.uint8))
     vit.close(); cropper.close()
+
+
+def test_batched_call_equals_per_image_calls(gpu):
+    """preproc_crops_u8_batch (three launches for many images; plans by kernel argument up to 32 crops, by device array
+    beyond) gives the same bytes as one call per image, for mixed sizes and repeated batches."""
+    from clip_assisted_data_labeling_amd.preprocess import GpuCropper
+    rs = np.random.RandomState(9)
+    cropper = GpuCropper(224, gpu)
+    for n_img in (1, 3, 8, 9, 40):                          # 4, 12, 32 (argument path) | 36, 160 crops (device-array path)
+        imgs = [torch.from_numpy(rs.randint(0, 256, (rs.randint(60, 700), rs.randint(60, 700), 3), dtype=np.uint8))
+                for _ in range(n_img)]
+        out, names = cropper.batch(imgs)
+        assert out.shape == (4 * n_img, 3, 224, 224) and all(len(n) == 4 for n in names)
+        single = torch.cat([cropper(im)[0] for im in imgs], 0)
+        assert torch.equal(out, single)
+    cropper.close()
