@@ -68,6 +68,12 @@ SIGNATURES = {
     "clipenc_op_gemm_nt": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "clipenc_op_gemm_nt_stamps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "clipenc_op_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "fctrain_create": (c_int, [c_int, POINTER(c_int), c_float_pp, c_float_pp, c_float, c_int, POINTER(c_void_p)]),
+    "fctrain_destroy": (c_int, [c_void_p]),
+    "fctrain_epoch": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_float, c_float, ctypes.c_uint,
+                              c_void_p, c_void_p]),
+    "fctrain_predict": (c_int, [c_void_p, c_void_p, c_long, c_void_p, c_void_p]),
+    "fctrain_get_params": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "preproc_crops_u8_batch": (c_int, [c_void_p, c_int, POINTER(c_void_p), POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                        POINTER(c_int), POINTER(c_int), c_int, c_void_p, c_void_p]),
     "simsearch_distances": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_int, c_void_p, c_void_p]),

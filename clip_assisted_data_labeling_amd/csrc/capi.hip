@@ -157,6 +157,11 @@ struct preproc_s {
   PreprocState* st = nullptr;
 };
 
+struct fctrain_s {
+  int device = 0;
+  FcTrainState* st = nullptr;
+};
+
 struct fcreg_s {
   int device = 0;
   int n_layers = 0;
@@ -677,6 +682,62 @@ int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int
   const int ld = (d + 127) / 128 * 128;
   HIP_TRY(ce_dedup_normalize_f16(emb_f16_dev, ehat_ws_dev, n, d, ld, st));
   HIP_TRY(ce_dedup_pairs(ehat_ws_dev, n, d, ld, threshold, fp16_compare, pairs_dev, vals_dev, capacity, count_dev, st));
+  return 0;
+}
+
+int fctrain_create(int n_layers, const int* sizes, const float* const* W, const float* const* b, float negative_slope,
+                   int device, fctrain_t* out) {
+  if (!sizes || !W || !b || !out) return fail("fctrain_create: NULL argument");
+  if (n_layers < 1 || n_layers > CE_FC_MAX_LAYERS) return fail("fctrain_create: %d layers (1..%d supported)", n_layers, CE_FC_MAX_LAYERS);
+  if (sizes[n_layers] != 1) return fail("fctrain_create: the last layer must have one output (MSE on a scalar label), got %d", sizes[n_layers]);
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail("device %d out of range (%d visible)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  hipError_t err = hipSuccess;
+  FcTrainState* st = ce_fctrain_create(n_layers, sizes, W, b, negative_slope, &err);
+  if (!st) return fail("fctrain_create failed: %s", hipGetErrorString(err));
+  fctrain_s* t = new fctrain_s();
+  t->device = device; t->st = st;
+  *out = t;
+  return 0;
+}
+
+int fctrain_destroy(fctrain_t t) {
+  if (!t) return 0;
+  (void)hipSetDevice(t->device);
+  ce_fctrain_destroy(t->st);
+  delete t;
+  return 0;
+}
+
+int fctrain_epoch(fctrain_t t, const float* x_dev, const float* labels_dev, const long long* order_dev, long n_order,
+                  int batch_size, float lr, float weight_decay, float dropout_prob, unsigned seed, float* batch_losses_dev,
+                  void* stream) {
+  if (!t || !t->st) return fail("NULL handle");
+  if (!x_dev || !labels_dev) return fail("fctrain_epoch: NULL device pointer");
+  if (n_order == 0) return 0;
+  HIP_TRY(hipSetDevice(t->device));
+  hipError_t err = ce_fctrain_epoch(t->st, x_dev, labels_dev, order_dev, n_order, batch_size, lr, weight_decay, dropout_prob, seed,
+                                    batch_losses_dev, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("fctrain_epoch(%ld rows, batch %d) failed: %s", n_order, batch_size, hipGetErrorString(err));
+  return 0;
+}
+
+int fctrain_predict(fctrain_t t, const float* x_dev, long n, float* y_dev, void* stream) {
+  if (!t || !t->st) return fail("NULL handle");
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(t->device));
+  hipError_t err = ce_fctrain_predict(t->st, x_dev, n, y_dev, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("fctrain_predict(%ld rows) failed: %s", n, hipGetErrorString(err));
+  return 0;
+}
+
+int fctrain_get_params(fctrain_t t, int layer, float* W_host, float* b_host) {
+  if (!t || !t->st) return fail("NULL handle");
+  HIP_TRY(hipSetDevice(t->device));
+  hipError_t err = ce_fctrain_get_params(t->st, layer, W_host, b_host);
+  if (err != hipSuccess) return fail("fctrain_get_params(layer %d) failed: %s", layer, hipGetErrorString(err));
   return 0;
 }
 

@@ -22,6 +22,15 @@ hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out
 hipError_t ce_static_scale(const void* W_bf16, const float* bias, int N, int K, float* s, float* inv_s, hipStream_t stream);
 hipError_t ce_scale_cols(const void* W_bf16, const float* s, float* out_f32, int N, int K, hipStream_t stream);
 
+// fctrain.hip
+struct FcTrainState;
+FcTrainState* ce_fctrain_create(int n_layers, const int* sizes, const float* const* W, const float* const* b, float slope, hipError_t* err);
+void ce_fctrain_destroy(FcTrainState* s);
+hipError_t ce_fctrain_epoch(FcTrainState* s, const float* X, const float* T, const long long* order, long n_order, int batch_size,
+                            float lr, float wd, float p_drop, uint32_t seed, float* losses, hipStream_t st);
+hipError_t ce_fctrain_predict(FcTrainState* s, const float* X, long n, float* y, hipStream_t st);
+hipError_t ce_fctrain_get_params(FcTrainState* s, int layer, float* W_host, float* b_host);
+
 // simsearch.hip
 hipError_t ce_simsearch_distances(const void* emb, int emb_f16, long n, int d, long row_stride, const float* query, int measure,
                                   float* out, hipStream_t stream);

@@ -110,6 +110,28 @@ int clipenc_encode_score(clipenc_t enc, fcreg_t reg, const void* crops_dev, int 
                          int in_dtype, const int* crop_select, int n_select, float* emb_dev, float* score_dev,
                          void* stream);
 
+/* Regressor training on the device.  Replaces the optimisation loop of
+ * /root/reference/_4_train_model.py:199-207 for the SimpleFC of utils/nn_model.py (created with the initial parameters,
+ * same layout as fcreg_create; the last layer must have one output): per batch forward (LeakyReLU + Dropout hidden
+ * layers, Sigmoid output), MSELoss, backward and one torch.optim.Adam step (betas 0.9 / 0.999, eps 1e-8, weight_decay
+ * added to the gradient).
+ *   x_dev / labels_dev   float32 [n][sizes[0]] / [n], the whole training set in HBM
+ *   order_dev            int64 [n_order] row indices (one epoch's shuffled order), or NULL for rows 0..n_order-1
+ *   lr                   the epoch's learning rate (CosineAnnealingWarmRestarts is evaluated by the caller, :210)
+ *   dropout_prob, seed   masks are a counter-based hash of (seed, optimisation step, layer, row, column) -- reproducible,
+ *                        but not torch's generator
+ *   batch_losses_dev     float32 [ceil(n_order / batch_size)] out: each batch's MSE before its update (may be NULL)
+ * The handle counts optimisation steps across calls (Adam's bias correction).  fctrain_predict is the eval-mode forward. */
+typedef struct fctrain_s* fctrain_t;
+int fctrain_create(int n_layers, const int* sizes, const float* const* W, const float* const* b, float negative_slope,
+                   int device, fctrain_t* out);
+int fctrain_destroy(fctrain_t t);
+int fctrain_epoch(fctrain_t t, const float* x_dev, const float* labels_dev, const long long* order_dev, long n_order,
+                  int batch_size, float lr, float weight_decay, float dropout_prob, unsigned seed, float* batch_losses_dev,
+                  void* stream);
+int fctrain_predict(fctrain_t t, const float* x_dev, long n, float* y_dev, void* stream);
+int fctrain_get_params(fctrain_t t, int layer, float* W_host, float* b_host);
+
 /* Replaces the similarity search of find_near_duplicates (/root/reference/_2_remove_duplicates.py:63-80):
  * rows of emb_f16_dev [n][d] (float16, as :38 casts them) are normalised (:67) and every pair i < j with
  * cosine > threshold (:69-74) is appended, unordered, to pairs_dev (int64 [capacity][2]) / vals_dev

@@ -15,6 +15,9 @@ What is pinned against what:
                          reference has no vectors at the open_clip boundary).
   simsearch_small.npz    the reference's `compute_distance` and `topN` (/root/reference/tools/find_similar_imgs.py)
                          on a seeded embedding set: l2 and cosine distances, the top-N set it keeps.
+  train_small.npz        the reference's SimpleFC trained by torch.optim.Adam + CosineAnnealingWarmRestarts + MSELoss (the
+                         objects /root/reference/_4_train_model.py:125-130 builds) at dropout 0 on a seeded regression set
+                         with an explicit batch order: learning rates, per-epoch train loss, final parameters.
 None of the reference's source travels: only arrays are written.
 """
 import os
@@ -164,6 +167,62 @@ def make_simsearch():
     print("simsearch_small: oracle == reference compute_distance/topN for l2 and cosine")
 
 
+def make_train():
+    sys.path.insert(0, REF)
+    from utils.nn_model import SimpleFC  # the reference class itself
+    from torch.optim import Adam
+    from torch.optim.lr_scheduler import CosineAnnealingWarmRestarts
+    from oracle import train_oracle
+    torch.manual_seed(5)
+    n, d, hidden, bs, epochs = 200, 48, [24, 12, 6], 16, 7
+    lr, wd, min_lr, T0 = 2e-3, 6e-4, 1e-6, 3
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(n, d, generator=g)
+    w_true = torch.randn(d, generator=g) / d ** 0.5
+    T = torch.sigmoid(X @ w_true + 0.3 * torch.randn(n, generator=g))
+    T = (T - T.min()) / (T.max() - T.min())                      # labels normalised to [0, 1] (:87-91)
+    model = SimpleFC(d, hidden, 1, ["M/x"], crop_names=["centre_crop"], dropout_prob=0.0)
+    lin = [m for m in model.layers if isinstance(m, torch.nn.Linear)]
+    W0 = [m.weight.detach().clone().numpy() for m in lin]; b0 = [m.bias.detach().clone().numpy() for m in lin]
+    model.train()
+    opt = Adam(model.parameters(), lr=lr, weight_decay=wd)
+    sched = CosineAnnealingWarmRestarts(opt, T_0=T0, T_mult=1, eta_min=min_lr)
+    crit = torch.nn.MSELoss()
+    rs = np.random.RandomState(3)
+    orders, lrs, losses = [], [], []
+    for ep in range(epochs):
+        order = rs.permutation(n)
+        orders.append(order)
+        lrs.append(opt.param_groups[0]["lr"])
+        tl = 0.0
+        for b0_ in range(0, n, bs):
+            idx = torch.from_numpy(order[b0_:b0_ + bs])
+            opt.zero_grad()
+            loss = crit(model(X[idx]).squeeze(), T[idx])
+            loss.backward()
+            opt.step()
+            tl += loss.item()
+        sched.step()
+        losses.append(tl / ((n + bs - 1) // bs))
+    Wf = [m.weight.detach().numpy() for m in lin]; bf = [m.bias.detach().numpy() for m in lin]
+    # pin the oracle (float64 arithmetic) against the reference run
+    tr = train_oracle.Trainer(W0, b0, wd, 0.0, 0, dtype=np.float64)
+    ol = []
+    for ep in range(epochs):
+        olr = train_oracle.cosine_lr(lr, min_lr, T0, ep)
+        assert abs(olr - lrs[ep]) < 1e-12, (olr, lrs[ep])
+        ol.append(tr.epoch(X.numpy().astype(np.float64), T.numpy().astype(np.float64), orders[ep], bs, olr))
+    assert np.abs(np.array(ol) - np.array(losses)).max() < 2e-6, np.abs(np.array(ol) - np.array(losses)).max()
+    for a, b in zip(tr.W + tr.b, Wf + bf):
+        assert np.abs(a - b).max() < 2e-4, np.abs(a - b).max()
+    out = {"X": X.numpy(), "T": T.numpy(), "orders": np.array(orders), "lrs": np.array(lrs), "losses": np.array(losses),
+           "hidden": np.array(hidden), "batch_size": bs, "lr": lr, "weight_decay": wd, "min_lr": min_lr, "T_0": T0}
+    for i in range(len(W0)):
+        out[f"W0_{i}"], out[f"b0_{i}"], out[f"Wf_{i}"], out[f"bf_{i}"] = W0[i], b0[i], Wf[i], bf[i]
+    np.savez_compressed(os.path.join(HERE, "train_small.npz"), **out)
+    print("train_small: oracle == reference SimpleFC + torch Adam + CosineAnnealingWarmRestarts over", epochs, "epochs; final train mse", losses[-1])
+
+
 def make_encoder(arch, n_crops, seed, in_seed):
     from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
     cfg = vit_config.ARCHS[arch]
@@ -226,6 +285,7 @@ if __name__ == "__main__":
     make_regressor()
     make_dedup()
     make_simsearch()
+    make_train()
     make_encoder("ViT-tiny-test", 6, seed=3, in_seed=4)
     make_encoder("ViT-small-test", 5, seed=1, in_seed=2)
     make_encoder("ViT-B-32", 8, seed=0, in_seed=1234)

@@ -87,3 +87,35 @@ def test_feature_assembly_order(tmp_path):
     f = predict_driver.assemble_features(p, ["M2/y", "M1/x"], ["subcrop2", "centre_crop", "missing_crop"])
     assert f.tolist() == [13.0] * E + [10.0] * E + [3.0] * E + [0.0] * E     # [model][crop in crop_names order][E]
     assert predict_driver.find_model("nope", str(tmp_path)) is None
+
+
+def test_saved_regressor_is_loadable_by_the_reference_class(tmp_path):
+    """train_driver.save_reference_compatible writes `torch.save(model)` (_4_train_model.py:237) naming the reference's own
+    class.  Where the reference checkout is present (the authoring container), load it with THAT class in a clean
+    interpreter and compare its CPU forward with the oracle; elsewhere only the pickle's class path is checked."""
+    import subprocess, sys
+    from clip_assisted_data_labeling_amd.nn_model import SimpleFC
+    from clip_assisted_data_labeling_amd.train_driver import save_reference_compatible
+    from oracle import fcreg_oracle
+    torch.manual_seed(0)
+    m = SimpleFC(12, [7, 5], 1, ["M/x"], crop_names=["centre_crop"], dropout_prob=0.3).eval()
+    path = str(tmp_path / "m.pth")
+    save_reference_compatible(m, path)
+    assert type(m).__module__ == "clip_assisted_data_labeling_amd.nn_model" and "utils" not in sys.modules
+    raw = open(path, "rb").read()
+    assert b"utils.nn_model" in raw and b"clip_assisted_data_labeling_amd" not in raw
+    if not os.path.isdir("/root/reference/utils"):
+        pytest.skip("reference checkout not present: class-path check only")
+    x = np.random.RandomState(0).randn(4, 12).astype(np.float32)
+    np.save(str(tmp_path / "x.npy"), x)
+    code = ("import sys, numpy as np, torch; sys.path.insert(0, '/root/reference');"
+            f"m = torch.load({path!r}, map_location='cpu', weights_only=False);"
+            "assert type(m).__module__ == 'utils.nn_model' and not m.training, type(m);"
+            f"x = torch.from_numpy(np.load({str(tmp_path / 'x.npy')!r}));"
+            f"np.save({str(tmp_path / 'y.npy')!r}, m(x).detach().numpy()); print(m.clip_models, m.crop_names)")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "['M/x'] ['centre_crop']" in out.stdout
+    lin = m._linears()
+    ref = fcreg_oracle.forward_np([l.weight.detach().numpy() for l in lin], [l.bias.detach().numpy() for l in lin], x)
+    assert np.abs(np.load(str(tmp_path / "y.npy")) - ref).max() < 1e-6
