@@ -4,6 +4,8 @@
 // the affine part: gamma is folded into the weight rows and beta into the bias at create time, exactly as for the
 // bf16 path, so the quantised operand is the unit-variance row.  One wave per row, 16 B per lane and access;
 // v_cvt_pk_fp8_f32 does not saturate (1000 -> NaN, tools/probes/fp8probe2.hip), so values are clamped to +-448 first.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -35,68 +37,80 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float (
   v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
-template <typename TIN, bool LN>
+// One wave per row, NR rows in flight per wave (their loads are issued together: a 2 KiB row alone leaves too few bytes
+// in flight to approach the HBM rate), rows strided over the grid.
+template <typename TIN, bool LN, int CH, int NR>
 __global__ __launch_bounds__(256) void quant_rows_kernel(const TIN* __restrict__ in, size_t ld_in, uint8_t* __restrict__ out,
                                                          size_t ld_out, float* __restrict__ scale, int n_rows, int K, float eps) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n_rows) return;
-  const TIN* src = in + (size_t)row * ld_in;
-  float v[QMAXC][8];
-  float s = 0.f;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+  for (int row0 = wave * NR; row0 < n_rows; row0 += n_waves * NR) {
+    float v[NR][CH][8];
 #pragma unroll
-  for (int ci = 0; ci < QMAXC; ++ci) {
-    const int c = ci * 512 + lane * 8;
-    if (c < K) {
-      load8<TIN>(src + c, v[ci]);
+    for (int r = 0; r < NR; ++r) {
+      const int row = min(row0 + r, n_rows - 1);
+      const TIN* src = in + (size_t)row * ld_in;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[ci][j];
-    }
-  }
-  if constexpr (LN) {
-    const float mean = wave_sum(s) / (float)K;
-    float ss = 0.f;
+      for (int ci = 0; ci < CH; ++ci) {
+        const int c = ci * 512 + lane * 8;
+        if (c < K) load8<TIN>(src + c, v[r][ci]);
+        else {
 #pragma unroll
-    for (int ci = 0; ci < QMAXC; ++ci)
-      if (ci * 512 + lane * 8 < K) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { v[ci][j] -= mean; ss += v[ci][j] * v[ci][j]; }
+          for (int j = 0; j < 8; ++j) v[r][ci][j] = 0.f;
+        }
       }
-    const float rstd = rsqrtf(wave_sum(ss) / (float)K + eps);
+    }
 #pragma unroll
-    for (int ci = 0; ci < QMAXC; ++ci)
-      if (ci * 512 + lane * 8 < K) {
+    for (int r = 0; r < NR; ++r) {
+      const int row = row0 + r;
+      if (row >= n_rows) break;
+      if constexpr (LN) {
+        float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[ci][j] *= rstd;
+        for (int ci = 0; ci < CH; ++ci)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s += v[r][ci][j];
+        const float mean = wave_sum(s) / (float)K;
+        float ss = 0.f;
+#pragma unroll
+        for (int ci = 0; ci < CH; ++ci)
+          if (ci * 512 + lane * 8 < K) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[r][ci][j] -= mean; ss += v[r][ci][j] * v[r][ci][j]; }
+          }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)K + eps);
+#pragma unroll
+        for (int ci = 0; ci < CH; ++ci)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[r][ci][j] *= rstd;
       }
-  }
-  float amax = 0.f;
+      float amax = 0.f;
 #pragma unroll
-  for (int ci = 0; ci < QMAXC; ++ci)
-    if (ci * 512 + lane * 8 < K) {
+      for (int ci = 0; ci < CH; ++ci)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[ci][j]));
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[r][ci][j]));
+      amax = wave_max(amax);
+      const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+      const float inv = amax > 0.f ? 448.0f / amax : 0.f;
+      uint8_t* dst = out + (size_t)row * ld_out;
+#pragma unroll
+      for (int ci = 0; ci < CH; ++ci) {
+        const int c = ci * 512 + lane * 8;
+        if (c < K) {
+          float q[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) q[j] = fminf(fmaxf(v[r][ci][j] * inv, -448.0f), 448.0f);
+          int w0 = 0, w1 = 0;
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false);
+          w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false);
+          w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
+          *(uint2*)(dst + c) = uint2{(uint32_t)w0, (uint32_t)w1};
+        }
+      }
+      if (lane == 0) scale[row] = sc;
     }
-  amax = wave_max(amax);
-  const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
-  const float inv = amax > 0.f ? 448.0f / amax : 0.f;
-  uint8_t* dst = out + (size_t)row * ld_out;
-#pragma unroll
-  for (int ci = 0; ci < QMAXC; ++ci) {
-    const int c = ci * 512 + lane * 8;
-    if (c < K) {
-      float q[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) q[j] = fminf(fmaxf(v[ci][j] * inv, -448.0f), 448.0f);
-      int w0 = 0, w1 = 0;
-      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[0], q[1], w0, false);
-      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(q[2], q[3], w0, true);
-      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[4], q[5], w1, false);
-      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(q[6], q[7], w1, true);
-      *(uint2*)(dst + c) = uint2{(uint32_t)w0, (uint32_t)w1};
-    }
   }
-  if (lane == 0) scale[row] = sc;
 }
 
 // Static (data-free) output scale of a LayerNorm-fed linear layer, from the Cauchy-Schwarz bound
@@ -158,13 +172,25 @@ hipError_t ce_scale_cols(const void* W_bf16, const float* s, float* out_f32, int
 hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out8, size_t ld_out, float* scale, int n_rows,
                              int K, int ln, float eps, hipStream_t stream) {
   if (n_rows < 1 || K < 8 || K % 8 != 0 || K > QMAXC * 512 || ld_in < (size_t)K || ld_out < (size_t)K) return hipErrorInvalidValue;
-  dim3 grid((n_rows + 3) / 4), block(256);
-  if (in_f32) {
-    if (ln) hipLaunchKernelGGL((quant_rows_kernel<float, true>), grid, block, 0, stream, (const float*)in, ld_in, (uint8_t*)out8, ld_out, scale, n_rows, K, eps);
-    else hipLaunchKernelGGL((quant_rows_kernel<float, false>), grid, block, 0, stream, (const float*)in, ld_in, (uint8_t*)out8, ld_out, scale, n_rows, K, eps);
-  } else {
-    if (ln) hipLaunchKernelGGL((quant_rows_kernel<bf16_t, true>), grid, block, 0, stream, (const bf16_t*)in, ld_in, (uint8_t*)out8, ld_out, scale, n_rows, K, eps);
-    else hipLaunchKernelGGL((quant_rows_kernel<bf16_t, false>), grid, block, 0, stream, (const bf16_t*)in, ld_in, (uint8_t*)out8, ld_out, scale, n_rows, K, eps);
-  }
+  const int chunks = (K + 511) / 512;
+  // rows per wave step: as many as keep the row registers (CH * 8 * NR floats) around 64
+#define QLAUNCH(T, LNV, CH, NR)                                                             \
+  do {                                                                                      \
+    const int waves = (n_rows + (NR) - 1) / (NR);                                           \
+    dim3 grid((unsigned)std::min((waves + 3) / 4, 8192)), block(256);                       \
+    hipLaunchKernelGGL((quant_rows_kernel<T, LNV, CH, NR>), grid, block, 0, stream, (const T*)in, ld_in, (uint8_t*)out8, ld_out, scale, \
+                       n_rows, K, eps);                                                     \
+  } while (0)
+#define QDISPATCH(T, LNV)                                                                   \
+  do {                                                                                      \
+    if (chunks <= 1) QLAUNCH(T, LNV, 1, 4);                                                 \
+    else if (chunks <= 2) QLAUNCH(T, LNV, 2, 4);                                            \
+    else if (chunks <= 4) QLAUNCH(T, LNV, 4, 2);                                            \
+    else QLAUNCH(T, LNV, 8, 1);                                                             \
+  } while (0)
+  if (in_f32) { if (ln) QDISPATCH(float, true); else QDISPATCH(float, false); }
+  else { if (ln) QDISPATCH(bf16_t, true); else QDISPATCH(bf16_t, false); }
+#undef QDISPATCH
+#undef QLAUNCH
   return hipGetLastError();
 }
