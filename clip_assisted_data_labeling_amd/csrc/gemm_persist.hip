@@ -133,15 +133,32 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
   // one K=32 stage = two phases; ISSUE_W / ISSUE_A are the DMA statements of the phases, VM the counted wait
-#define STAGE(slot, ISSUE_W, ISSUE_A, VM)                                                   \
+#define STAGE(slot, ISSUE_W, ISSUE_A, WAIT_VM)                                              \
   do {                                                                                      \
     LD_W(slot) __builtin_amdgcn_sched_barrier(0); LD_A(slot, 0)                             \
     ISSUE_W;                                                                                \
     BARRIER(); WAIT_LDS(); MMA(0); BARRIER();                                               \
     LD_A(slot, 1)                                                                           \
     ISSUE_A;                                                                                \
-    asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                  \
+    WAIT_VM;                                                                                \
     BARRIER(); WAIT_LDS(); MMA(1); BARRIER();                                               \
+  } while (0)
+  // Both parts of stage t+3 are issued in stage t (W in phase a, A in phase b); the counted wait leaves stages t+2 and t+3
+  // in flight (4 x 2 pieces) and retires stage t+1.
+#define VM8 asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+  // First two stages after an epilogue: the pieces they need (stages 1 and 2 of the new tile) were issued BEFORE the
+  // epilogue's stores, and vmcnt retires in order -- so when every wave issued exactly its 16 row stores (17 for the
+  // waves that also write EPI_RESID statistics) the wait may leave those outstanding as well, and the stores get two
+  // and a half stage times to drain instead of stalling the ring (1.9 us per tile, tools/gemm_stamps.py).
+#define VM_AFTER_EPILOGUE                                                                   \
+  do {                                                                                      \
+    /* one opaque instruction for the compiler (a real branch here splits every stage into basic blocks and costs   */ \
+    /* ~20 spilled VGPRs): sel 0 -> vmcnt(8), 1 -> vmcnt(24), 2 -> vmcnt(25); only in the first two stages of a tile */ \
+    const int sel_ = __builtin_amdgcn_readfirstlane(relax > 0 ? relax_sel : 0);                                          \
+    relax = relax > 0 ? relax - 1 : 0;                                                      \
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lvm8_%=\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Lvm24_%=\n\t"          \
+                 "s_waitcnt vmcnt(25)\n\ts_branch .Lvmend_%=\n.Lvm24_%=:\n\ts_waitcnt vmcnt(24)\n\ts_branch .Lvmend_%=\n"       \
+                 ".Lvm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lvmend_%=:" : : "s"(sel_) : "memory", "scc");                                  \
   } while (0)
 
   // ---- cold prologue of the first tile ----
@@ -149,9 +166,11 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   STAGE_STATS(0, cur.m0);
   STAGE_A(0, Ablk, aoff0, aoff1, 0); STAGE_W(0, Wblk, 0);
   STAGE_A(1, Ablk, aoff0, aoff1, 64); STAGE_W(1, Wblk, 64);
-  STAGE_A(2, Ablk, aoff0, aoff1, 128);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  STAGE_A(2, Ablk, aoff0, aoff1, 128); STAGE_W(2, Wblk, 128);
+  VM8;
   BARRIER();
+  int relax = 0;                             // stages of the coming tile that may leave the previous tile's stores in flight
+  const int relax_sel = (EPI == EPI_RESID && w < 4) ? 2 : 1;   // those waves also write the row statistics: 17 stores, not 16
 
   for (;;) {
     f32x4_t acc[8][4];
@@ -165,10 +184,10 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
     for (int kb = 0; kb < kend - 256; kb += 256) {
-      STAGE(0, STAGE_W(2, Wblk, kb + 128), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), 6);
-      STAGE(1, STAGE_W(3, Wblk, kb + 192), STAGE_A(0, Ablk, aoff0, aoff1, kb + 256), 6);
-      STAGE(2, STAGE_W(0, Wblk, kb + 256), STAGE_A(1, Ablk, aoff0, aoff1, kb + 320), 6);
-      STAGE(3, STAGE_W(1, Wblk, kb + 320), STAGE_A(2, Ablk, aoff0, aoff1, kb + 384), 6);
+      STAGE(0, STAGE_W(3, Wblk, kb + 192), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), VM_AFTER_EPILOGUE);
+      STAGE(1, STAGE_W(0, Wblk, kb + 256), STAGE_A(0, Ablk, aoff0, aoff1, kb + 256), VM_AFTER_EPILOGUE);
+      STAGE(2, STAGE_W(1, Wblk, kb + 320), STAGE_A(1, Ablk, aoff0, aoff1, kb + 320), VM8);
+      STAGE(3, STAGE_W(2, Wblk, kb + 384), STAGE_A(2, Ablk, aoff0, aoff1, kb + 384), VM8);
     }
     // ---- last four stages: the DMA crosses into the next tile ----
     const int nidx = idx + G;
@@ -188,10 +207,10 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       // ONE code path: without a next tile the DMA harmlessly re-fetches this tile's first stages into dead
       // slots (two variants of this block made hipcc spill ~270 VGPRs)
       if (has_next) STAGE_STATS((tile_iter + 1) & 1, nxt.m0);
-      STAGE(0, STAGE_W(2, Wblk, kb + 128), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), 6);
-      STAGE(1, STAGE_W(3, Wblk, kb + 192), STAGE_A(0, Anext, naoff0, naoff1, 0), 6);
-      STAGE(2, STAGE_W(0, Wnext, 0), STAGE_A(1, Anext, naoff0, naoff1, 64), 6);
-      STAGE(3, STAGE_W(1, Wnext, 64), STAGE_A(2, Anext, naoff0, naoff1, 128), 6);
+      STAGE(0, STAGE_W(3, Wblk, kb + 192), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), VM_AFTER_EPILOGUE);
+      STAGE(1, STAGE_W(0, Wnext, 0), STAGE_A(0, Anext, naoff0, naoff1, 0), VM_AFTER_EPILOGUE);
+      STAGE(2, STAGE_W(1, Wnext, 64), STAGE_A(1, Anext, naoff0, naoff1, 64), VM8);
+      STAGE(3, STAGE_W(2, Wnext, 128), STAGE_A(2, Anext, naoff0, naoff1, 128), VM8);
     }
     if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 5] = __builtin_amdgcn_s_memtime(); }
@@ -268,7 +287,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
         // residual rows of this 16-row block: row-major image -> fragment layout
         *(uint4*)(tr + tr_base) = rres[(mt * 2) & 7];
         *(uint4*)(tr + 1024 + tr_base) = rres[(mt * 2 + 1) & 7];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // cross-lane hand-off through the image
+        // (no wait: the LDS serves one wave's accesses in order, so the fragment-layout reads below see these writes)
         if (mt + 4 < 8) { LOAD_RES(mt * 2 + 8); LOAD_RES(mt * 2 + 9); }
         float s = 0.f, ss = 0.f;
 #pragma unroll
@@ -288,18 +307,17 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
         s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
         if (lane < 16)
           *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane) * 8) = float2{s, ss};
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // fragment reads done before the image is rewritten
+        // (in order again: the image may be rewritten right behind the fragment reads)
       }
       // fragment layout -> row-major image -> two 16-B-per-lane stores of 8 full rows each
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) *(uint2*)TW_ADDR(nt) = pk[nt];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      // (no wait between the image writes and the row-major reads, nor before the next block's writes: one wave, in order)
       const uint4 v0 = *(const uint4*)(tr + tr_base);
       const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
       const int ma = mw0 + mt * 16 + row_l, mb = ma + 8;
       if (ma < p.M) *(uint4*)((bf16_t*)p.out + (size_t)ma * p.ldo + gcol) = v0;
       if (mb < p.M) *(uint4*)((bf16_t*)p.out + (size_t)mb * p.ldo + gcol) = v1;
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // image reads done before the next block's writes
     }
 
     if constexpr (EPI == EPI_RESID) {
@@ -321,6 +339,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant DMA before the LDS is released
       break;
     }
+    relax = (cur.m0 + BM <= p.M && p.dbg == nullptr) ? 2 : 0;   // all 256 rows valid: every guarded store above was issued
     idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext; aoff0 = naoff0; aoff1 = naoff1;
     ++tile_iter;
   }
