@@ -138,22 +138,41 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
-#define STAGE(slot, ISSUE_W, ISSUE_A, VM)                                                   \
+#define STAGE(slot, ISSUE_W, ISSUE_A, WAIT_VM)                                              \
   do {                                                                                      \
     LD_W(slot) __builtin_amdgcn_sched_barrier(0); LD_A(slot, 0)                             \
     ISSUE_W;                                                                                \
     BARRIER(); WAIT_LDS(); MMA(0); BARRIER();                                               \
     LD_A(slot, 1)                                                                           \
     ISSUE_A;                                                                                \
-    asm volatile("s_waitcnt vmcnt(" #VM ")" ::: "memory");                                  \
+    WAIT_VM;                                                                                \
     BARRIER(); WAIT_LDS(); MMA(1); BARRIER();                                               \
+  } while (0)
+
+  // Both parts of stage t+3 are issued in stage t; the counted wait leaves stages t+2 and t+3 in flight (4 x 2 pieces).
+#define VM8 asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+  // First two stages after an epilogue: what they need was issued before the epilogue's stores and vmcnt retires in
+  // order, so the wait may leave the NST row stores of a complete tile outstanding as well (see gemm_persist.hip); one
+  // opaque instruction for the compiler.
+  constexpr int NST = EPI == 2 ? 8 : 16;     // row stores per wave and tile
+#define VM_AFTER_EPILOGUE                                                                   \
+  do {                                                                                      \
+    const int sel_ = __builtin_amdgcn_readfirstlane(relax > 0 ? 1 : 0);                     \
+    relax = relax > 0 ? relax - 1 : 0;                                                      \
+    if constexpr (NST == 16)                                                                \
+      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm8_%=\n\ts_waitcnt vmcnt(24)\n\ts_branch .Lf8end_%=\n"               \
+                   ".Lf8vm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lf8end_%=:" : : "s"(sel_) : "memory", "scc");                            \
+    else                                                                                    \
+      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm8_%=\n\ts_waitcnt vmcnt(16)\n\ts_branch .Lf8end_%=\n"               \
+                   ".Lf8vm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lf8end_%=:" : : "s"(sel_) : "memory", "scc");                            \
   } while (0)
 
   // ---- cold prologue of the first tile ----
   STAGE_A(0, Ablk, aoff0, aoff1, 0); STAGE_W(0, Wblk, 0);
   STAGE_A(1, Ablk, aoff0, aoff1, 64); STAGE_W(1, Wblk, 64);
-  STAGE_A(2, Ablk, aoff0, aoff1, 128);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  STAGE_A(2, Ablk, aoff0, aoff1, 128); STAGE_W(2, Wblk, 128);
+  VM8;
+  int relax = 0;                             // stages of the coming tile that may leave the previous tile's stores in flight
   BARRIER();
 
   for (;;) {
@@ -169,10 +188,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
     for (int kb = 0; kb < kend - 256; kb += 256) {
-      STAGE(0, STAGE_W(2, Wblk, kb + 128), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), 6);
-      STAGE(1, STAGE_W(3, Wblk, kb + 192), STAGE_A(0, Ablk, aoff0, aoff1, kb + 256), 6);
-      STAGE(2, STAGE_W(0, Wblk, kb + 256), STAGE_A(1, Ablk, aoff0, aoff1, kb + 320), 6);
-      STAGE(3, STAGE_W(1, Wblk, kb + 320), STAGE_A(2, Ablk, aoff0, aoff1, kb + 384), 6);
+      STAGE(0, STAGE_W(3, Wblk, kb + 192), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), VM_AFTER_EPILOGUE);
+      STAGE(1, STAGE_W(0, Wblk, kb + 256), STAGE_A(0, Ablk, aoff0, aoff1, kb + 256), VM_AFTER_EPILOGUE);
+      STAGE(2, STAGE_W(1, Wblk, kb + 320), STAGE_A(1, Ablk, aoff0, aoff1, kb + 320), VM8);
+      STAGE(3, STAGE_W(2, Wblk, kb + 384), STAGE_A(2, Ablk, aoff0, aoff1, kb + 384), VM8);
     }
     // ---- last four stages: the DMA crosses into the next tile (or re-fetches this one into dead slots) ----
     const int nidx = idx + G;
@@ -189,10 +208,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     }
     {
       const int kb = kend - 256;
-      STAGE(0, STAGE_W(2, Wblk, kb + 128), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), 6);
-      STAGE(1, STAGE_W(3, Wblk, kb + 192), STAGE_A(0, Anext, naoff0, naoff1, 0), 6);
-      STAGE(2, STAGE_W(0, Wnext, 0), STAGE_A(1, Anext, naoff0, naoff1, 64), 6);
-      STAGE(3, STAGE_W(1, Wnext, 64), STAGE_A(2, Anext, naoff0, naoff1, 128), 6);
+      STAGE(0, STAGE_W(3, Wblk, kb + 192), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), VM_AFTER_EPILOGUE);
+      STAGE(1, STAGE_W(0, Wnext, 0), STAGE_A(0, Anext, naoff0, naoff1, 0), VM_AFTER_EPILOGUE);
+      STAGE(2, STAGE_W(1, Wnext, 64), STAGE_A(1, Anext, naoff0, naoff1, 64), VM8);
+      STAGE(3, STAGE_W(2, Wnext, 128), STAGE_A(2, Anext, naoff0, naoff1, 128), VM8);
     }
     // pin the accumulators here: without a use in this block LLVM sinks the tail's 32 MFMAs below the conditional
     // barrier (all fragments live at once -> hundreds of spilled VGPRs)
@@ -317,6 +336,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant DMA before the LDS is released
       break;
     }
+    relax = (cur.m0 + BM <= p.M) ? 2 : 0;    // all 256 rows valid: every guarded row store above was issued
     idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext; aoff0 = naoff0; aoff1 = naoff1;
   }
 }
