@@ -2,8 +2,12 @@
 // block-scaled MFMA v_mfma_scale_f32_32x32x64_f8f6f4 (2x the bf16 MFMA rate) with all hardware block scales set to
 // 1.0 (E8M0 0x7f) and the real scales applied in the epilogue:  out = acc * sa[m] * sw[n] + bias[n]
 // (per-token activation scale, per-output-channel weight scale).  Operand / result lane maps were established on
-// hardware by tools/probes/fp8probe2.hip: lane l holds row l&31, 32 consecutive k bytes at 32*(l>>5); D as the
-// 32x32 bf16 form.
+// hardware by tools/probes/fp8probe2.hip: lane l holds row l&31 and 32 of its 64 k bytes; D as the 32x32 bf16 form.
+// With unit scales any assignment of k bytes to (lane half, register half) is correct as long as both operands use the
+// same one (this kernel gives lane half h the bytes [32h, 32h+32)).  The hardware's own order matters only for non-unit
+// block scales (tools/probes/fp8probe3-5.hip): bytes 0-15 of lanes 0-31 are k 0..15, bytes 0-15 of lanes 32-63 are
+// k 16..31, bytes 16-31 of lanes 0-31 are k 32..47, bytes 16-31 of lanes 32-63 are k 48..63; byte `opsel` of a lane's
+// scale register scales block l>>5 (k 32*(l>>5) .. +31) of row l&31 of that operand.
 //
 // Same structure as gemm_persist.hip: persistent 256x256 tiles, 8 waves as 2(M) x 4(N), 4-slot LDS ring of 64-BYTE
 // row stages (K = 64 fp8 elements per stage: the ring geometry, the LDS-DMA and the two-phase / half-phase-stagger
