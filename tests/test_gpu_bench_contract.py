@@ -1,0 +1,50 @@
+"""bench.py keeps the driver's contract: ONE JSON line with the agreed keys (N = 1), and the N > 1 control flow (barrier,
+max-over-ranks timing, whole-job value, the all-gather of results) works — exercised here with two ranks sharing the one
+GPU of the box over gloo (BENCH_DEVICE / BENCH_BACKEND hooks); the real multi-GPU run is one GPU per rank over RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(out: str):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]                      # exactly one JSON line on stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_keys(gpu):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--images", "32"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_json(p.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["unit"] == "images/s" and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "bf16" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 32 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-3      # value = images / timed seconds
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "traffic" in r and "kernel" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "images/s" and c["sample"]
+
+
+def test_two_ranks_report_the_whole_job(gpu):
+    env = dict(os.environ, BENCH_DEVICE="0", BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29571", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--images", "32",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 2 and "cpu_baseline" not in d
+    assert abs(d["value"] - 2 * 32 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-3  # both ranks' images over the max-over-ranks time
+    assert d["config"]["parallelism"] == "image-sharded x2"
