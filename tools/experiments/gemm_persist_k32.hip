@@ -1,34 +1,14 @@
-// Persistent bf16 "NT" GEMM (tile, MFMA mapping and epilogues as in gemm_bf16.hip; this file changes WHO runs
-// the tiles and HOW the operands are staged): one workgroup per CU walks a strided list of 256x256 tiles and keeps a
-// double-buffered K=64 stage pipeline running ACROSS tile boundaries (the last two stages of a tile already fetch
-// stages 0 and 1 of the next tile), so a tile costs main loop + epilogue only.
+// Persistent variant of the bf16 "NT" GEMM (see gemm_bf16.hip for the tile, LDS image and phase
+// schedule; this file only changes WHO runs the tiles): one workgroup per CU walks a strided list of
+// 256x256 tiles and keeps the 4-slot K=32 stage ring running ACROSS tile boundaries.  During the last
+// stages of a tile the LDS-DMA already fetches stages 0,1,2 of the next tile, so a tile costs main loop +
+// epilogue only: the per-workgroup launch gap (~3 us) and the cold prologue (~1.8 us) of the
+// one-tile-per-workgroup kernel (31 us per K=1024 tile, measured with in-kernel stamps) disappear.
 //
-// Staging: every LDS-DMA instruction fetches 8 rows x 128 B = 8 WHOLE cache lines (8 consecutive lanes per line).
-// The earlier K=32 ring fetched 16 rows x 64 B per instruction, i.e. half lines: same bytes, but twice the L1->L2 read
-// requests (rocprofv3 TCP_TCC_READ_REQ: 100.8 M vs 50.3 M per launch for the vendor kernel on the same shapes), and at
-// ~87 requests per clock the L2's request throughput, not the MFMA issue stream, set the pace of every variant of the
-// main loop that was tried.
-//
-// LDS (160 KiB): 2 buffers x (A 256 rows x 128 B | W 256 rows x 128 B) = 128 KiB | [128K,144K) AUX: EPI_LNFOLD raw row
-// statistics, 2 x [4 parts][256 rows][sum,sumsq] landed by LDS-DMA one tile ahead; EPI_RESID per-wave row partial sums
-// | [144K,160K) 8 wave-private 2 KiB images for the epilogue's layout change.
-// Buffer image: 1-KiB blocks of 8 rows x 128 B; 16-B chunk c of row r is stored at position c ^ (r & 6) of its row
-// (applied to the per-lane SOURCE address of the DMA and to the read address), which makes every ds_read_b128 of a
-// 16-row x 4-chunk fragment conflict-free (checked exhaustively against the lane-group table).
-//
-// One K=64 stage = 4 phases, each {fragment reads, DMA issue} lgkmcnt(0) s_barrier {16 MFMA} s_barrier, the two wave
-// rows half a phase apart (one extra barrier) so that one issues MFMAs while the other reads LDS:
-//   P1: W(k 0..31), A(rows half 0, k 0..31)   P2: A(half 1, k 0..31)   P3: W(k 32..63), A(half 1, k 32..63)
-//   P4: A(half 0, k 32..63)
-// so the W rows and the A rows of half 1 of a buffer are last read in P3, the A rows of half 0 in P4.  Stage s+2 is
-// fetched into the buffer of stage s: W and A(half 1) in P4 of stage s, A(half 0) in P1 of stage s+1; one counted
-// wait (vmcnt(6), before the first barrier of P4) retires stage s+1 one phase before its first read.
-// Ordering: a phase's reads are retired by lgkmcnt(0) BEFORE its first barrier, so rows are re-staged one phase after
-// their last read: when a wave issues DMA in phase p it has passed the second barrier of p-1, which the other wave row
-// only reaches after the first barrier of its own p-1, i.e. after its reads of p-1 have returned.  A stage is read one
-// phase after the wait that retired it (the later wave row waits one barrier later and reads one barrier later).
-// The epilogue's 16-17 row stores per wave are issued between the DMA of P4 and P1 and simply retire in order in
-// front of the next counted wait.
+// LDS (160 KiB): [0,128K) stage ring | [128K,144K) AUX: EPI_LNFOLD raw row statistics, 2 buffers x
+// [4 parts][256 rows][sum,sumsq] landed by LDS-DMA one tile ahead; EPI_RESID per-wave row partial sums |
+// [144K,160K) 8 wave-private 2 KiB images used to turn the MFMA fragment layout into whole 16-B row
+// chunks (and the residual the other way) one 16-row block at a time.
 #include <stdlib.h>
 
 #include "common.h"
@@ -37,8 +17,8 @@
 namespace {
 
 constexpr int BM = 256, BN = 256;
-constexpr int BUF = 65536, WREG = 32768;    // one K=64 stage: A region | W region
-constexpr int RING = 2 * BUF;               // 131072
+constexpr int STG = 32768, WPART = 16384;
+constexpr int RING = 4 * STG;               // 131072
 constexpr int AUX_OFF = RING;               // 16 KiB
 constexpr int TR_OFF = RING + 16384;        // 8 x 2 KiB
 constexpr int LDS_BYTES = RING + 32768;     // 163840
@@ -55,11 +35,9 @@ __device__ __forceinline__ float act_apply_t(float u) {
 }
 
 
-// One LDS-DMA piece: 64 lanes x 16 B from (uniform base in an SGPR pair + per-lane 32-bit offset) to 1 KiB of LDS at
-// lds_off.  Inline asm: the builtin makes a 64-bit VGPR address per piece (two VGPRs per offset plus temporaries, which
-// this kernel does not have), and every wait on these pieces is hand-placed anyway.
-__device__ __forceinline__ void glds16_at(const char* base, unsigned off, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_addr) : "memory");
+// uniform base (SGPR pair) + per-lane 32-bit unsigned offset: selects the saddr form of the DMA, no 64-bit VGPR address
+__device__ __forceinline__ void glds16(const char* base, unsigned off, char* smem, int lds_off) {
+  __builtin_amdgcn_global_load_lds(GLOBAL_PTR(base + off), LDS_PTR(lds_off), 16, 0, 0);
 }
 
 struct TileId { int m0, n0, tn; };
@@ -92,22 +70,16 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   const int nwg = tiles_m * tiles_n;
   const int G = gridDim.x;
   const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
-  const int kend = p.K * 2;                  // bytes along K; one stage = 128 B; K % 128 == 0 (stages come in pairs)
+  const int kend = p.K * 2;                  // bytes along K; one stage = 64 B; K % 128 == 0
 
-  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(0));   // LDS address of smem[0]
-  // LDS-DMA lane mapping: lane L fetches logical 16-B chunk (L&7) ^ ((L>>3)&6) of row L>>3 of an 8-row block
-  const int dg = lane >> 3;
-  const int dchunk16 = ((lane & 7) ^ (dg & 6)) * 16;
-  // A blocks of wave w (per row half h): q = 2w+i, i = 0,1 -> tile rows (w>>2)*128 + h*64 + (2(w&3)+i)*8 + dg
-  const int arow0 = (w >> 2) * 128 + (2 * (w & 3)) * 8 + dg;          // + h*64 + i*8
-  const int a_dma = ((w >> 2) * 16 + 2 * (w & 3)) * 1024;             // + (h*8 + i)*1024 (+ buffer)
-  // W blocks of wave w: rows 32w + 8i + dg, i = 0..3
-  const unsigned woff = (unsigned)((32 * w + dg) * ldw_b) + dchunk16;   // + i*8*ldw_b through the scalar base
-  const int w_dma = WREG + 4 * w * 1024;                               // + i*1024 (+ buffer)
-  // fragment reads: row frow, k-chunk kq of a 16-row block; the second k half (k 32..63) is the address ^ 64
-  const int rdl = (frow >> 3) * 1024 + (frow & 7) * 128 + ((((lane >> 4) ^ (frow & 6))) << 4);
-  const int a_rd0 = wr * 16 * 1024 + rdl, a_rd1 = a_rd0 ^ 64;
-  const int w_rd0 = WREG + wc * 8 * 1024 + rdl, w_rd1 = w_rd0 ^ 64;
+  // LDS-DMA lane mapping (see gemm_bf16.hip IMPL 2)
+  const int lrow = 16 * w + (lane >> 2);
+  const int lchunk16 = ((lane & 3) ^ (((lane >> 5) & 1) << 1)) * 16;
+  const int dma_lds = w * 1024;
+  const int rd = frow * 64 + (((lane >> 4) ^ ((frow >> 3) << 1)) << 4);
+  const int a_rd = wr * 8 * 1024 + rd;
+  const int w_rd = WPART + wc * 4 * 1024 + rd;
+  const unsigned woff0 = (unsigned)(lrow * ldw_b) + lchunk16, woff1 = (unsigned)((128 + lrow) * ldw_b) + lchunk16;
 
   // epilogue lane mapping: 16-row x 128-B image per wave, 16-B chunk index XOR row&7
   char* tr = smem + TR_OFF + w * 2048;
@@ -122,28 +94,20 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   TileId cur = decode_tile(idx, tiles_m, tiles_n);
   const char* Ablk = (const char*)p.A + (size_t)cur.m0 * lda_b;
   const char* Wblk = (const char*)p.W + (size_t)cur.n0 * ldw_b;
-#define AOFF(m0v, r) ((unsigned)((min((m0v) + (r), p.M - 1) - (m0v)) * lda_b) + dchunk16)
-  unsigned aoff00 = AOFF(cur.m0, arow0), aoff01 = AOFF(cur.m0, arow0 + 8);            // half 0, i = 0,1
-  unsigned aoff10 = AOFF(cur.m0, arow0 + 64), aoff11 = AOFF(cur.m0, arow0 + 72);      // half 1
+  unsigned aoff0 = (unsigned)((min(cur.m0 + lrow, p.M - 1) - cur.m0) * lda_b) + lchunk16;
+  unsigned aoff1 = (unsigned)((min(cur.m0 + 128 + lrow, p.M - 1) - cur.m0) * lda_b) + lchunk16;
 
-  // DMA pieces of one stage (buffer b, operand block pointers, byte offset along K)
-#define ISSUE_AH0(b, blk, o0, o1, kbyte)                                                    \
+#define STAGE_A(slot, blk, o0, o1, kbyte)                                                   \
   do {                                                                                      \
-    glds16((blk) + (kbyte), (o0), smem, (b) * BUF + a_dma);                                 \
-    glds16((blk) + (kbyte), (o1), smem, (b) * BUF + a_dma + 1024);                          \
+    glds16((blk) + (kbyte), (o0), smem, (slot) * STG + dma_lds);                            \
+    glds16((blk) + (kbyte), (o1), smem, (slot) * STG + 8192 + dma_lds);                     \
   } while (0)
-#define ISSUE_AH1(b, blk, o0, o1, kbyte)                                                    \
+#define STAGE_W(slot, blk, kbyte)                                                           \
   do {                                                                                      \
-    glds16((blk) + (kbyte), (o0), smem, (b) * BUF + a_dma + 8192);                          \
-    glds16((blk) + (kbyte), (o1), smem, (b) * BUF + a_dma + 9216);                          \
-  } while (0)
-#define ISSUE_W(b, blk, kbyte)                                                              \
-  do {                                                                                      \
-    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                        \
-      glds16((blk) + (kbyte) + (size_t)i_ * 8 * ldw_b, woff, smem, (b) * BUF + w_dma + i_ * 1024); \
+    glds16((blk) + (kbyte), woff0, smem, (slot) * STG + WPART + dma_lds);                   \
+    glds16((blk) + (kbyte), woff1, smem, (slot) * STG + WPART + 8192 + dma_lds);            \
   } while (0)
   // raw row statistics of a tile's 256 rows: parts x 2 KiB, fetched by waves 0 and 1 (EPI_LNFOLD)
-#define glds16(base, off, smem_, lds_off) glds16_at((base), (off), lds0 + (unsigned)(lds_off))
 #define STAGE_STATS(buf, m0v)                                                               \
   do {                                                                                      \
     if (EPI == EPI_LNFOLD && w < 2) {                                                        \
@@ -152,8 +116,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
                AUX_OFF + (buf) * 8192 + part * 2048 + w * 1024);                             \
     }                                                                                       \
   } while (0)
-#define LD_W(b, rdv) _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (b) * BUF + (rdv) + j * 2048);
-#define LD_A(b, half, rdv) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (b) * BUF + (rdv) + ((half) * 8 + i * 2) * 1024);
+#define LD_W(slot) _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (slot) * STG + w_rd + j * 1024);
+#define LD_A(slot, half) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (slot) * STG + a_rd + ((half) * 4 + i) * 1024);
 #define MMA(half)                                                                           \
   do {                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                          \
@@ -168,39 +132,45 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
-  // {reads retired} barrier {16 MFMA} barrier; the sched_barrier keeps the register-only MFMAs behind the s_barrier
-#define SYNC_MMA(half)                                                                      \
+  // one K=32 stage = two phases; ISSUE_W / ISSUE_A are the DMA statements of the phases, VM the counted wait
+#define STAGE(slot, ISSUE_W, ISSUE_A, WAIT_VM)                                              \
   do {                                                                                      \
-    WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0); MMA(half); BARRIER();         \
+    LD_W(slot) __builtin_amdgcn_sched_barrier(0); LD_A(slot, 0)                             \
+    ISSUE_W;                                                                                \
+    BARRIER(); WAIT_LDS(); MMA(0); BARRIER();                                               \
+    LD_A(slot, 1)                                                                           \
+    ISSUE_A;                                                                                \
+    WAIT_VM;                                                                                \
+    BARRIER(); WAIT_LDS(); MMA(1); BARRIER();                                               \
   } while (0)
-  // stage s+1 is retired here (its 8 pieces are older than the 6 just issued; vmcnt retires in order)
-#define VM6 asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
-#define ISSUE_P4(b, ablk, wblk, o10, o11, kbyte)                                            \
-  do { ISSUE_W(b, wblk, kbyte); ISSUE_AH1(b, ablk, o10, o11, kbyte); } while (0)
-  // one K=64 stage on buffer b = four phases; P1_ISSUE: A(half 0) of the next stage into the other buffer,
-  // P4_ISSUE: W and A(half 1) of the stage after that into this buffer
-#define STAGE(b, P1_ISSUE, P4_ISSUE)                                                        \
+  // Both parts of stage t+3 are issued in stage t (W in phase a, A in phase b); the counted wait leaves stages t+2 and t+3
+  // in flight (4 x 2 pieces) and retires stage t+1.
+#define VM8 asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+  // First two stages after an epilogue: the pieces they need (stages 1 and 2 of the new tile) were issued BEFORE the
+  // epilogue's stores, and vmcnt retires in order -- so when every wave issued exactly its 16 row stores (17 for the
+  // waves that also write EPI_RESID statistics) the wait may leave those outstanding as well, and the stores get two
+  // and a half stage times to drain instead of stalling the ring (1.9 us per tile, tools/gemm_stamps.py).
+#define VM_AFTER_EPILOGUE                                                                   \
   do {                                                                                      \
-    LD_W(b, w_rd0) __builtin_amdgcn_sched_barrier(0); LD_A(b, 0, a_rd0)                     \
-    P1_ISSUE;                                                                               \
-    SYNC_MMA(0);                                                                            \
-    LD_A(b, 1, a_rd0)                                                                       \
-    SYNC_MMA(1);                                                                            \
-    LD_W(b, w_rd1) __builtin_amdgcn_sched_barrier(0); LD_A(b, 1, a_rd1)                     \
-    SYNC_MMA(1);                                                                            \
-    LD_A(b, 0, a_rd1)                                                                       \
-    P4_ISSUE;                                                                               \
-    VM6;                                                                                    \
-    SYNC_MMA(0);                                                                            \
+    /* one opaque instruction for the compiler (a real branch here splits every stage into basic blocks and costs   */ \
+    /* ~20 spilled VGPRs): sel 0 -> vmcnt(8), 1 -> vmcnt(24), 2 -> vmcnt(25); only in the first two stages of a tile */ \
+    const int sel_ = __builtin_amdgcn_readfirstlane(relax > 0 ? relax_sel : 0);                                          \
+    relax = relax > 0 ? relax - 1 : 0;                                                      \
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lvm8_%=\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Lvm24_%=\n\t"          \
+                 "s_waitcnt vmcnt(25)\n\ts_branch .Lvmend_%=\n.Lvm24_%=:\n\ts_waitcnt vmcnt(24)\n\ts_branch .Lvmend_%=\n"       \
+                 ".Lvm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lvmend_%=:" : : "s"(sel_) : "memory", "scc");                                  \
   } while (0)
 
   // ---- cold prologue of the first tile ----
   int tile_iter = 0;
   STAGE_STATS(0, cur.m0);
-  ISSUE_AH0(0, Ablk, aoff00, aoff01, 0); ISSUE_AH1(0, Ablk, aoff10, aoff11, 0); ISSUE_W(0, Wblk, 0);
-  ISSUE_P4(1, Ablk, Wblk, aoff10, aoff11, 128);          // A(half 0) of stage 1 follows in P1 of stage 0
-  VM6;
+  STAGE_A(0, Ablk, aoff0, aoff1, 0); STAGE_W(0, Wblk, 0);
+  STAGE_A(1, Ablk, aoff0, aoff1, 64); STAGE_W(1, Wblk, 64);
+  STAGE_A(2, Ablk, aoff0, aoff1, 128); STAGE_W(2, Wblk, 128);
+  VM8;
   BARRIER();
+  int relax = 0;                             // stages of the coming tile that may leave the previous tile's stores in flight
+  const int relax_sel = (EPI == EPI_RESID && w < 4) ? 2 : 1;   // those waves also write the row statistics: 17 stores, not 16
 
   for (;;) {
     f32x4_t acc[8][4];
@@ -214,29 +184,33 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
     for (int kb = 0; kb < kend - 256; kb += 256) {
-      STAGE(0, ISSUE_AH0(1, Ablk, aoff00, aoff01, kb + 128), ISSUE_P4(0, Ablk, Wblk, aoff10, aoff11, kb + 256));
-      STAGE(1, ISSUE_AH0(0, Ablk, aoff00, aoff01, kb + 256), ISSUE_P4(1, Ablk, Wblk, aoff10, aoff11, kb + 384));
+      STAGE(0, STAGE_W(3, Wblk, kb + 192), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), VM_AFTER_EPILOGUE);
+      STAGE(1, STAGE_W(0, Wblk, kb + 256), STAGE_A(0, Ablk, aoff0, aoff1, kb + 256), VM_AFTER_EPILOGUE);
+      STAGE(2, STAGE_W(1, Wblk, kb + 320), STAGE_A(1, Ablk, aoff0, aoff1, kb + 320), VM8);
+      STAGE(3, STAGE_W(2, Wblk, kb + 384), STAGE_A(2, Ablk, aoff0, aoff1, kb + 384), VM8);
     }
-    // ---- last two stages: the DMA crosses into the next tile ----
+    // ---- last four stages: the DMA crosses into the next tile ----
     const int nidx = idx + G;
     const bool has_next = nidx < nwg;
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
-    unsigned naoff00 = aoff00, naoff01 = aoff01, naoff10 = aoff10, naoff11 = aoff11;
+    unsigned naoff0 = aoff0, naoff1 = aoff1;
     if (has_next) {
       nxt = decode_tile(nidx, tiles_m, tiles_n);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
-      naoff00 = AOFF(nxt.m0, arow0); naoff01 = AOFF(nxt.m0, arow0 + 8);
-      naoff10 = AOFF(nxt.m0, arow0 + 64); naoff11 = AOFF(nxt.m0, arow0 + 72);
+      naoff0 = (unsigned)((min(nxt.m0 + lrow, p.M - 1) - nxt.m0) * lda_b) + lchunk16;
+      naoff1 = (unsigned)((min(nxt.m0 + 128 + lrow, p.M - 1) - nxt.m0) * lda_b) + lchunk16;
     }
     {
       const int kb = kend - 256;
       // ONE code path: without a next tile the DMA harmlessly re-fetches this tile's first stages into dead
-      // buffers (two variants of this block made hipcc spill ~270 VGPRs)
+      // slots (two variants of this block made hipcc spill ~270 VGPRs)
       if (has_next) STAGE_STATS((tile_iter + 1) & 1, nxt.m0);
-      STAGE(0, ISSUE_AH0(1, Ablk, aoff00, aoff01, kb + 128), ISSUE_P4(0, Anext, Wnext, naoff10, naoff11, 0));
-      STAGE(1, ISSUE_AH0(0, Anext, naoff00, naoff01, 0), ISSUE_P4(1, Anext, Wnext, naoff10, naoff11, 128));
+      STAGE(0, STAGE_W(3, Wblk, kb + 192), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), VM_AFTER_EPILOGUE);
+      STAGE(1, STAGE_W(0, Wnext, 0), STAGE_A(0, Anext, naoff0, naoff1, 0), VM_AFTER_EPILOGUE);
+      STAGE(2, STAGE_W(1, Wnext, 64), STAGE_A(1, Anext, naoff0, naoff1, 64), VM8);
+      STAGE(3, STAGE_W(2, Wnext, 128), STAGE_A(2, Anext, naoff0, naoff1, 128), VM8);
     }
     if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 5] = __builtin_amdgcn_s_memtime(); }
@@ -365,8 +339,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant DMA before the LDS is released
       break;
     }
-    idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
-    aoff00 = naoff00; aoff01 = naoff01; aoff10 = naoff10; aoff11 = naoff11;
+    relax = (cur.m0 + BM <= p.M && p.dbg == nullptr) ? 2 : 0;   // all 256 rows valid: every guarded store above was issued
+    idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext; aoff0 = naoff0; aoff1 = naoff1;
     ++tile_iter;
   }
 }
