@@ -21,14 +21,14 @@
 //   P1: W(k 0..31), A(rows half 0, k 0..31)   P2: A(half 1, k 0..31)   P3: W(k 32..63), A(half 1, k 32..63)
 //   P4: A(half 0, k 32..63)
 // so the W rows and the A rows of half 1 of a buffer are last read in P3, the A rows of half 0 in P4.  Stage s+2 is
-// fetched into the buffer of stage s: W and A(half 1) in P4 of stage s, A(half 0) in P1 of stage s+1; one counted
-// wait (vmcnt(6), before the first barrier of P4) retires stage s+1 one phase before its first read.
+// fetched into the buffer of stage s: W and A(half 1) in P4 of stage s, A(half 0) right behind P4; one counted wait
+// (vmcnt(6), before the first barrier of P4) retires stage s+1 one phase before its first read.
 // Ordering: a phase's reads are retired by lgkmcnt(0) BEFORE its first barrier, so rows are re-staged one phase after
 // their last read: when a wave issues DMA in phase p it has passed the second barrier of p-1, which the other wave row
 // only reaches after the first barrier of its own p-1, i.e. after its reads of p-1 have returned.  A stage is read one
 // phase after the wait that retired it (the later wave row waits one barrier later and reads one barrier later).
-// The epilogue's 16-17 row stores per wave are issued between the DMA of P4 and P1 and simply retire in order in
-// front of the next counted wait.
+// Across a tile boundary stages 0 and 1 of the next tile are complete in the pipeline BEFORE the epilogue's stores are
+// issued, so the first counted wait of the new tile may leave those 16-17 stores outstanding (vmcnt retires in order).
 #include <stdlib.h>
 
 #include "common.h"
@@ -175,14 +175,26 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   } while (0)
   // stage s+1 is retired here (its 8 pieces are older than the 6 just issued; vmcnt retires in order)
 #define VM6 asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+  // First stage after an epilogue: stage 1 of the new tile was issued BEFORE the epilogue's stores, so when every wave
+  // issued exactly its 16 row stores (17 for the waves that also store EPI_RESID statistics) the wait may leave those
+  // outstanding as well, and the stores drain under four phases of MFMAs instead of stalling the pipeline at the head
+  // of every tile.  One opaque instruction for the compiler (a real branch here splits the stage into basic blocks and
+  // costs ~20 spilled VGPRs): sel 0 -> vmcnt(6), 1 -> vmcnt(22), 2 -> vmcnt(23).
+#define VM_FIRST                                                                            \
+  do {                                                                                      \
+    const int sel_ = __builtin_amdgcn_readfirstlane(relax);                                 \
+    relax = 0;                                                                              \
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lvm6_%=\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Lvm22_%=\n\t"          \
+                 "s_waitcnt vmcnt(23)\n\ts_branch .Lvmend_%=\n.Lvm22_%=:\n\ts_waitcnt vmcnt(22)\n\ts_branch .Lvmend_%=\n"       \
+                 ".Lvm6_%=:\n\ts_waitcnt vmcnt(6)\n.Lvmend_%=:" : : "s"(sel_) : "memory", "scc");                                  \
+  } while (0)
 #define ISSUE_P4(b, ablk, wblk, o10, o11, kbyte)                                            \
   do { ISSUE_W(b, wblk, kbyte); ISSUE_AH1(b, ablk, o10, o11, kbyte); } while (0)
-  // one K=64 stage on buffer b = four phases; P1_ISSUE: A(half 0) of the next stage into the other buffer,
-  // P4_ISSUE: W and A(half 1) of the stage after that into this buffer
-#define STAGE(b, P1_ISSUE, P4_ISSUE)                                                        \
+  // one K=64 stage on buffer b = four phases; P4_ISSUE: W and A(half 1) of stage s+2 into this buffer (their rows were
+  // last read in P3), POST_ISSUE: its A(half 0) rows once P4 is over
+#define STAGE(b, VMWAIT, P4_ISSUE, POST_ISSUE)                                              \
   do {                                                                                      \
     LD_W(b, w_rd0) __builtin_amdgcn_sched_barrier(0); LD_A(b, 0, a_rd0)                     \
-    P1_ISSUE;                                                                               \
     SYNC_MMA(0);                                                                            \
     LD_A(b, 1, a_rd0)                                                                       \
     SYNC_MMA(1);                                                                            \
@@ -190,17 +202,19 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     SYNC_MMA(1);                                                                            \
     LD_A(b, 0, a_rd1)                                                                       \
     P4_ISSUE;                                                                               \
-    VM6;                                                                                    \
+    VMWAIT;                                                                                 \
     SYNC_MMA(0);                                                                            \
+    POST_ISSUE;                                                                             \
   } while (0)
 
   // ---- cold prologue of the first tile ----
   int tile_iter = 0;
   STAGE_STATS(0, cur.m0);
-  ISSUE_AH0(0, Ablk, aoff00, aoff01, 0); ISSUE_AH1(0, Ablk, aoff10, aoff11, 0); ISSUE_W(0, Wblk, 0);
-  ISSUE_P4(1, Ablk, Wblk, aoff10, aoff11, 128);          // A(half 0) of stage 1 follows in P1 of stage 0
-  VM6;
+  ISSUE_AH0(0, Ablk, aoff00, aoff01, 0); ISSUE_P4(0, Ablk, Wblk, aoff10, aoff11, 0);
+  ISSUE_AH0(1, Ablk, aoff00, aoff01, 128); ISSUE_P4(1, Ablk, Wblk, aoff10, aoff11, 128);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   BARRIER();
+  int relax = 0;                             // 1 / 2: the coming tile's first wait may leave the previous tile's 16 / 17 stores in flight
 
   for (;;) {
     f32x4_t acc[8][4];
@@ -214,8 +228,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
     for (int kb = 0; kb < kend - 256; kb += 256) {
-      STAGE(0, ISSUE_AH0(1, Ablk, aoff00, aoff01, kb + 128), ISSUE_P4(0, Ablk, Wblk, aoff10, aoff11, kb + 256));
-      STAGE(1, ISSUE_AH0(0, Ablk, aoff00, aoff01, kb + 256), ISSUE_P4(1, Ablk, Wblk, aoff10, aoff11, kb + 384));
+      STAGE(0, VM_FIRST, ISSUE_P4(0, Ablk, Wblk, aoff10, aoff11, kb + 256), ISSUE_AH0(0, Ablk, aoff00, aoff01, kb + 256));
+      STAGE(1, VM6, ISSUE_P4(1, Ablk, Wblk, aoff10, aoff11, kb + 384), ISSUE_AH0(1, Ablk, aoff00, aoff01, kb + 384));
     }
     // ---- last two stages: the DMA crosses into the next tile ----
     const int nidx = idx + G;
@@ -231,12 +245,11 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       naoff10 = AOFF(nxt.m0, arow0 + 64); naoff11 = AOFF(nxt.m0, arow0 + 72);
     }
     {
-      const int kb = kend - 256;
       // ONE code path: without a next tile the DMA harmlessly re-fetches this tile's first stages into dead
       // buffers (two variants of this block made hipcc spill ~270 VGPRs)
       if (has_next) STAGE_STATS((tile_iter + 1) & 1, nxt.m0);
-      STAGE(0, ISSUE_AH0(1, Ablk, aoff00, aoff01, kb + 128), ISSUE_P4(0, Anext, Wnext, naoff10, naoff11, 0));
-      STAGE(1, ISSUE_AH0(0, Anext, naoff00, naoff01, 0), ISSUE_P4(1, Anext, Wnext, naoff10, naoff11, 128));
+      STAGE(0, VM_FIRST, ISSUE_P4(0, Anext, Wnext, naoff10, naoff11, 0), ISSUE_AH0(0, Anext, naoff00, naoff01, 0));
+      STAGE(1, VM6, ISSUE_P4(1, Anext, Wnext, naoff10, naoff11, 128), ISSUE_AH0(1, Anext, naoff00, naoff01, 128));
     }
     if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 5] = __builtin_amdgcn_s_memtime(); }
@@ -365,6 +378,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant DMA before the LDS is released
       break;
     }
+    // all 256 rows valid: every guarded store above was issued (the waves of EPI_RESID that store statistics issued 17)
+    relax = (cur.m0 + BM <= p.M && p.dbg == nullptr) ? ((EPI == EPI_RESID && w < 4) ? 2 : 1) : 0;
     idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
     aoff00 = naoff00; aoff01 = naoff01; aoff10 = naoff10; aoff11 = naoff11;
     ++tile_iter;
