@@ -9,19 +9,23 @@
 // k 16..31, bytes 16-31 of lanes 0-31 are k 32..47, bytes 16-31 of lanes 32-63 are k 48..63; byte `opsel` of a lane's
 // scale register scales block l>>5 (k 32*(l>>5) .. +31) of row l&31 of that operand.
 //
-// Same structure as gemm_persist.hip: persistent 256x256 tiles, 8 waves as 2(M) x 4(N), 4-slot LDS ring of 64-BYTE
-// row stages (K = 64 fp8 elements per stage: the ring geometry, the LDS-DMA and the two-phase / half-phase-stagger
-// schedule are byte-for-byte those of the bf16 kernel), cross-tile DMA prefetch, bf16 output through a wave-private
-// LDS image.  Per stage and wave: 2 phases x 4 MFMAs of 64 cycles = the bf16 kernel's phase length at twice the K.
-// The 16-B chunk swizzle gets one more term (subtile parity) so that the 32-row fragment reads are conflict-free.
+// Same structure as gemm_persist.hip (read its header for the pipeline and its ordering argument): persistent 256x256
+// tiles, 8 waves as 2(M) x 4(N), two LDS buffers of 128-BYTE row stages (K = 128 fp8 elements per stage) filled by
+// LDS-DMA pieces of 8 rows x 128 B = 8 whole cache lines (the earlier 64-byte-row ring issued twice the L1->L2 read
+// requests for the same bytes), four phases per stage with the half-phase stagger of the two wave rows, stages 0-1 of
+// the next tile in the pipeline before the epilogue's stores, bf16 / e4m3 output through a wave-private LDS image.
+// Per stage and wave: 4 phases x 4 MFMAs of 64 cycles.  Buffer image: 1-KiB blocks of 8 rows x 128 B, 16-B chunk c of
+// row r at position c ^ ((r >> 1) & 7); a lane reads chunks (4kh + 2h, 4kh + 2h + 1) of its row: conflict-free for the
+// 32-row fragments (checked against the ds_read_b128 lane groups).  Every wave stages blocks of ONE parity (block index
+// = wave + 8i), so the swizzle term of the block parity is a per-wave constant of the DMA source offset.
 #include "common.h"
 #include "gemm.h"
 
 namespace {
 
 constexpr int BM = 256, BN = 256;
-constexpr int STG = 32768, WPART = 16384;
-constexpr int RING = 4 * STG;               // 131072
+constexpr int BUF = 65536, WREG = 32768;    // one K=128 stage: A region | W region
+constexpr int RING = 2 * BUF;               // 131072
 constexpr int TR_OFF = RING;                // 8 x 4 KiB wave-private images
 constexpr int LDS_BYTES = RING + 32768;     // 163840
 
@@ -37,13 +41,12 @@ __device__ __forceinline__ float act_apply_t(float u) {
   else return u;
 }
 
-// One LDS-DMA piece: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to 1 KiB of LDS at lds_off.
+// One LDS-DMA piece: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to 1 KiB of LDS at lds_addr.
 // Inline asm on purpose: behind the builtin, LLVM's waitcnt pass treats every later ds_read as possibly aliasing the
 // pieces in flight and puts `s_waitcnt vmcnt(0)` in front of the fragment reads of EVERY phase -- a full drain of the
-// prefetch ring twice per stage (it did so in this kernel; the ring's correctness is the hand-placed counted waits).
+// prefetch pipeline (it did so in this kernel; the pipeline's correctness is the hand-placed counted waits).
 // (m0 is written; nothing else in this file uses it.)
-__device__ __forceinline__ void glds16(const char* base, unsigned off, char* smem, int lds_off) {
-  const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(lds_off));
+__device__ __forceinline__ void glds16_at(const char* base, unsigned off, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_addr) : "memory");
 }
 
@@ -78,21 +81,23 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   const int nwg = tiles_m * tiles_n;
   const int G = gridDim.x;
   const size_t lda_b = (size_t)p.lda, ldw_b = (size_t)p.ldw;      // fp8: 1 byte per element
-  const int kend = p.K;                      // bytes along K; one stage = 64 B; K % 256 == 0 (>= 4 stages)
+  const int kend = p.K;                      // bytes along K; one stage = 128 B; K % 256 == 0 (stages come in pairs)
 
-  // LDS-DMA: instruction j of a part fills 1-KiB subtile 8j + w (16 rows x 64 B); LDS chunk lane&3 of row lane>>2
-  // holds logical chunk (lane&3) ^ (2*(row>>3)) ^ (subtile & 1)
-  const int lrow = 16 * w + (lane >> 2);
-  const unsigned lchunk16 = (unsigned)(((lane & 3) ^ (((lane >> 5) & 1) << 1) ^ (w & 1)) * 16);
-  const int dma_lds = w * 1024;
-  const unsigned woff0 = (unsigned)(lrow * ldw_b) + lchunk16, woff1 = (unsigned)((128 + lrow) * ldw_b) + lchunk16;
-  // fragment of a 32-row tile: lane (r32, h) reads the two 16-B chunks 2h, 2h+1 of row r32 (subtile r32>>4)
-  const int rr = r32 & 15;
-  const int swz = ((rr >> 3) << 1) ^ (r32 >> 4);
-  const int rd0 = (r32 >> 4) * 1024 + rr * 64 + (((2 * h) ^ swz) << 4);
-  const int rd1 = (r32 >> 4) * 1024 + rr * 64 + (((2 * h + 1) ^ swz) << 4);
-  const int a_base = wr * 8 * 1024;                      // + slot*STG + mt*2048
-  const int w_base = WPART + wc * 4 * 1024;              // + slot*STG + nt*2048
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(0));   // LDS address of smem[0]
+#define glds16(base, off, smem_, lds_off) glds16_at((base), (off), lds0 + (unsigned)(lds_off))
+  // LDS-DMA: lane L fetches logical chunk (L&7) ^ f of row L>>3 of an 8-row block, f = (block parity << 2) | (row >> 1);
+  // wave w stages the A blocks i*16 + h*8 + w (tile rows i*128 + h*64 + 8w, i = 0,1 per row half h) and the W blocks
+  // w + 8i (rows 8w + 64i, i = 0..3): all of parity w & 1
+  const int dg = lane >> 3;
+  const unsigned dchunk16 = (unsigned)(((lane & 7) ^ (((w & 1) << 2) | (dg >> 1))) * 16);
+  const int arow0 = 8 * w + dg;                          // + i*128 + h*64
+  const int a_dma = w * 1024;                            // + (i*16 + h*8)*1024 (+ buffer)
+  const unsigned woff = (unsigned)((8 * w + dg) * ldw_b) + dchunk16;   // + i*64*ldw_b through the scalar base
+  const int w_dma = WREG + w * 1024;                     // + i*8192 (+ buffer)
+  // fragment of a 32-row tile: lane (r32, h) reads the 16-B chunks 4kh + 2h and 4kh + 2h + 1 of row r32
+  const int rd0 = (r32 >> 3) * 1024 + (r32 & 7) * 128 + ((((2 * h) ^ ((r32 >> 1) & 7))) << 4);   // kh = 0; second chunk ^16, kh = 1 ^64
+  const int a_base = wr * 16 * 1024;                     // + buffer + mt*4096
+  const int w_base = WREG + wc * 8 * 1024;               // + buffer + nt*4096
 
   // epilogue image: [32 rows][128 B] per wave, 16-B chunk index XOR row&7
   char* tr = smem + TR_OFF + w * 4096;
@@ -106,27 +111,35 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   TileId cur = decode_tile(idx, tiles_m, tiles_n);
   const char* Ablk = (const char*)p.A + (size_t)cur.m0 * lda_b;
   const char* Wblk = (const char*)p.W + (size_t)cur.n0 * ldw_b;
-  unsigned aoff0 = (unsigned)((min(cur.m0 + lrow, p.M - 1) - cur.m0) * lda_b) + lchunk16;
-  unsigned aoff1 = (unsigned)((min(cur.m0 + 128 + lrow, p.M - 1) - cur.m0) * lda_b) + lchunk16;
+#define AOFF(m0v, r) ((unsigned)((min((m0v) + (r), p.M - 1) - (m0v)) * lda_b) + dchunk16)
+  unsigned aoff00 = AOFF(cur.m0, arow0), aoff01 = AOFF(cur.m0, arow0 + 128);          // half 0, i = 0,1
+  unsigned aoff10 = AOFF(cur.m0, arow0 + 64), aoff11 = AOFF(cur.m0, arow0 + 192);     // half 1
 
-#define STAGE_A(slot, blk, o0, o1, kbyte)                                                   \
+#define ISSUE_AH0(b, blk, o0, o1, kbyte)                                                    \
   do {                                                                                      \
-    glds16((blk) + (kbyte), (o0), smem, (slot) * STG + dma_lds);                            \
-    glds16((blk) + (kbyte), (o1), smem, (slot) * STG + 8192 + dma_lds);                     \
+    glds16((blk) + (kbyte), (o0), smem, (b) * BUF + a_dma);                                 \
+    glds16((blk) + (kbyte), (o1), smem, (b) * BUF + a_dma + 16384);                         \
   } while (0)
-#define STAGE_W(slot, blk, kbyte)                                                           \
+#define ISSUE_AH1(b, blk, o0, o1, kbyte)                                                    \
   do {                                                                                      \
-    glds16((blk) + (kbyte), woff0, smem, (slot) * STG + WPART + dma_lds);                   \
-    glds16((blk) + (kbyte), woff1, smem, (slot) * STG + WPART + 8192 + dma_lds);            \
+    glds16((blk) + (kbyte), (o0), smem, (b) * BUF + a_dma + 8192);                          \
+    glds16((blk) + (kbyte), (o1), smem, (b) * BUF + a_dma + 24576);                         \
   } while (0)
-#define LD_FRAG(dst, off)                                                                   \
+#define ISSUE_W(b, blk, kbyte)                                                              \
   do {                                                                                      \
-    const uint4 lo_ = *(const uint4*)(smem + (off) + rd0);                                  \
-    const uint4 hi_ = *(const uint4*)(smem + (off) + rd1);                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                        \
+      glds16((blk) + (kbyte) + (size_t)i_ * 64 * ldw_b, woff, smem, (b) * BUF + w_dma + i_ * 8192); \
+  } while (0)
+#define ISSUE_P4(b, ablk, wblk, o10, o11, kbyte)                                            \
+  do { ISSUE_W(b, wblk, kbyte); ISSUE_AH1(b, ablk, o10, o11, kbyte); } while (0)
+#define LD_FRAG(dst, off, kh)                                                               \
+  do {                                                                                      \
+    const uint4 lo_ = *(const uint4*)(smem + (off) + (rd0 ^ ((kh) * 64)));                  \
+    const uint4 hi_ = *(const uint4*)(smem + (off) + (rd0 ^ ((kh) * 64) ^ 16));             \
     dst = i32x8_t{(int)lo_.x, (int)lo_.y, (int)lo_.z, (int)lo_.w, (int)hi_.x, (int)hi_.y, (int)hi_.z, (int)hi_.w}; \
   } while (0)
-#define LD_W(slot) _Pragma("unroll") for (int j = 0; j < 2; ++j) LD_FRAG(fb[j], (slot) * STG + w_base + j * 2048);
-#define LD_A(slot, half) _Pragma("unroll") for (int i = 0; i < 2; ++i) LD_FRAG(fa[i], (slot) * STG + a_base + ((half) * 2 + i) * 2048);
+#define LD_W(b, kh) _Pragma("unroll") for (int j = 0; j < 2; ++j) LD_FRAG(fb[j], (b) * BUF + w_base + j * 4096, kh);
+#define LD_A(b, half, kh) _Pragma("unroll") for (int i = 0; i < 2; ++i) LD_FRAG(fa[i], (b) * BUF + a_base + ((half) * 2 + i) * 4096, kh);
 #define MMA(half)                                                                           \
   do {                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                          \
@@ -142,41 +155,48 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
-#define STAGE(slot, ISSUE_W, ISSUE_A, WAIT_VM)                                              \
+#define SYNC_MMA(half)                                                                      \
   do {                                                                                      \
-    LD_W(slot) __builtin_amdgcn_sched_barrier(0); LD_A(slot, 0)                             \
-    ISSUE_W;                                                                                \
-    BARRIER(); WAIT_LDS(); MMA(0); BARRIER();                                               \
-    LD_A(slot, 1)                                                                           \
-    ISSUE_A;                                                                                \
-    WAIT_VM;                                                                                \
-    BARRIER(); WAIT_LDS(); MMA(1); BARRIER();                                               \
+    WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0); MMA(half); BARRIER();         \
   } while (0)
-
-  // Both parts of stage t+3 are issued in stage t; the counted wait leaves stages t+2 and t+3 in flight (4 x 2 pieces).
-#define VM8 asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
-  // First two stages after an epilogue: what they need was issued before the epilogue's stores and vmcnt retires in
+  // one K=128 stage on buffer b = four phases (gemm_persist.hip): P4_ISSUE = W and A(half 1) of stage s+2 into this
+  // buffer, POST_ISSUE = its A(half 0) rows once P4 is over; VMWAIT retires stage s+1
+#define STAGE(b, VMWAIT, P4_ISSUE, POST_ISSUE)                                              \
+  do {                                                                                      \
+    LD_W(b, 0) __builtin_amdgcn_sched_barrier(0); LD_A(b, 0, 0)                             \
+    SYNC_MMA(0);                                                                            \
+    LD_A(b, 1, 0)                                                                           \
+    SYNC_MMA(1);                                                                            \
+    LD_W(b, 1) __builtin_amdgcn_sched_barrier(0); LD_A(b, 1, 1)                             \
+    SYNC_MMA(1);                                                                            \
+    LD_A(b, 0, 1)                                                                           \
+    P4_ISSUE;                                                                               \
+    VMWAIT;                                                                                 \
+    SYNC_MMA(0);                                                                            \
+    POST_ISSUE;                                                                             \
+  } while (0)
+#define VM6 asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
+  // First stage after an epilogue: stages 0-1 of the tile were issued before the epilogue's stores and vmcnt retires in
   // order, so the wait may leave the NST row stores of a complete tile outstanding as well (see gemm_persist.hip); one
   // opaque instruction for the compiler.
   constexpr int NST = EPI == 2 ? 8 : 16;     // row stores per wave and tile
-#define VM_AFTER_EPILOGUE                                                                   \
+#define VM_FIRST                                                                            \
   do {                                                                                      \
-    const int sel_ = __builtin_amdgcn_readfirstlane(relax > 0 ? 1 : 0);                     \
-    relax = relax > 0 ? relax - 1 : 0;                                                      \
+    const int sel_ = __builtin_amdgcn_readfirstlane(relax);                                 \
+    relax = 0;                                                                              \
     if constexpr (NST == 16)                                                                \
-      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm8_%=\n\ts_waitcnt vmcnt(24)\n\ts_branch .Lf8end_%=\n"               \
-                   ".Lf8vm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lf8end_%=:" : : "s"(sel_) : "memory", "scc");                            \
+      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm6_%=\n\ts_waitcnt vmcnt(22)\n\ts_branch .Lf8end_%=\n"               \
+                   ".Lf8vm6_%=:\n\ts_waitcnt vmcnt(6)\n.Lf8end_%=:" : : "s"(sel_) : "memory", "scc");                            \
     else                                                                                    \
-      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm8_%=\n\ts_waitcnt vmcnt(16)\n\ts_branch .Lf8end_%=\n"               \
-                   ".Lf8vm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lf8end_%=:" : : "s"(sel_) : "memory", "scc");                            \
+      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm6_%=\n\ts_waitcnt vmcnt(14)\n\ts_branch .Lf8end_%=\n"               \
+                   ".Lf8vm6_%=:\n\ts_waitcnt vmcnt(6)\n.Lf8end_%=:" : : "s"(sel_) : "memory", "scc");                            \
   } while (0)
 
   // ---- cold prologue of the first tile ----
-  STAGE_A(0, Ablk, aoff0, aoff1, 0); STAGE_W(0, Wblk, 0);
-  STAGE_A(1, Ablk, aoff0, aoff1, 64); STAGE_W(1, Wblk, 64);
-  STAGE_A(2, Ablk, aoff0, aoff1, 128); STAGE_W(2, Wblk, 128);
-  VM8;
-  int relax = 0;                             // stages of the coming tile that may leave the previous tile's stores in flight
+  ISSUE_AH0(0, Ablk, aoff00, aoff01, 0); ISSUE_P4(0, Ablk, Wblk, aoff10, aoff11, 0);
+  ISSUE_AH0(1, Ablk, aoff00, aoff01, 128); ISSUE_P4(1, Ablk, Wblk, aoff10, aoff11, 128);
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  int relax = 0;                             // 1: the coming tile's first wait may leave the previous tile's stores in flight
   BARRIER();
 
   for (;;) {
@@ -192,30 +212,25 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
     for (int kb = 0; kb < kend - 256; kb += 256) {
-      STAGE(0, STAGE_W(3, Wblk, kb + 192), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), VM_AFTER_EPILOGUE);
-      STAGE(1, STAGE_W(0, Wblk, kb + 256), STAGE_A(0, Ablk, aoff0, aoff1, kb + 256), VM_AFTER_EPILOGUE);
-      STAGE(2, STAGE_W(1, Wblk, kb + 320), STAGE_A(1, Ablk, aoff0, aoff1, kb + 320), VM8);
-      STAGE(3, STAGE_W(2, Wblk, kb + 384), STAGE_A(2, Ablk, aoff0, aoff1, kb + 384), VM8);
+      STAGE(0, VM_FIRST, ISSUE_P4(0, Ablk, Wblk, aoff10, aoff11, kb + 256), ISSUE_AH0(0, Ablk, aoff00, aoff01, kb + 256));
+      STAGE(1, VM6, ISSUE_P4(1, Ablk, Wblk, aoff10, aoff11, kb + 384), ISSUE_AH0(1, Ablk, aoff00, aoff01, kb + 384));
     }
-    // ---- last four stages: the DMA crosses into the next tile (or re-fetches this one into dead slots) ----
+    // ---- last two stages: the DMA crosses into the next tile (or re-fetches this one into dead buffers) ----
     const int nidx = idx + G;
     const bool has_next = nidx < nwg;
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
-    unsigned naoff0 = aoff0, naoff1 = aoff1;
+    unsigned naoff00 = aoff00, naoff01 = aoff01, naoff10 = aoff10, naoff11 = aoff11;
     if (has_next) {
       nxt = decode_tile(nidx, tiles_m, tiles_n);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
-      naoff0 = (unsigned)((min(nxt.m0 + lrow, p.M - 1) - nxt.m0) * lda_b) + lchunk16;
-      naoff1 = (unsigned)((min(nxt.m0 + 128 + lrow, p.M - 1) - nxt.m0) * lda_b) + lchunk16;
+      naoff00 = AOFF(nxt.m0, arow0); naoff01 = AOFF(nxt.m0, arow0 + 128);
+      naoff10 = AOFF(nxt.m0, arow0 + 64); naoff11 = AOFF(nxt.m0, arow0 + 192);
     }
     {
-      const int kb = kend - 256;
-      STAGE(0, STAGE_W(3, Wblk, kb + 192), STAGE_A(3, Ablk, aoff0, aoff1, kb + 192), VM_AFTER_EPILOGUE);
-      STAGE(1, STAGE_W(0, Wnext, 0), STAGE_A(0, Anext, naoff0, naoff1, 0), VM_AFTER_EPILOGUE);
-      STAGE(2, STAGE_W(1, Wnext, 64), STAGE_A(1, Anext, naoff0, naoff1, 64), VM8);
-      STAGE(3, STAGE_W(2, Wnext, 128), STAGE_A(2, Anext, naoff0, naoff1, 128), VM8);
+      STAGE(0, VM_FIRST, ISSUE_P4(0, Anext, Wnext, naoff10, naoff11, 0), ISSUE_AH0(0, Anext, naoff00, naoff01, 0));
+      STAGE(1, VM6, ISSUE_P4(1, Anext, Wnext, naoff10, naoff11, 128), ISSUE_AH0(1, Anext, naoff00, naoff01, 128));
     }
     // pin the accumulators here: without a use in this block LLVM sinks the tail's 32 MFMAs below the conditional
     // barrier (all fragments live at once -> hundreds of spilled VGPRs)
@@ -340,8 +355,9 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant DMA before the LDS is released
       break;
     }
-    relax = (cur.m0 + BM <= p.M) ? 2 : 0;    // all 256 rows valid: every guarded row store above was issued
-    idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext; aoff0 = naoff0; aoff1 = naoff1;
+    relax = (cur.m0 + BM <= p.M) ? 1 : 0;    // all 256 rows valid: every guarded row store above was issued
+    idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
+    aoff00 = naoff00; aoff01 = naoff01; aoff10 = naoff10; aoff11 = naoff11;
   }
 }
 
