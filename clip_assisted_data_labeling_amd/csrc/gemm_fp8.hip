@@ -220,17 +220,17 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     const bool has_next = nidx < nwg;
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
-    unsigned naoff00 = aoff00, naoff01 = aoff01, naoff10 = aoff10, naoff11 = aoff11;
+    // (this tile's A offsets are dead from here on: the next tile's take their registers)
     if (has_next) {
       nxt = decode_tile(nidx, tiles_m, tiles_n);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
-      naoff00 = AOFF(nxt.m0, arow0); naoff01 = AOFF(nxt.m0, arow0 + 128);
-      naoff10 = AOFF(nxt.m0, arow0 + 64); naoff11 = AOFF(nxt.m0, arow0 + 192);
+      aoff00 = AOFF(nxt.m0, arow0); aoff01 = AOFF(nxt.m0, arow0 + 128);
+      aoff10 = AOFF(nxt.m0, arow0 + 64); aoff11 = AOFF(nxt.m0, arow0 + 192);
     }
     {
-      STAGE(0, VM_FIRST, ISSUE_P4(0, Anext, Wnext, naoff10, naoff11, 0), ISSUE_AH0(0, Anext, naoff00, naoff01, 0));
-      STAGE(1, VM6, ISSUE_P4(1, Anext, Wnext, naoff10, naoff11, 128), ISSUE_AH0(1, Anext, naoff00, naoff01, 128));
+      STAGE(0, VM_FIRST, ISSUE_P4(0, Anext, Wnext, aoff10, aoff11, 0), ISSUE_AH0(0, Anext, aoff00, aoff01, 0));
+      STAGE(1, VM6, ISSUE_P4(1, Anext, Wnext, aoff10, aoff11, 128), ISSUE_AH0(1, Anext, aoff00, aoff01, 128));
     }
     // pin the accumulators here: without a use in this block LLVM sinks the tail's 32 MFMAs below the conditional
     // barrier (all fragments live at once -> hundreds of spilled VGPRs)
@@ -357,7 +357,6 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     }
     relax = (cur.m0 + BM <= p.M) ? 1 : 0;    // all 256 rows valid: every guarded row store above was issued
     idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
-    aoff00 = naoff00; aoff01 = naoff01; aoff10 = naoff10; aoff11 = naoff11;
   }
 }
 

@@ -236,20 +236,20 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     const bool has_next = nidx < nwg;
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
-    unsigned naoff00 = aoff00, naoff01 = aoff01, naoff10 = aoff10, naoff11 = aoff11;
+    // (this tile's A offsets are dead from here on: the next tile's take their registers)
     if (has_next) {
       nxt = decode_tile(nidx, tiles_m, tiles_n);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
-      naoff00 = AOFF(nxt.m0, arow0); naoff01 = AOFF(nxt.m0, arow0 + 8);
-      naoff10 = AOFF(nxt.m0, arow0 + 64); naoff11 = AOFF(nxt.m0, arow0 + 72);
+      aoff00 = AOFF(nxt.m0, arow0); aoff01 = AOFF(nxt.m0, arow0 + 8);
+      aoff10 = AOFF(nxt.m0, arow0 + 64); aoff11 = AOFF(nxt.m0, arow0 + 72);
     }
     {
       // ONE code path: without a next tile the DMA harmlessly re-fetches this tile's first stages into dead
       // buffers (two variants of this block made hipcc spill ~270 VGPRs)
       if (has_next) STAGE_STATS((tile_iter + 1) & 1, nxt.m0);
-      STAGE(0, VM_FIRST, ISSUE_P4(0, Anext, Wnext, naoff10, naoff11, 0), ISSUE_AH0(0, Anext, naoff00, naoff01, 0));
-      STAGE(1, VM6, ISSUE_P4(1, Anext, Wnext, naoff10, naoff11, 128), ISSUE_AH0(1, Anext, naoff00, naoff01, 128));
+      STAGE(0, VM_FIRST, ISSUE_P4(0, Anext, Wnext, aoff10, aoff11, 0), ISSUE_AH0(0, Anext, aoff00, aoff01, 0));
+      STAGE(1, VM6, ISSUE_P4(1, Anext, Wnext, aoff10, aoff11, 128), ISSUE_AH0(1, Anext, aoff00, aoff01, 128));
     }
     if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 5] = __builtin_amdgcn_s_memtime(); }
@@ -381,7 +381,6 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     // all 256 rows valid: every guarded store above was issued (the waves of EPI_RESID that store statistics issued 17)
     relax = (cur.m0 + BM <= p.M && p.dbg == nullptr) ? ((EPI == EPI_RESID && w < 4) ? 2 : 1) : 0;
     idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
-    aoff00 = naoff00; aoff01 = naoff01; aoff10 = naoff10; aoff11 = naoff11;
     ++tile_iter;
   }
 }
