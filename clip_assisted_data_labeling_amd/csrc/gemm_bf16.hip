@@ -23,6 +23,8 @@
 // The two wave rows (wr = 0 / 1: the two waves of every SIMD) run half a phase apart, so one issues MFMAs
 // while the other issues LDS reads and DMA.  A slot is re-staged >= 2 phases after its last read; a stage is
 // read >= 1 phase after the wait that retired it.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm.h"
 

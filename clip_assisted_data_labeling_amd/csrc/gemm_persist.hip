@@ -58,7 +58,8 @@ __device__ __forceinline__ float act_apply_t(float u) {
 // One LDS-DMA piece: 64 lanes x 16 B from (uniform base in an SGPR pair + per-lane 32-bit offset) to 1 KiB of LDS at
 // lds_off.  Inline asm: the builtin makes a 64-bit VGPR address per piece (two VGPRs per offset plus temporaries, which
 // this kernel does not have), and every wait on these pieces is hand-placed anyway.
-__device__ __forceinline__ void glds16_at(const char* base, unsigned off, unsigned lds_addr) {
+__device__ __forceinline__ void glds16_at(const char* base, unsigned off, unsigned lds_addr_) {
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds_addr_);   // uniform by construction; tells the compiler so
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_addr) : "memory");
 }
 

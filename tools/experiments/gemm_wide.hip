@@ -1,14 +1,16 @@
-// bf16 "NT" GEMM, wide-wave variant of gemm_persist.hip: the same persistent 256x256 tiles, the same 4-slot K=32 LDS
-// ring fed by LDS-DMA across tile boundaries and the same three epilogues, but FOUR waves per workgroup (one per SIMD,
-// 2 x 2), each owning a 128 x 128 corner of the tile with its 256 accumulator registers in the upper half of the 512-entry
-// register file.  Against the eight-wave kernel (128 x 64 per wave) that is 1/3 less LDS fragment traffic per MFMA and
-// half the barrier participants.  One wave per SIMD has nobody to hide behind, so the stage is software-pipelined in
-// registers with single-buffered fragments and a half-stage skew:
-//   pass 0 of stage s:  32 MFMAs (A rows 0..7 x W cols 0..3) | reads fb[4..7](s) | the wave's 8 DMA pieces of stage s+3
-//   wait for the wave's pieces of stage s+1, barrier
-//   pass 1 of stage s:  32 MFMAs (A rows 0..7 x W cols 4..7) | fa[i](s+1) after row i, fb[0..3](s+1)
-// A ring slot is read during pass 1 of the stage before and pass 0 of its own stage, so the slot refilled in pass 0 of
-// stage s (stage s+3 -> slot (s-1)&3) was released by the barrier of stage s-1.
+// bf16 "NT" GEMM, wide-wave variant of gemm_persist.hip: the same persistent 256x256 tiles, the same two LDS buffers of
+// K=64 stages (8-row x 128-B blocks, every LDS-DMA piece = 8 whole cache lines, chunk swizzle c ^ (r & 6)) fed across
+// tile boundaries and the same three epilogues, but FOUR waves per workgroup (one per SIMD, 2 x 2), each owning a
+// 128 x 128 corner of the tile with its 256 accumulator registers in the upper half of the 512-entry register file.
+// Against the eight-wave kernel (128 x 64 per wave) that is 1/3 less LDS fragment traffic per MFMA, half the waves and
+// ONE barrier per K=64 stage.  One wave per SIMD has nobody to hide behind, so a stage is software-pipelined in
+// registers with single-buffered fragments; per stage s (buffer b) and wave, two K=32 halves of two passes each:
+//   H0 pass 0: 32 MFMAs (A rows 0..7 x W cols 0..3)   | reads fb[4..7](s, k 0..31)
+//   H0 pass 1: 32 MFMAs (cols 4..7)                   | reads fa[i](s, k 32..63) behind row i, fb[0..3](s, k 32..63)
+//   H1 pass 0: 32 MFMAs (cols 0..3)                   | reads fb[4..7](s, k 32..63)
+//   wait for the wave's 16 pieces of stage s+1, lgkmcnt(0), barrier      (buffer b is dead, buffer b^1 has landed)
+//   H1 pass 1: 32 MFMAs (cols 4..7)                   | reads fa[i], fb[0..3](s+1, k 0..31) | the 16 pieces of stage s+2 -> b
+#include <stdlib.h>
 #include <stdlib.h>
 
 #include "common.h"
@@ -17,8 +19,8 @@
 namespace {
 
 constexpr int BM = 256, BN = 256;
-constexpr int STG = 32768, WPART = 16384;
-constexpr int RING = 4 * STG;               // 131072
+constexpr int BUF = 65536, WREG = 32768;    // one K=64 stage: A region | W region
+constexpr int RING = 2 * BUF;               // 131072
 constexpr int AUX_OFF = RING;               // 16 KiB: LNFOLD raw row statistics (2 buffers) / RESID per-wave-column row sums
 constexpr int TR_OFF = RING + 16384;        // 4 x 4 KiB wave-private images: 16 rows x 256 B
 constexpr int LDS_BYTES = RING + 32768;     // 163840
@@ -32,13 +34,13 @@ __device__ __forceinline__ float act_apply_t(float u) {
   else return u;
 }
 
-// One LDS-DMA piece: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to 1 KiB of LDS at lds_off.
+// One LDS-DMA piece: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) to 1 KiB of LDS at lds_addr.
 // Inline asm on purpose: behind the builtin LLVM books every LDS-DMA as a FLAT access pending on BOTH counters and, as
 // this kernel's vmcnt waits are hand-placed, never sees it retire -- every later LDS dependency then becomes
 // `s_waitcnt lgkmcnt(0)` instead of a counted wait, which serialises the register-pipelined fragment reads.
 // (m0 is written; nothing else in this file uses it.)
-__device__ __forceinline__ void glds16(const char* base, unsigned off, char* smem, int lds_off) {
-  const unsigned lds_addr = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(lds_off));
+__device__ __forceinline__ void glds16_at(const char* base, unsigned off, unsigned lds_addr_) {
+  const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds_addr_);   // uniform by construction; tells the compiler so
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_addr) : "memory");
 }
 
@@ -72,19 +74,19 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const GemmParams p) {
   const int nwg = tiles_m * tiles_n;
   const int G = gridDim.x;
   const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
-  const int kend = p.K * 2;                  // bytes along K; one stage = 64 B; K % 128 == 0 (stages % 4 == 0)
+  const int kend = p.K * 2;                  // bytes along K; one stage = 128 B; K % 128 == 0 (stages come in pairs)
 
-  // LDS-DMA: wave w fills the 1-KiB subtiles 4w..4w+3 (16 rows x 64 B) of both operands; LDS chunk lane&3 of row lane>>2
-  // holds logical 16-B chunk (lane&3) ^ (2*(row>>3))
-  const int lchunk16 = ((lane & 3) ^ (((lane >> 5) & 1) << 1)) * 16;
-  const int srow = 64 * w + (lane >> 2);                 // + 16*j
-  const int dma_lds = w * 4096;                          // + slot*STG (+ WPART) + j*1024
-  const int rd = frow * 64 + (((lane >> 4) ^ ((frow >> 3) << 1)) << 4);
-  const int a_rd = wr * 8 * 1024 + rd;                   // + slot*STG + i*1024
-  const int w_rd = WPART + wc * 8 * 1024 + rd;           // + slot*STG + j*1024
-  unsigned woff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) woff[j] = (unsigned)((srow + 16 * j) * ldw_b) + lchunk16;
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(0));   // LDS address of smem[0]
+  // LDS-DMA: lane L fetches logical 16-B chunk (L&7) ^ ((L>>3)&6) of row L>>3 of an 8-row block; wave w fills the blocks
+  // 8w..8w+7 (rows 64w + 8q + dg) of both operands: 16 pieces per stage
+  const int dg = lane >> 3;
+  const unsigned dchunk16 = (unsigned)(((lane & 7) ^ (dg & 6)) * 16);
+  const int drow0 = 64 * w + dg;                         // + 8q
+  const int dma_lds = 8 * w * 1024;                      // + buffer (+ WREG) + q*1024
+  const int rdl = (frow >> 3) * 1024 + (frow & 7) * 128 + (((qd ^ (frow & 6))) << 4);   // k 0..31; k 32..63 is ^64
+  const int a_rd = wr * 16 * 1024 + rdl;                 // + buffer + i*2048
+  const int w_rd = WREG + wc * 16 * 1024 + rdl;          // + buffer + j*2048
+  const unsigned woff = (unsigned)(drow0 * ldw_b) + dchunk16;   // + q*8*ldw_b through the scalar base
 
   // epilogue image: 16 rows x 256 B per wave, 16-B chunk index XOR row
   char* tr = smem + TR_OFF + w * 4096;
@@ -97,16 +99,21 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const GemmParams p) {
   TileId cur = decode_tile(idx, tiles_m, tiles_n);
   const char* Ablk = (const char*)p.A + (size_t)cur.m0 * lda_b;
   const char* Wblk = (const char*)p.W + (size_t)cur.n0 * ldw_b;
-  unsigned aoff[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) aoff[j] = (unsigned)((min(cur.m0 + srow + 16 * j, p.M - 1) - cur.m0) * lda_b) + lchunk16;
+  unsigned aoff[8], naoff[8];                 // this tile's / the next tile's clamped A row offsets
+#define SET_AOFF(o, m0v) _Pragma("unroll") for (int q_ = 0; q_ < 8; ++q_) o[q_] = (unsigned)((min((m0v) + drow0 + 8 * q_, p.M - 1) - (m0v)) * lda_b) + dchunk16
+  SET_AOFF(aoff, cur.m0);
 
-#define PIECE_A(slot, blk, o, kbyte, j) glds16((blk) + (kbyte), (o)[j], smem, (slot) * STG + dma_lds + (j) * 1024)
-#define PIECE_W(slot, blk, kbyte, j) glds16((blk) + (kbyte), woff[j], smem, (slot) * STG + WPART + dma_lds + (j) * 1024)
-#define STAGE_ALL(slot, ab, ao, wb, kbyte)                                                  \
+  // piece q of a stage: q < 8 = A block 8w+q, else W block 8w+q-8
+#define PIECE(b, ao, ablk, wblk, kbyte, q)                                                  \
   do {                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) { PIECE_A(slot, ab, ao, kbyte, j); PIECE_W(slot, wb, kbyte, j); } \
+    if ((q) < 8) glds16_at((ablk) + (kbyte), ao[(q) & 7], lds0 + (unsigned)((b) * BUF + dma_lds + ((q) & 7) * 1024)); \
+    else glds16_at((wblk) + (kbyte) + (size_t)((q) & 7) * 8 * ldw_b, woff, lds0 + (unsigned)((b) * BUF + WREG + dma_lds + ((q) & 7) * 1024)); \
   } while (0)
+#define STAGE_ALL(b, ablk, wblk, kbyte)                                                     \
+  do {                                                                                      \
+    _Pragma("unroll") for (int q_ = 0; q_ < 16; ++q_) PIECE(b, aoff, ablk, wblk, kbyte, q_); \
+  } while (0)
+#define glds16(base, off, smem_, lds_off) glds16_at((base), (off), lds0 + (unsigned)(lds_off))
   // raw row statistics of a tile's 256 rows: parts x 2 KiB, fetched by waves 0 and 1 (EPI_LNFOLD); always issued BEFORE
   // the stage's own pieces, so that the counted waits (newest 16 outstanding) only ever leave stage pieces in flight
 #define STAGE_STATS(buf, m0v)                                                               \
@@ -117,43 +124,66 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const GemmParams p) {
                AUX_OFF + (buf) * 8192 + part * 2048 + w * 1024);                             \
     }                                                                                       \
   } while (0)
-#define RD_A(slot, i) fa[i] = *(const frag_t*)(smem + (slot) * STG + a_rd + (i) * 1024)
-#define RD_W(slot, j) fb[j] = *(const frag_t*)(smem + (slot) * STG + w_rd + (j) * 1024)
+#define RD_A(b, kh, i) fa[i] = *(const frag_t*)(smem + (b) * BUF + (a_rd ^ ((kh) * 64)) + (i) * 2048)
+#define RD_W(b, kh, j) fb[j] = *(const frag_t*)(smem + (b) * BUF + (w_rd ^ ((kh) * 64)) + (j) * 2048)
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
 #define SB() __builtin_amdgcn_sched_barrier(0)
+  // The MFMA as an asm statement with the accumulator tied to an AGPR quad: with the builtin the register allocator
+  // rotated accumulators through arch VGPRs in this loop (hundreds of v_accvgpr_read/write/mov per iteration).
 #define MMA_ROW(i, j0)                                                                      \
   _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
-    acc[i][(j0) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[(j0) + j], fa[i], acc[i][(j0) + j], 0, 0, 0)
-  // stage on ring slot S; NS = slot of the next stage; the 8 DMA pieces of stage +3 go to slot (S+3)&3: piece index 0..3
-  // A, 4..7 W, written as the statement list DMA(q).  PREF = 0: last stage of a tile.
-#define PSTAGE(S, NS, DMA, PREF)                                                            \
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][(j0) + j]) : "v"(fb[(j0) + j]), "v"(fa[i]))
+  // stage s+1 retired: its 16 pieces are the wave's only outstanding ones (vmcnt(0)) -- except right after an epilogue,
+  // whose 32 row stores (33 with the EPI_RESID statistics) were issued BEHIND them and may stay in flight
+#define VM0 asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define VM_FIRST                                                                            \
+  do {                                                                                      \
+    const int sel_ = __builtin_amdgcn_readfirstlane(relax);                                 \
+    relax = 0;                                                                              \
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lwv0_%=\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Lwv32_%=\n\t"          \
+                 "s_waitcnt vmcnt(33)\n\ts_branch .Lwvend_%=\n.Lwv32_%=:\n\ts_waitcnt vmcnt(32)\n\ts_branch .Lwvend_%=\n"       \
+                 ".Lwv0_%=:\n\ts_waitcnt vmcnt(0)\n.Lwvend_%=:" : : "s"(sel_) : "memory", "scc");                                  \
+  } while (0)
+  // one K=64 stage on buffer b; the 16 pieces of stage s+2 (operand block pointers nab/nwb, byte offset nkb) go to buffer
+  // b behind the barrier.  PREF = 0: last stage of a tile (the next tile's first fragments are read at its top).
+#define WSTAGE(b, VMWAIT, nao, nab, nwb, nkb, PREF)                                              \
   do {                                                                                      \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                         \
-      MMA_ROW(i, 0);                                                                        \
-      SB();                                                                                 \
-      if (i < 4) RD_W(S, 4 + i);                                                            \
-      DMA(i);                                                                               \
+      MMA_ROW(i, 0); SB();                                                                  \
+      if (i < 4) RD_W(b, 0, 4 + i);                                                         \
       SB();                                                                                 \
     }                                                                                       \
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   /* stages +2, +3 may be in flight: stage +1 has landed */ \
-    BARRIER();                                                                              \
     _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                         \
-      MMA_ROW(i, 4);                                                                        \
+      MMA_ROW(i, 4); SB();                                                                  \
+      RD_A(b, 1, i);                                                                        \
+      if (i < 4) RD_W(b, 1, i);                                                             \
       SB();                                                                                 \
-      if (PREF) RD_A(NS, i);                                                                \
-      if (PREF && i < 4) RD_W(NS, i);                                                       \
+    }                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                         \
+      MMA_ROW(i, 0); SB();                                                                  \
+      if (i < 4) RD_W(b, 1, 4 + i);                                                         \
+      SB();                                                                                 \
+    }                                                                                       \
+    VMWAIT;                                                                                 \
+    BARRIER();                                                                              \
+    SB();                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                         \
+      MMA_ROW(i, 4); SB();                                                                  \
+      if (PREF) RD_A((b) ^ 1, 0, i);                                                        \
+      if (PREF && i < 4) RD_W((b) ^ 1, 0, i);                                               \
+      PIECE(b, nao, nab, nwb, nkb, 2 * i); PIECE(b, nao, nab, nwb, nkb, 2 * i + 1);                 \
       SB();                                                                                 \
     }                                                                                       \
   } while (0)
 
-  // ---- cold prologue of the first tile: stages 0, 1, 2 ----
+  // ---- cold prologue of the first tile: stages 0 and 1 ----
   int tile_iter = 0;
   STAGE_STATS(0, cur.m0);
-  STAGE_ALL(0, Ablk, aoff, Wblk, 0);
-  STAGE_ALL(1, Ablk, aoff, Wblk, 64);
-  STAGE_ALL(2, Ablk, aoff, Wblk, 128);
+  STAGE_ALL(0, Ablk, Wblk, 0);
+  STAGE_ALL(1, Ablk, Wblk, 128);
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   BARRIER();
+  int relax = 0;                             // 1 / 2: the coming tile's first wait may leave the previous tile's 32 / 33 stores in flight
 
   for (;;) {
     f32x4_t acc[8][8];
@@ -167,48 +197,35 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const GemmParams p) {
     const bool has_next = nidx < nwg;
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
-    unsigned naoff[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) naoff[j] = aoff[j];
     if (has_next) {
       nxt = decode_tile(nidx, tiles_m, tiles_n);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) naoff[j] = (unsigned)((min(nxt.m0 + srow + 16 * j, p.M - 1) - nxt.m0) * lda_b) + lchunk16;
       STAGE_STATS((tile_iter + 1) & 1, nxt.m0);
+      SET_AOFF(naoff, nxt.m0);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) naoff[q] = aoff[q];
     }
-    // fragments of the tile's first stage (slot 0 landed at least one barrier ago); fb[4..7] follow in its pass 0
+    // fragments of the tile's first half stage (buffer 0 landed at least one barrier ago); fb[4..7] follow in its pass 0
 #pragma unroll
-    for (int j = 0; j < 4; ++j) RD_W(0, j);
+    for (int j = 0; j < 4; ++j) RD_W(0, 0, j);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) RD_A(0, i);
+    for (int i = 0; i < 8; ++i) RD_A(0, 0, i);
     if (p.dbg && tid == 0) p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
-#define DMA_CUR(slot, kbyte) if (q < 4) PIECE_A(slot, Ablk, aoff, kbyte, q & 3); else PIECE_W(slot, Wblk, kbyte, q & 3)
-#define DMA_NXT(slot, kbyte) if (q < 4) PIECE_A(slot, Anext, naoff, kbyte, q & 3); else PIECE_W(slot, Wnext, kbyte, q & 3)
-#define D0(q_) { const int q = q_; DMA_CUR(3, kb + 192); }
-#define D1(q_) { const int q = q_; DMA_CUR(0, kb + 256); }
-#define D2(q_) { const int q = q_; DMA_CUR(1, kb + 320); }
-#define D3(q_) { const int q = q_; DMA_CUR(2, kb + 384); }
-#define E1(q_) { const int q = q_; DMA_NXT(0, 0); }
-#define E2(q_) { const int q = q_; DMA_NXT(1, 64); }
-#define E3(q_) { const int q = q_; DMA_NXT(2, 128); }
     for (int kb = 0; kb < kend - 256; kb += 256) {
-      PSTAGE(0, 1, D0, 1);
-      PSTAGE(1, 2, D1, 1);
-      PSTAGE(2, 3, D2, 1);
-      PSTAGE(3, 0, D3, 1);
+      WSTAGE(0, VM_FIRST, aoff, Ablk, Wblk, kb + 256, 1);
+      WSTAGE(1, VM0, aoff, Ablk, Wblk, kb + 384, 1);
     }
     {
-      // last four stages: the DMA crosses into the next tile (without one it re-fetches this tile's first stages into
-      // slots that nobody reads again -- one code path, see gemm_persist.hip)
-      const int kb = kend - 256;
-      PSTAGE(0, 1, D0, 1);
-      PSTAGE(1, 2, E1, 1);
-      PSTAGE(2, 3, E2, 1);
-      PSTAGE(3, 0, E3, 0);
+      // last two stages: the DMA crosses into the next tile (without one it re-fetches this tile's first stages into
+      // buffers that nobody reads again -- one code path, see gemm_persist.hip)
+      WSTAGE(0, VM_FIRST, naoff, Anext, Wnext, 0, 1);
+      WSTAGE(1, VM0, naoff, Anext, Wnext, 128, 0);
     }
+    // the MFMAs are asm statements: hipcc pads nothing between the last one and the epilogue's accumulator reads
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     if (p.dbg && tid == 0) p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime();
 
     // ------------------------------- epilogue of tile `cur` -------------------------------
@@ -337,9 +354,11 @@ __global__ __launch_bounds__(256) void gemm_wide_kernel(const GemmParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant DMA before the LDS is released
       break;
     }
+    // all 256 rows valid: every guarded store above was issued (32 row stores per wave, 33 with EPI_RESID statistics)
+    relax = (cur.m0 + BM <= p.M && p.dbg == nullptr) ? (EPI == EPI_RESID ? 2 : 1) : 0;
     idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) aoff[j] = naoff[j];
+    for (int q = 0; q < 8; ++q) aoff[q] = naoff[q];
     ++tile_iter;
   }
 }
