@@ -79,6 +79,9 @@ SIGNATURES = {
     "simsearch_distances": (c_int, [c_void_p, c_int, c_long, c_int, c_long, c_void_p, c_int, c_void_p, c_void_p]),
     "simsearch_topn_workspace": (c_size_t, [c_long, c_int]),
     "simsearch_topn": (c_int, [c_void_p, c_long, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "diversity_workspace": (c_size_t, [c_long]),
+    "diversity_order": (c_int, [c_void_p, c_long, c_int, c_long, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t,
+                                c_void_p]),
     "clipenc_op_attention_q": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "clipenc_op_quant_rows_fp8": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "clipenc_op_gemm_fp8_q": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,

@@ -762,6 +762,19 @@ int simsearch_topn(const float* dist_dev, long n, int top_n, long long* idx_out_
   return 0;
 }
 
+size_t diversity_workspace(long n) { return n < 1 ? 512 : ce_diversity_workspace_bytes(n); }
+
+int diversity_order(const float* emb_dev, long n, int d, long row_stride, int first, const int* samples_dev, int steps,
+                    int sample_size, int* order_dev, void* ws_dev, size_t ws_bytes, void* stream) {
+  if (!emb_dev || !order_dev || !ws_dev || (steps > 0 && !samples_dev)) return fail("diversity_order: NULL device pointer");
+  if (n < 1 || first < 0 || first >= n) return fail("diversity_order: first index %d outside [0, %ld)", first, n);
+  if (steps < 0 || sample_size < 1) return fail("diversity_order: steps %d / sample_size %d", steps, sample_size);
+  hipError_t err = ce_diversity_order(emb_dev, n, d, row_stride, first, samples_dev, steps, sample_size, order_dev, ws_dev, ws_bytes,
+                                      (hipStream_t)stream);
+  if (err != hipSuccess) return fail("diversity_order(n=%ld, d=%d, steps=%d) failed: %s", n, d, steps, hipGetErrorString(err));
+  return 0;
+}
+
 int clipenc_op_gemm_nt(const void* a_dev, const void* w_dev, int m, int n, int k, int dtype, int epi,
                        const float* bias_dev, void* out_dev, void* stream) {
   if (epi != CLIPENC_EPI_STORE_F32 && epi != CLIPENC_EPI_STORE_BF16) return fail("epi %d not exposed", epi);

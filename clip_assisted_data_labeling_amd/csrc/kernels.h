@@ -38,6 +38,11 @@ size_t ce_topn_workspace_bytes(long n, int top_n);
 hipError_t ce_topn_smallest(const float* dist, long n, int top_n, long long* out_i, float* out_v, void* ws, size_t ws_bytes,
                             hipStream_t stream);
 
+// diversity.hip
+size_t ce_diversity_workspace_bytes(long n);
+hipError_t ce_diversity_order(const float* emb, long n, int d, long ld, int first, const int* samples, int steps, int sample_size,
+                              int* order, void* ws, size_t ws_bytes, hipStream_t stream);
+
 // fcreg.hip
 #define CE_FC_MAX_LAYERS 8
 #define CE_FC_MAX_SEG 16

@@ -162,6 +162,18 @@ size_t simsearch_topn_workspace(long n, int top_n);
 int simsearch_topn(const float* dist_dev, long n, int top_n, long long* idx_out_dev, float* val_out_dev, void* ws_dev,
                    size_t ws_bytes, void* stream);
 
+/* Replaces the function diversity_ordered_image_files of /root/reference/_3_label_images.py:135-177, the "diversity" ordering of a fresh
+ * labeling session: starting from image `first`, `steps` times take the step's `sample_size` sampled candidates, and append
+ * the one whose largest cosine similarity to the images chosen so far is smallest (torch.argmin: the first minimum).
+ *   emb_dev      float32 [n] rows of d elements, row_stride elements apart (one crop of the packed [n][crops][E] store)
+ *   samples_dev  int32 [steps][sample_size] candidate indices (the host draws them as the reference does, random.sample)
+ *   order_dev    int32 [steps] out: the index appended at each step
+ *   ws_dev       scratch of diversity_workspace(n) bytes
+ * Asynchronous on `stream`; the walk's state (running maximum per image, last chosen index) never leaves the device. */
+size_t diversity_workspace(long n);
+int diversity_order(const float* emb_dev, long n, int d, long row_stride, int first, const int* samples_dev, int steps,
+                    int sample_size, int* order_dev, void* ws_dev, size_t ws_bytes, void* stream);
+
 
 /* GPU front end.  Replaces, for a decoded image that is already in HBM, the crop
  * extraction and the Resize + CenterCrop of the validation transform that the reference runs in its DataLoader
