@@ -47,7 +47,7 @@ def diversity_order(emb: np.ndarray, samples: Sequence[Sequence[int]], first: in
 
 def margins(emb: np.ndarray, samples, first: int = 0) -> np.ndarray:
     """Gap between the smallest and second smallest column maximum at every step (float64): a step whose gap is below the
-    fp32 accumulation-order noise (~1e-6) has no single right answer."""
+    fp32 accumulation-order noise (a few 1e-7) has no single right answer."""
     e = np.asarray(emb, dtype=np.float64)
     e = e / np.linalg.norm(e, axis=1, keepdims=True)
     order = diversity_order(emb, samples, first)
