@@ -15,8 +15,12 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {              // round-t
   __bf16 b = (__bf16)f;
   return __builtin_bit_cast(bf16_t, b);
 }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-  return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+  // one v_cvt_pk_bf16_f32 (RNE, as the scalar cast): two scalar casts + shift/or compiled to five VALU instructions per pair
+  const f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 // host-side bf16 rounding identical to the device cast (RNE)
