@@ -46,8 +46,7 @@ __device__ __forceinline__ float act_apply_t(float u) {
 // pieces in flight and puts `s_waitcnt vmcnt(0)` in front of the fragment reads of EVERY phase -- a full drain of the
 // prefetch pipeline (it did so in this kernel; the pipeline's correctness is the hand-placed counted waits).
 // (m0 is written; nothing else in this file uses it.)
-__device__ __forceinline__ void glds16_at(const char* base, unsigned off, unsigned lds_addr_) {
-  const unsigned lds_addr = __builtin_amdgcn_readfirstlane(lds_addr_);   // uniform by construction; tells the compiler so
+__device__ __forceinline__ void glds16_at(const char* base, unsigned off, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_addr) : "memory");
 }
 

@@ -11,7 +11,7 @@
 //
 // LDS (160 KiB): 2 buffers x (A 256 rows x 128 B | W 256 rows x 128 B) = 128 KiB | [128K,144K) AUX: EPI_LNFOLD raw row
 // statistics, 2 x [4 parts][256 rows][sum,sumsq] landed by LDS-DMA one tile ahead; EPI_RESID per-wave row partial sums
-// | [144K,160K) 8 wave-private 2 KiB images for the epilogue's layout change.
+// (the epilogue needs no LDS image: 8-byte fragment pieces become 16-byte row pieces by one lane exchange).
 // Buffer image: 1-KiB blocks of 8 rows x 128 B; 16-B chunk c of row r is stored at position c ^ (r & 6) of its row
 // (applied to the per-lane SOURCE address of the DMA and to the read address), which makes every ds_read_b128 of a
 // 16-row x 4-chunk fragment conflict-free (checked exhaustively against the lane-group table).
@@ -40,8 +40,7 @@ constexpr int BM = 256, BN = 256;
 constexpr int BUF = 65536, WREG = 32768;    // one K=64 stage: A region | W region
 constexpr int RING = 2 * BUF;               // 131072
 constexpr int AUX_OFF = RING;               // 16 KiB
-constexpr int TR_OFF = RING + 16384;        // 8 x 2 KiB
-constexpr int LDS_BYTES = RING + 32768;     // 163840
+constexpr int LDS_BYTES = RING + 16384;     // 147456
 
 #define LDS_PTR(off) ((__attribute__((address_space(3))) void*)(smem + (off)))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -109,14 +108,14 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   const int a_rd0 = wr * 16 * 1024 + rdl, a_rd1 = a_rd0 ^ 64;
   const int w_rd0 = WREG + wc * 8 * 1024 + rdl, w_rd1 = w_rd0 ^ 64;
 
-  // epilogue lane mapping: 16-row x 128-B image per wave, 16-B chunk index XOR row&7
-  char* tr = smem + TR_OFF + w * 2048;
+  // epilogue lane mapping.  A lane (frow, qd) holds row frow, columns 16 nt + 4 qd + (0..3) of a 16-row block: 8-byte
+  // pieces.  One v_permlane16_swap per dword and pair of column blocks (nt, nt+1) exchanges with the lane 16 away (qd ^ 1):
+  // lanes with even qd then hold columns 16 nt + 4 qd .. + 7, lanes with odd qd columns 16 (nt+1) + 4 (qd-1) .. + 7 -- 16
+  // contiguous bytes per lane, so a block leaves in two 16-B stores per lane (and the residual arrives in two 16-B loads
+  // and the same swap, which is its own inverse) without a trip through LDS.  (The earlier row-major LDS image cost the
+  // epilogue its LDS write time -- ds_write_b64 moves ~85 B/clk/CU -- in front of the store time.)
   const int qd = lane >> 4;
-  const int tw_base = frow * 128 + (qd & 1) * 8;
-  const int tw_sw = frow & 7;
-  const int tr_base = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // + 1024 for rows 8..15
-  const int row_l = lane >> 3;
-#define TW_ADDR(nt) (tr + tw_base + ((((nt) * 2 + (qd >> 1)) ^ tw_sw) << 4))
+  const int ecol = (qd >> 1) * 8 + (qd & 1) * 16;        // first column of the lane's 16-B piece (+32: second piece)
 
   int idx = blockIdx.x;
   TileId cur = decode_tile(idx, tiles_m, tiles_n);
@@ -154,11 +153,13 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   } while (0)
 #define LD_W(b, rdv) _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (b) * BUF + (rdv) + j * 2048);
 #define LD_A(b, half, rdv) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (b) * BUF + (rdv) + ((half) * 8 + i * 2) * 1024);
-#define MMA_ROWS(half, i0, i1)                                                              \
+#define MMA(half)                                                                           \
   do {                                                                                      \
-    _Pragma("unroll") for (int i = (i0); i < (i1); ++i)                                     \
+    __builtin_amdgcn_s_setprio(1);                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
       acc[(half) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[(half) * 4 + i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                          \
   } while (0)
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
 #define WAIT_LDS()                                                                          \
@@ -166,15 +167,10 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
-  // {reads retired} barrier {16 MFMA} barrier; the sched_barrier keeps the register-only MFMAs behind the s_barrier.
-  // Measured alternatives: handing over early (the second barrier in front of the last four MFMAs) was 8 % SLOWER end to
-  // end; refilling the W fragments inside P2's MFMA section (W fragment as the outer loop), so that P3 waits for 4 reads
-  // instead of 8, changed nothing (1689 vs 1689 images/s).
+  // {reads retired} barrier {16 MFMA} barrier; the sched_barrier keeps the register-only MFMAs behind the s_barrier
 #define SYNC_MMA(half)                                                                      \
   do {                                                                                      \
-    WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0);                               \
-    __builtin_amdgcn_s_setprio(1); MMA_ROWS(half, 0, 4); __builtin_amdgcn_s_setprio(0);     \
-    BARRIER();                                                                              \
+    WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0); MMA(half); BARRIER();         \
   } while (0)
   // stage s+1 is retired here (its 8 pieces are older than the 6 just issued; vmcnt retires in order)
 #define VM6 asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
@@ -261,7 +257,12 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     const int q4 = qd * 4;
     const int ncol0 = cur.n0 + wc * 64 + q4;         // + nt*16
     const int mw0 = cur.m0 + wr * 128;               // first row of the wave tile
-    const size_t gcol = (size_t)cur.n0 + wc * 64 + (lane & 7) * 8;
+    const size_t gcol = (size_t)cur.n0 + wc * 64 + ecol;
+#define SWAP16(a_, b_)                                                                        \
+  do {                                                                                        \
+    const auto r_ = __builtin_amdgcn_permlane16_swap((a_), (b_), false, false);               \
+    (a_) = r_[0]; (b_) = r_[1];                                                               \
+  } while (0)
 
     if constexpr (EPI == EPI_LNFOLD) {
       // (mean, rstd) of the tile's rows from the raw partial sums that the DMA left in AUX[buf]
@@ -292,13 +293,13 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       for (int nt = 0; nt < 4; ++nt) bs[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
 
-    // residual rows, 8 x 16 B per lane in flight (four 16-row blocks ahead of their use)
+    // residual pieces, 8 x 16 B per lane in flight (four 16-row blocks ahead of their use): piece k = block k>>1, half k&1
     uint4 rres[8];
 #define LOAD_RES(k)                                                                           \
   do {                                                                                        \
-    const int m_ = mw0 + (k) * 8 + row_l;                                                     \
+    const int m_ = mw0 + ((k) >> 1) * 16 + frow;                                              \
     rres[(k) & 7] = uint4{0, 0, 0, 0};                                                        \
-    if (m_ < p.M) rres[(k) & 7] = *(const uint4*)((const bf16_t*)p.resid + (size_t)m_ * p.ldo + gcol); \
+    if (m_ < p.M) rres[(k) & 7] = *(const uint4*)((const bf16_t*)p.resid + (size_t)m_ * p.ldo + gcol + ((k) & 1) * 32); \
   } while (0)
     if constexpr (EPI == EPI_RESID) {
 #pragma unroll
@@ -337,15 +338,18 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
           pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         }
       } else {
-        // residual rows of this 16-row block: row-major image -> fragment layout
-        *(uint4*)(tr + tr_base) = rres[(mt * 2) & 7];
-        *(uint4*)(tr + 1024 + tr_base) = rres[(mt * 2 + 1) & 7];
-        // (no wait: the LDS serves one wave's accesses in order, so the fragment-layout reads below see these writes)
+        // residual pieces of this 16-row block: the swap turns the two 16-B pieces back into the lane's four 8-B pieces
+        uint2 rq[4];
+        {
+          uint4 r0 = rres[(mt * 2) & 7], r1 = rres[(mt * 2 + 1) & 7];
+          SWAP16(r0.x, r0.z); SWAP16(r0.y, r0.w); SWAP16(r1.x, r1.z); SWAP16(r1.y, r1.w);
+          rq[0] = uint2{r0.x, r0.y}; rq[1] = uint2{r0.z, r0.w}; rq[2] = uint2{r1.x, r1.y}; rq[3] = uint2{r1.z, r1.w};
+        }
         if (mt + 4 < 8) { LOAD_RES(mt * 2 + 8); LOAD_RES(mt * 2 + 9); }
         float s = 0.f, ss = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-          const uint2 rr = *(const uint2*)TW_ADDR(nt);
+          const uint2 rr = rq[nt];
           f32x4_t v = acc[mt][nt] + bs[nt];
           v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
           v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
@@ -360,18 +364,17 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
         s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
         if (lane < 16)
           *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane) * 8) = float2{s, ss};
-        // (in order again: the image may be rewritten right behind the fragment reads)
       }
-      // fragment layout -> row-major image -> two 16-B-per-lane stores of 8 full rows each
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt) *(uint2*)TW_ADDR(nt) = pk[nt];
-      // (no wait between the image writes and the row-major reads, nor before the next block's writes: one wave, in order)
-      const uint4 v0 = *(const uint4*)(tr + tr_base);
-      const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
-      const int ma = mw0 + mt * 16 + row_l, mb = ma + 8;
-      if (ma < p.M) *(uint4*)((bf16_t*)p.out + (size_t)ma * p.ldo + gcol) = v0;
-      if (mb < p.M) *(uint4*)((bf16_t*)p.out + (size_t)mb * p.ldo + gcol) = v1;
+      // 8-B pieces -> 16-B pieces (exchange with lane ^ 16), two 16-B-per-lane stores of 16 half rows (64 B) each
+      SWAP16(pk[0].x, pk[1].x); SWAP16(pk[0].y, pk[1].y); SWAP16(pk[2].x, pk[3].x); SWAP16(pk[2].y, pk[3].y);
+      const int mrow = mw0 + mt * 16 + frow;
+      if (mrow < p.M) {
+        bf16_t* orow = (bf16_t*)p.out + (size_t)mrow * p.ldo + gcol;
+        *(uint4*)orow = uint4{pk[0].x, pk[0].y, pk[1].x, pk[1].y};
+        *(uint4*)(orow + 32) = uint4{pk[2].x, pk[2].y, pk[3].x, pk[3].y};
+      }
     }
+#undef SWAP16
 
     if constexpr (EPI == EPI_RESID) {
       __syncthreads();
