@@ -36,6 +36,7 @@
 
 namespace {
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int BM = 256, BN = 256;
 constexpr int BUF = 65536, WREG = 32768;    // one K=64 stage: A region | W region
 constexpr int RING = 2 * BUF;               // 131072
@@ -109,13 +110,6 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   const int a_rd0 = wr * 16 * 1024 + rdl, a_rd1 = a_rd0 ^ 64;
   const int w_rd0 = WREG + wc * 8 * 1024 + rdl, w_rd1 = w_rd0 ^ 64;
 
-  // epilogue lane mapping: 16-row x 128-B image per wave, 16-B chunk index XOR row&7
-  char* tr = smem + TR_OFF + w * 2048;
-  const int qd = lane >> 4;
-  const int tw_base = frow * 128 + (qd & 1) * 8;
-  const int tw_sw = frow & 7;
-  const int tr_base = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // + 1024 for rows 8..15
-  const int row_l = lane >> 3;
 #define TW_ADDR(nt) (tr + tw_base + ((((nt) * 2 + (qd >> 1)) ^ tw_sw) << 4))
 
   int idx = blockIdx.x;
@@ -244,8 +238,17 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       nxt = decode_tile(nidx, tiles_m, tiles_n);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
-      aoff00 = AOFF(nxt.m0, arow0); aoff01 = AOFF(nxt.m0, arow0 + 8);
-      aoff10 = AOFF(nxt.m0, arow0 + 64); aoff11 = AOFF(nxt.m0, arow0 + 72);
+      // re-derived from an opaque copy of the lane id: as loop invariants these constants would be kept (spilled) across
+      // the main loop, and a spill reload here carries a compiler-counted vmcnt wait that drains the DMA pipeline
+      int lane_b = lane;
+      asm volatile("" : "+v"(lane_b));
+      const int dg_b = lane_b >> 3;
+      const unsigned dch_b = (unsigned)(((lane_b & 7) ^ (dg_b & 6)) * 16);
+      const int arow_b = (w >> 2) * 128 + (2 * (w & 3)) * 8 + dg_b;
+#define AOFF_B(r) ((unsigned)((min(nxt.m0 + (r), p.M - 1) - nxt.m0) * lda_b) + dch_b)
+      aoff00 = AOFF_B(arow_b); aoff01 = AOFF_B(arow_b + 8);
+      aoff10 = AOFF_B(arow_b + 64); aoff11 = AOFF_B(arow_b + 72);
+#undef AOFF_B
     }
     {
       // ONE code path: without a next tile the DMA harmlessly re-fetches this tile's first stages into dead
@@ -258,10 +261,27 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 5] = __builtin_amdgcn_s_memtime(); }
 
     // ------------------------------- epilogue of tile `cur` -------------------------------
+    // epilogue lane mapping: 16-row x 128-B image per wave, 16-B chunk index XOR row&7 -- derived here from an opaque copy
+    // of the lane id, so that hipcc does not carry these constants through the main loop
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    char* tr = smem + TR_OFF + w * 2048;
+    const int frow_e = lane_e & 15, qd = lane_e >> 4;
+    const int tw_base = frow_e * 128 + (qd & 1) * 8;
+    const int tw_sw = frow_e & 7;
+    const int tr_base = (lane_e >> 3) * 128 + (((lane_e & 7) ^ (lane_e >> 3)) << 4);   // + 1024 for rows 8..15
+    const int row_l = lane_e >> 3;
     const int q4 = qd * 4;
     const int ncol0 = cur.n0 + wc * 64 + q4;         // + nt*16
     const int mw0 = cur.m0 + wr * 128;               // first row of the wave tile
-    const size_t gcol = (size_t)cur.n0 + wc * 64 + (lane & 7) * 8;
+    // Row stores and residual loads go through buffer descriptors that cover exactly the tile's existing rows: the hardware
+    // drops (stores) / zero-fills (loads) the rows of a ragged last tile, so the blocks below are straight-line code
+    // without per-row exec-mask branches.  Descriptors are built from wave-uniform values only (SGPRs, no waterfall loop).
+    const unsigned row_bytes = (unsigned)p.ldo * 2u;
+    const unsigned tile_bytes = (unsigned)min(p.M - cur.m0, BM) * row_bytes;                  // <= 256 rows x 8 KiB
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (size_t)cur.m0 * row_bytes, 0, (int)tile_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((char*)p.resid + (size_t)cur.m0 * row_bytes, 0, (int)tile_bytes, 0x00020000);
+    const unsigned lcol_b = (unsigned)(cur.n0 + wc * 64 + (lane_e & 7) * 8) * 2u;              // byte column of the lane's 16-B piece
 
     if constexpr (EPI == EPI_LNFOLD) {
       // (mean, rstd) of the tile's rows from the raw partial sums that the DMA left in AUX[buf]
@@ -296,9 +316,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     uint4 rres[8];
 #define LOAD_RES(k)                                                                           \
   do {                                                                                        \
-    const int m_ = mw0 + (k) * 8 + row_l;                                                     \
-    rres[(k) & 7] = uint4{0, 0, 0, 0};                                                        \
-    if (m_ < p.M) rres[(k) & 7] = *(const uint4*)((const bf16_t*)p.resid + (size_t)m_ * p.ldo + gcol); \
+    const unsigned off_ = (unsigned)(wr * 128 + (k) * 8 + row_l) * row_bytes + lcol_b;        \
+    rres[(k) & 7] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off_, 0, 0)); \
   } while (0)
     if constexpr (EPI == EPI_RESID) {
 #pragma unroll
@@ -315,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
           pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         }
       } else if constexpr (EPI == EPI_LNFOLD) {
-        const float2 t = *(const float2*)(smem + AUX_OFF + (tile_iter & 1) * 8192 + (wr * 128 + mt * 16 + frow) * 8);
+        const float2 t = *(const float2*)(smem + AUX_OFF + (tile_iter & 1) * 8192 + (wr * 128 + mt * 16 + frow_e) * 8);
         const float mean = t.x, rstd = t.y;
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -355,11 +374,11 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
           s += (r0 + r1) + (r2 + r3);
           ss += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
         }
-        if (mw0 + mt * 16 + frow >= p.M) { s = 0.f; ss = 0.f; }
+        if (mw0 + mt * 16 + frow_e >= p.M) { s = 0.f; ss = 0.f; }
         s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
         s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-        if (lane < 16)
-          *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane) * 8) = float2{s, ss};
+        if (lane_e < 16)
+          *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane_e) * 8) = float2{s, ss};
         // (in order again: the image may be rewritten right behind the fragment reads)
       }
       // fragment layout -> row-major image -> two 16-B-per-lane stores of 8 full rows each
@@ -368,9 +387,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       // (no wait between the image writes and the row-major reads, nor before the next block's writes: one wave, in order)
       const uint4 v0 = *(const uint4*)(tr + tr_base);
       const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
-      const int ma = mw0 + mt * 16 + row_l, mb = ma + 8;
-      if (ma < p.M) *(uint4*)((bf16_t*)p.out + (size_t)ma * p.ldo + gcol) = v0;
-      if (mb < p.M) *(uint4*)((bf16_t*)p.out + (size_t)mb * p.ldo + gcol) = v1;
+      const unsigned oa = (unsigned)(wr * 128 + mt * 16 + row_l) * row_bytes + lcol_b;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v0), orsrc, oa, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v1), orsrc, oa + 8 * row_bytes, 0, 0);
     }
 
     if constexpr (EPI == EPI_RESID) {
