@@ -146,13 +146,18 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
                AUX_OFF + (buf) * 8192 + part * 2048 + w * 1024);                             \
     }                                                                                       \
   } while (0)
-#define LD_W(b, rdv) _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (b) * BUF + (rdv) + j * 2048);
-#define LD_A(b, half, rdv) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (b) * BUF + (rdv) + ((half) * 8 + i * 2) * 1024);
-#define MMA_ROWS(half, i0, i1)                                                              \
+  // fragments of one phase: W for both k halves (fb[4 kh + j], kept for both phases of the stage) and one A row half for
+  // both k halves (fa[4 kh + i]); the k 0..31 fragments are read first, they feed the first MFMAs
+#define LD_W2(b) _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (b) * BUF + w_rd0 + j * 2048);  \
+                 _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[4 + j] = *(const frag_t*)(smem + (b) * BUF + w_rd1 + j * 2048);
+#define LD_A2(b, half) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (b) * BUF + a_rd0 + ((half) * 8 + i * 2) * 1024);  \
+                       _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[4 + i] = *(const frag_t*)(smem + (b) * BUF + a_rd1 + ((half) * 8 + i * 2) * 1024);
+#define MMA2(half)                                                                          \
   do {                                                                                      \
-    _Pragma("unroll") for (int i = (i0); i < (i1); ++i)                                     \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
-      acc[(half) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[j], fa[i], acc[(half) * 4 + i][j], 0, 0, 0); \
+      acc[(half) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kh * 4 + j], fa[kh * 4 + i], acc[(half) * 4 + i][j], 0, 0, 0); \
   } while (0)
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
 #define WAIT_LDS()                                                                          \
@@ -160,58 +165,53 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
-  // {reads retired} barrier {16 MFMA} barrier; the sched_barrier keeps the register-only MFMAs behind the s_barrier.
-  // Measured alternatives: handing over early (the second barrier in front of the last four MFMAs) was 8 % SLOWER end to
-  // end; refilling the W fragments inside P2's MFMA section (W fragment as the outer loop), so that P3 waits for 4 reads
-  // instead of 8, changed nothing (1689 vs 1689 images/s).
+  // {reads retired} barrier {32 MFMA} barrier; the sched_barrier keeps the register-only MFMAs behind the s_barrier
 #define SYNC_MMA(half)                                                                      \
   do {                                                                                      \
     WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0);                               \
-    __builtin_amdgcn_s_setprio(1); MMA_ROWS(half, 0, 4); __builtin_amdgcn_s_setprio(0);     \
+    __builtin_amdgcn_s_setprio(1); MMA2(half); __builtin_amdgcn_s_setprio(0);               \
     BARRIER();                                                                              \
   } while (0)
-  // stage s+1 is retired here (its 8 pieces are older than the 6 just issued; vmcnt retires in order)
-#define VM6 asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
-  // First stage after an epilogue: stage 1 of the new tile was issued BEFORE the epilogue's stores, so when every wave
-  // issued exactly its 16 row stores (17 for the waves that also store EPI_RESID statistics) the wait may leave those
-  // outstanding as well, and the stores drain under four phases of MFMAs instead of stalling the pipeline at the head
-  // of every tile.  One opaque instruction for the compiler (a real branch here splits the stage into basic blocks and
-  // costs ~20 spilled VGPRs): sel 0 -> vmcnt(6), 1 -> vmcnt(22), 2 -> vmcnt(23).
-#define VM_FIRST                                                                            \
+  // The counted wait of a phase, issued behind the phase's own pieces: PA has just issued 2, PB 6, and the pieces that
+  // must have landed are older than the 8 newest (vmcnt retires in order).  First two waits after an epilogue: what they
+  // need was issued BEFORE the epilogue's stores, so when every wave issued exactly its 16 row stores (17 for the waves
+  // that also store EPI_RESID statistics) those may stay outstanding as well and drain under the MFMAs instead of
+  // stalling the pipeline at the head of every tile.  One opaque instruction for the compiler (a real branch here splits
+  // the stage into basic blocks and costs ~20 spilled VGPRs): sel 0 -> vmcnt(8), 1 -> vmcnt(24), 2 -> vmcnt(25).
+#define VM8 asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define VM_RELAX                                                                            \
   do {                                                                                      \
-    const int sel_ = __builtin_amdgcn_readfirstlane(relax);                                 \
-    relax = 0;                                                                              \
-    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lvm6_%=\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Lvm22_%=\n\t"          \
-                 "s_waitcnt vmcnt(23)\n\ts_branch .Lvmend_%=\n.Lvm22_%=:\n\ts_waitcnt vmcnt(22)\n\ts_branch .Lvmend_%=\n"       \
-                 ".Lvm6_%=:\n\ts_waitcnt vmcnt(6)\n.Lvmend_%=:" : : "s"(sel_) : "memory", "scc");                                  \
+    const int sel_ = __builtin_amdgcn_readfirstlane(relax > 0 ? relax_sel : 0);             \
+    relax = relax > 0 ? relax - 1 : 0;                                                      \
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lvm8_%=\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Lvm24_%=\n\t"          \
+                 "s_waitcnt vmcnt(25)\n\ts_branch .Lvmend_%=\n.Lvm24_%=:\n\ts_waitcnt vmcnt(24)\n\ts_branch .Lvmend_%=\n"       \
+                 ".Lvm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lvmend_%=:" : : "s"(sel_) : "memory", "scc");                                  \
   } while (0)
-#define ISSUE_P4(b, ablk, wblk, o10, o11, kbyte)                                            \
-  do { ISSUE_W(b, wblk, kbyte); ISSUE_AH1(b, ablk, o10, o11, kbyte); } while (0)
-  // one K=64 stage on buffer b = four phases; P4_ISSUE: W and A(half 1) of stage s+2 into this buffer (their rows were
-  // last read in P3), POST_ISSUE: its A(half 0) rows once P4 is over
-#define STAGE(b, VMWAIT, P4_ISSUE, POST_ISSUE)                                              \
+#define ISSUE_WAH0(b, ablk, wblk, o00, o01, kbyte)                                          \
+  do { ISSUE_W(b, wblk, kbyte); ISSUE_AH0(b, ablk, o00, o01, kbyte); } while (0)
+  // one K=64 stage on buffer b = two phases of 32 MFMAs per wave.  PA: W (both k halves) and A(half 0), PA_ISSUE = the
+  // A(half 1) rows of stage s+1 into the other buffer; PB: A(half 1), PB_ISSUE = W and A(half 0) of stage s+2 into this one
+#define STAGE(b, VMWAIT, PA_ISSUE, PB_ISSUE)                                                \
   do {                                                                                      \
-    LD_W(b, w_rd0) __builtin_amdgcn_sched_barrier(0); LD_A(b, 0, a_rd0)                     \
-    SYNC_MMA(0);                                                                            \
-    LD_A(b, 1, a_rd0)                                                                       \
-    SYNC_MMA(1);                                                                            \
-    LD_W(b, w_rd1) __builtin_amdgcn_sched_barrier(0); LD_A(b, 1, a_rd1)                     \
-    SYNC_MMA(1);                                                                            \
-    LD_A(b, 0, a_rd1)                                                                       \
-    P4_ISSUE;                                                                               \
+    LD_W2(b) __builtin_amdgcn_sched_barrier(0); LD_A2(b, 0)                                 \
+    PA_ISSUE;                                                                               \
     VMWAIT;                                                                                 \
     SYNC_MMA(0);                                                                            \
-    POST_ISSUE;                                                                             \
+    LD_A2(b, 1)                                                                             \
+    PB_ISSUE;                                                                               \
+    VMWAIT;                                                                                 \
+    SYNC_MMA(1);                                                                            \
   } while (0)
 
   // ---- cold prologue of the first tile ----
   int tile_iter = 0;
   STAGE_STATS(0, cur.m0);
-  ISSUE_AH0(0, Ablk, aoff00, aoff01, 0); ISSUE_P4(0, Ablk, Wblk, aoff10, aoff11, 0);
-  ISSUE_AH0(1, Ablk, aoff00, aoff01, 128); ISSUE_P4(1, Ablk, Wblk, aoff10, aoff11, 128);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 0); ISSUE_AH1(0, Ablk, aoff10, aoff11, 0);
+  ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 128);           // A(half 1) of stage 1 follows in PA of stage 0
+  VM8;                                                      // W and A(half 0) of stage 0 have landed
   BARRIER();
-  int relax = 0;                             // 1 / 2: the coming tile's first wait may leave the previous tile's 16 / 17 stores in flight
+  int relax = 0;                             // waits of the coming tile that may leave the previous tile's stores in flight
+  const int relax_sel = (EPI == EPI_RESID && w < 4) ? 2 : 1;   // those waves also store the row statistics: 17 stores, not 16
 
   for (;;) {
     f32x4_t acc[8][4];
@@ -219,44 +219,46 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    frag_t fa[4], fb[4];
+    frag_t fa[8], fb[8];
 
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 4] = __builtin_amdgcn_s_memtime(); }
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
     for (int kb = 0; kb < kend - 256; kb += 256) {
-      STAGE(0, VM_FIRST, ISSUE_P4(0, Ablk, Wblk, aoff10, aoff11, kb + 256), ISSUE_AH0(0, Ablk, aoff00, aoff01, kb + 256));
-      STAGE(1, VM6, ISSUE_P4(1, Ablk, Wblk, aoff10, aoff11, kb + 384), ISSUE_AH0(1, Ablk, aoff00, aoff01, kb + 384));
+      STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
+      STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
     }
     // ---- last two stages: the DMA crosses into the next tile ----
     const int nidx = idx + G;
     const bool has_next = nidx < nwg;
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
-    // (this tile's A offsets are dead from here on: the next tile's take their registers)
     if (has_next) {
       nxt = decode_tile(nidx, tiles_m, tiles_n);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
-      // re-derived from an opaque copy of the lane id: as loop invariants these constants would be kept (spilled) across
-      // the main loop, and a spill reload here carries a compiler-counted vmcnt wait that drains the DMA pipeline
-      int lane_b = lane;
-      asm volatile("" : "+v"(lane_b));
-      const int dg_b = lane_b >> 3;
-      const unsigned dch_b = (unsigned)(((lane_b & 7) ^ (dg_b & 6)) * 16);
-      const int arow_b = (w >> 2) * 128 + (2 * (w & 3)) * 8 + dg_b;
-#define AOFF_B(r) ((unsigned)((min(nxt.m0 + (r), p.M - 1) - nxt.m0) * lda_b) + dch_b)
-      aoff00 = AOFF_B(arow_b); aoff01 = AOFF_B(arow_b + 8);
-      aoff10 = AOFF_B(arow_b + 64); aoff11 = AOFF_B(arow_b + 72);
-#undef AOFF_B
     }
+    // The next tile's A offsets take over this tile's registers as they die (half 0 here, half 1 between the last two
+    // stages; without a next tile nxt == cur and they are recomputed to the same values).  They are re-derived from an
+    // opaque copy of the lane id: as loop invariants the constants would be kept (spilled) across the main loop, and a
+    // spill reload here carries a compiler-counted vmcnt wait that drains the DMA pipeline.
+    int lane_b = lane;
+    asm volatile("" : "+v"(lane_b));
+    const int dg_b = lane_b >> 3;
+    const unsigned dch_b = (unsigned)(((lane_b & 7) ^ (dg_b & 6)) * 16);
+    const int arow_b = (w >> 2) * 128 + (2 * (w & 3)) * 8 + dg_b;
+#define AOFF_B(r) ((unsigned)((min(nxt.m0 + (r), p.M - 1) - nxt.m0) * lda_b) + dch_b)
+    aoff00 = AOFF_B(arow_b); aoff01 = AOFF_B(arow_b + 8);
     {
+      const int kb = kend - 256;
       // ONE code path: without a next tile the DMA harmlessly re-fetches this tile's first stages into dead
       // buffers (two variants of this block made hipcc spill ~270 VGPRs)
       if (has_next) STAGE_STATS((tile_iter + 1) & 1, nxt.m0);
-      STAGE(0, VM_FIRST, ISSUE_P4(0, Anext, Wnext, aoff10, aoff11, 0), ISSUE_AH0(0, Anext, aoff00, aoff01, 0));
-      STAGE(1, VM6, ISSUE_P4(1, Anext, Wnext, aoff10, aoff11, 128), ISSUE_AH0(1, Anext, aoff00, aoff01, 128));
+      STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Anext, Wnext, aoff00, aoff01, 0));
+      aoff10 = AOFF_B(arow_b + 64); aoff11 = AOFF_B(arow_b + 72);
+      STAGE(1, VM8, ISSUE_AH1(0, Anext, aoff10, aoff11, 0), ISSUE_WAH0(1, Anext, Wnext, aoff00, aoff01, 128));
     }
+#undef AOFF_B
     if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 5] = __builtin_amdgcn_s_memtime(); }
 
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       break;
     }
     // all 256 rows valid: every guarded store above was issued (the waves of EPI_RESID that store statistics issued 17)
-    relax = (cur.m0 + BM <= p.M && p.dbg == nullptr) ? ((EPI == EPI_RESID && w < 4) ? 2 : 1) : 0;
+    relax = (cur.m0 + BM <= p.M && p.dbg == nullptr) ? 2 : 0;   // the first two waits of the coming tile
     idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
     ++tile_iter;
   }
