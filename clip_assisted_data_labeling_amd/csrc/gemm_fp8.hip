@@ -138,14 +138,17 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     const uint4 hi_ = *(const uint4*)(smem + (off) + (rd0 ^ ((kh) * 64) ^ 16));             \
     dst = i32x8_t{(int)lo_.x, (int)lo_.y, (int)lo_.z, (int)lo_.w, (int)hi_.x, (int)hi_.y, (int)hi_.z, (int)hi_.w}; \
   } while (0)
-#define LD_W(b, kh) _Pragma("unroll") for (int j = 0; j < 2; ++j) LD_FRAG(fb[j], (b) * BUF + w_base + j * 4096, kh);
-#define LD_A(b, half, kh) _Pragma("unroll") for (int i = 0; i < 2; ++i) LD_FRAG(fa[i], (b) * BUF + a_base + ((half) * 2 + i) * 4096, kh);
+  // fragments of one phase (gemm_persist.hip): W for both k halves (fb[2 kh + j], kept for both phases of the stage) and
+  // one A row half for both k halves (fa[2 kh + i])
+#define LD_W2(b) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int j = 0; j < 2; ++j) LD_FRAG(fb[kh * 2 + j], (b) * BUF + w_base + j * 4096, kh);
+#define LD_A2(b, half) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int i = 0; i < 2; ++i) LD_FRAG(fa[kh * 2 + i], (b) * BUF + a_base + ((half) * 2 + i) * 4096, kh);
 #define MMA(half)                                                                           \
   do {                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                          \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                        \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                           \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
-      acc[(half) * 2 + i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[j], fa[i], acc[(half) * 2 + i][j], 0, 0, \
+      acc[(half) * 2 + i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[kh * 2 + j], fa[kh * 2 + i], acc[(half) * 2 + i][j], 0, 0, \
                                                                               0, 0x7f7f7f7f, 0, 0x7f7f7f7f);        \
     __builtin_amdgcn_s_setprio(0);                                                          \
   } while (0)
@@ -159,44 +162,44 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   do {                                                                                      \
     WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0); MMA(half); BARRIER();         \
   } while (0)
-  // one K=128 stage on buffer b = four phases (gemm_persist.hip): P4_ISSUE = W and A(half 1) of stage s+2 into this
-  // buffer, POST_ISSUE = its A(half 0) rows once P4 is over; VMWAIT retires stage s+1
-#define STAGE(b, VMWAIT, P4_ISSUE, POST_ISSUE)                                              \
+#define ISSUE_WAH0(b, ablk, wblk, o00, o01, kbyte)                                          \
+  do { ISSUE_W(b, wblk, kbyte); ISSUE_AH0(b, ablk, o00, o01, kbyte); } while (0)
+  // one K=128 stage on buffer b = two phases of 8 MFMAs (512 cycles) per wave (gemm_persist.hip).  PA: W (both k halves)
+  // and A(half 0), PA_ISSUE = the A(half 1) rows of stage s+1 into the other buffer; PB: A(half 1), PB_ISSUE = W and
+  // A(half 0) of stage s+2 into this one; each phase's counted wait sits behind its own pieces (the 8 newest stay in flight)
+#define STAGE(b, VMWAIT, PA_ISSUE, PB_ISSUE)                                                \
   do {                                                                                      \
-    LD_W(b, 0) __builtin_amdgcn_sched_barrier(0); LD_A(b, 0, 0)                             \
-    SYNC_MMA(0);                                                                            \
-    LD_A(b, 1, 0)                                                                           \
-    SYNC_MMA(1);                                                                            \
-    LD_W(b, 1) __builtin_amdgcn_sched_barrier(0); LD_A(b, 1, 1)                             \
-    SYNC_MMA(1);                                                                            \
-    LD_A(b, 0, 1)                                                                           \
-    P4_ISSUE;                                                                               \
+    LD_W2(b) __builtin_amdgcn_sched_barrier(0); LD_A2(b, 0)                                 \
+    PA_ISSUE;                                                                               \
     VMWAIT;                                                                                 \
     SYNC_MMA(0);                                                                            \
-    POST_ISSUE;                                                                             \
+    LD_A2(b, 1)                                                                             \
+    PB_ISSUE;                                                                               \
+    VMWAIT;                                                                                 \
+    SYNC_MMA(1);                                                                            \
   } while (0)
-#define VM6 asm volatile("s_waitcnt vmcnt(6)" ::: "memory")
-  // First stage after an epilogue: stages 0-1 of the tile were issued before the epilogue's stores and vmcnt retires in
-  // order, so the wait may leave the NST row stores of a complete tile outstanding as well (see gemm_persist.hip); one
-  // opaque instruction for the compiler.
+#define VM8 asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+  // First two waits after an epilogue: what they need was issued before the epilogue's stores and vmcnt retires in order,
+  // so they may leave the NST row stores of a complete tile outstanding as well (see gemm_persist.hip); one opaque
+  // instruction for the compiler.
   constexpr int NST = EPI == 2 ? 8 : 16;     // row stores per wave and tile
-#define VM_FIRST                                                                            \
+#define VM_RELAX                                                                            \
   do {                                                                                      \
-    const int sel_ = __builtin_amdgcn_readfirstlane(relax);                                 \
-    relax = 0;                                                                              \
+    const int sel_ = __builtin_amdgcn_readfirstlane(relax > 0 ? 1 : 0);                     \
+    relax = relax > 0 ? relax - 1 : 0;                                                      \
     if constexpr (NST == 16)                                                                \
-      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm6_%=\n\ts_waitcnt vmcnt(22)\n\ts_branch .Lf8end_%=\n"               \
-                   ".Lf8vm6_%=:\n\ts_waitcnt vmcnt(6)\n.Lf8end_%=:" : : "s"(sel_) : "memory", "scc");                            \
+      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm8_%=\n\ts_waitcnt vmcnt(24)\n\ts_branch .Lf8end_%=\n"               \
+                   ".Lf8vm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lf8end_%=:" : : "s"(sel_) : "memory", "scc");                            \
     else                                                                                    \
-      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm6_%=\n\ts_waitcnt vmcnt(14)\n\ts_branch .Lf8end_%=\n"               \
-                   ".Lf8vm6_%=:\n\ts_waitcnt vmcnt(6)\n.Lf8end_%=:" : : "s"(sel_) : "memory", "scc");                            \
+      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm8_%=\n\ts_waitcnt vmcnt(16)\n\ts_branch .Lf8end_%=\n"               \
+                   ".Lf8vm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lf8end_%=:" : : "s"(sel_) : "memory", "scc");                            \
   } while (0)
 
   // ---- cold prologue of the first tile ----
-  ISSUE_AH0(0, Ablk, aoff00, aoff01, 0); ISSUE_P4(0, Ablk, Wblk, aoff10, aoff11, 0);
-  ISSUE_AH0(1, Ablk, aoff00, aoff01, 128); ISSUE_P4(1, Ablk, Wblk, aoff10, aoff11, 128);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  int relax = 0;                             // 1: the coming tile's first wait may leave the previous tile's stores in flight
+  ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 0); ISSUE_AH1(0, Ablk, aoff10, aoff11, 0);
+  ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 128);           // A(half 1) of stage 1 follows in PA of stage 0
+  VM8;                                                      // W and A(half 0) of stage 0 have landed
+  int relax = 0;                             // waits of the coming tile that may leave the previous tile's stores in flight
   BARRIER();
 
   for (;;) {
@@ -207,30 +210,32 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    i32x8_t fa[2], fb[2];
+    i32x8_t fa[4], fb[4];
 
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
     for (int kb = 0; kb < kend - 256; kb += 256) {
-      STAGE(0, VM_FIRST, ISSUE_P4(0, Ablk, Wblk, aoff10, aoff11, kb + 256), ISSUE_AH0(0, Ablk, aoff00, aoff01, kb + 256));
-      STAGE(1, VM6, ISSUE_P4(1, Ablk, Wblk, aoff10, aoff11, kb + 384), ISSUE_AH0(1, Ablk, aoff00, aoff01, kb + 384));
+      STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
+      STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
     }
     // ---- last two stages: the DMA crosses into the next tile (or re-fetches this one into dead buffers) ----
     const int nidx = idx + G;
     const bool has_next = nidx < nwg;
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
-    // (this tile's A offsets are dead from here on: the next tile's take their registers)
     if (has_next) {
       nxt = decode_tile(nidx, tiles_m, tiles_n);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
-      aoff00 = AOFF(nxt.m0, arow0); aoff01 = AOFF(nxt.m0, arow0 + 128);
-      aoff10 = AOFF(nxt.m0, arow0 + 64); aoff11 = AOFF(nxt.m0, arow0 + 192);
     }
+    // the next tile's A offsets take over this tile's registers as they die: half 0 here, half 1 between the last two
+    // stages (without a next tile nxt == cur and they are recomputed to the same values)
+    aoff00 = AOFF(nxt.m0, arow0); aoff01 = AOFF(nxt.m0, arow0 + 128);
     {
-      STAGE(0, VM_FIRST, ISSUE_P4(0, Anext, Wnext, aoff10, aoff11, 0), ISSUE_AH0(0, Anext, aoff00, aoff01, 0));
-      STAGE(1, VM6, ISSUE_P4(1, Anext, Wnext, aoff10, aoff11, 128), ISSUE_AH0(1, Anext, aoff00, aoff01, 128));
+      const int kb = kend - 256;
+      STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Anext, Wnext, aoff00, aoff01, 0));
+      aoff10 = AOFF(nxt.m0, arow0 + 64); aoff11 = AOFF(nxt.m0, arow0 + 192);
+      STAGE(1, VM8, ISSUE_AH1(0, Anext, aoff10, aoff11, 0), ISSUE_WAH0(1, Anext, Wnext, aoff00, aoff01, 128));
     }
     // pin the accumulators here: without a use in this block LLVM sinks the tail's 32 MFMAs below the conditional
     // barrier (all fragments live at once -> hundreds of spilled VGPRs)
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant DMA before the LDS is released
       break;
     }
-    relax = (cur.m0 + BM <= p.M) ? 1 : 0;    // all 256 rows valid: every guarded row store above was issued
+    relax = (cur.m0 + BM <= p.M) ? 2 : 0;    // all 256 rows valid: every guarded row store above was issued; the first two waits
     idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
   }
 }

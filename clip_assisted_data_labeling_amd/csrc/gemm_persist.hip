@@ -165,7 +165,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
-  // {reads retired} barrier {32 MFMA} barrier; the sched_barrier keeps the register-only MFMAs behind the s_barrier
+  // {reads retired} barrier {32 MFMA} barrier; the sched_barrier keeps the register-only MFMAs behind the s_barrier.
+  // (Handing over early -- the second barrier in front of the last four MFMAs, so that the other wave row starts while
+  // these drain -- measured 7-8 % SLOWER end to end, with 16- and with 32-MFMA phases.)
 #define SYNC_MMA(half)                                                                      \
   do {                                                                                      \
     WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0);                               \
