@@ -230,13 +230,22 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     }
     // the next tile's A offsets take over this tile's registers as they die: half 0 here, half 1 between the last two
     // stages (without a next tile nxt == cur and they are recomputed to the same values)
-    aoff00 = AOFF(nxt.m0, arow0); aoff01 = AOFF(nxt.m0, arow0 + 128);
+    // (re-derived from the hardware's lane id: kept across the main loop these constants -- and the lane id itself -- are spilled, and a spill
+    // reload between two stages carries a compiler-counted vmcnt wait that drains the DMA pipeline)
+    int lane_b;                                             // the lane id, from the hardware (an asm statement is not hoisted)
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_b));
+    const int dg_b = lane_b >> 3;
+    const unsigned dch_b = (unsigned)(((lane_b & 7) ^ (((w & 1) << 2) | (dg_b >> 1))) * 16);
+    const int arow_b = 8 * w + dg_b;
+#define AOFF_B(r) ((unsigned)((min(nxt.m0 + (r), p.M - 1) - nxt.m0) * lda_b) + dch_b)
+    aoff00 = AOFF_B(arow_b); aoff01 = AOFF_B(arow_b + 128);
     {
       const int kb = kend - 256;
       STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Anext, Wnext, aoff00, aoff01, 0));
-      aoff10 = AOFF(nxt.m0, arow0 + 64); aoff11 = AOFF(nxt.m0, arow0 + 192);
+      aoff10 = AOFF_B(arow_b + 64); aoff11 = AOFF_B(arow_b + 192);
       STAGE(1, VM8, ISSUE_AH1(0, Anext, aoff10, aoff11, 0), ISSUE_WAH0(1, Anext, Wnext, aoff00, aoff01, 128));
     }
+#undef AOFF_B
     // pin the accumulators here: without a use in this block LLVM sinks the tail's 32 MFMAs below the conditional
     // barrier (all fragments live at once -> hundreds of spilled VGPRs)
 #pragma unroll
