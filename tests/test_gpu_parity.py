@@ -75,6 +75,30 @@ def test_gemm_f16_and_bf16_store_with_bias(gpu):
     assert (ob.float().cpu() - ref).abs().max() <= 0.01 * ref.abs().max()      # one bf16 rounding
 
 
+@pytest.mark.parametrize("m", [1, 7, 255, 257, 513, 1031])
+@pytest.mark.parametrize("n,k", [(256, 128), (512, 256), (256, 640), (768, 1152)])
+def test_persistent_gemm_small_and_ragged_shapes(gpu, m, n, k):
+    # the bf16-store path is the persistent kernel: K = 128 is one stage pair (no steady-state loop iteration), M < 256 a
+    # single ragged tile (rows beyond M are dropped by the store descriptor and clamped in the LDS-DMA source), M = 257 a
+    # full tile followed by a one-row tile on another workgroup
+    g = torch.Generator().manual_seed(m * 131 + n + k)
+    a = torch.randn(m, k, generator=g).to(torch.bfloat16)
+    w = torch.randn(n, k, generator=g).to(torch.bfloat16)
+    bias = torch.randn(n, generator=g)
+    guard = torch.full((m + 3, n), 7.0, dtype=torch.bfloat16, device=gpu)        # rows behind the output must stay untouched
+    out = guard[:m]
+    lib = _lib.load()
+    a_d, w_d, b_d = a.to(gpu), w.to(gpu), bias.to(gpu)
+    _lib.check(lib.clipenc_op_gemm_nt(a_d.data_ptr(), w_d.data_ptr(), m, n, k, 0, 1, b_d.data_ptr(),
+                                      out.data_ptr(), _lib.current_stream_ptr(gpu)), "gemm")
+    torch.cuda.synchronize()
+    ref = (a.float() @ w.float().t() + bias).to(torch.bfloat16)                  # fp32 accumulate, one bf16 rounding
+    diff = (out.float().cpu() - ref.float()).abs()
+    assert diff.max().item() <= 2.0 ** -7 * ref.float().abs().max().item()       # accumulation order may move the last bf16 bit
+    assert (diff > 0).float().mean().item() < 0.05
+    assert torch.all(guard[m:] == 7.0)
+
+
 def test_gemm_rejects_bad_shapes(gpu):
     lib = _lib.load()
     t = torch.zeros(256, 256, device=gpu, dtype=torch.bfloat16)
