@@ -11,18 +11,12 @@
 // acc[8 m-tiles][4 n-tiles] of 16x16 (128 fp32 VGPRs).  The MFMA is issued as D = Wfrag . Afrag^T, so a lane
 // ends up with 4 CONSECUTIVE output columns of one row (row = lane&15, cols = 4*(lane>>4)+reg).
 //
-// LDS (128 KiB): 4-slot ring of K=32 stages, each A part 16 KiB | W part 16 KiB.  LDS subtile = 16 rows x
-// 64 B (1 KiB, what one LDS-DMA instruction writes); 16-B chunk c of row r sits at chunk c ^ (2*(r>>3)):
-// every ds_read_b128 fragment read is conflict-free.  The LDS-DMA writes LDS linearly (lane*16), so the
-// swizzle is applied to the per-lane SOURCE address and to the read address (guide rule 21).
-//
-// Schedule: two phases per stage, each {ds_read fragments, issue 2 DMA} s_barrier {16 MFMA} s_barrier:
-//   (a) reads W frags + A frags of m-tiles 0-3, issues the W part of stage t+2;
-//   (b) reads A frags of m-tiles 4-7, issues the A part of stage t+3, and retires stage t+1 with ONE counted
-//       vmcnt that leaves the 3 youngest parts (6 DMA) in flight.
-// The two wave rows (wr = 0 / 1: the two waves of every SIMD) run half a phase apart, so one issues MFMAs
-// while the other issues LDS reads and DMA.  A slot is re-staged >= 2 phases after its last read; a stage is
-// read >= 1 phase after the wait that retired it.
+// LDS (128 KiB): two buffers of K=64 stages, (A 256 rows x 128 B | W 256 rows x 128 B) each, staged exactly as in
+// gemm_persist.hip (read its header): every LDS-DMA piece = 8 whole cache lines, 16-B chunk c of row r at c ^ (r & 6),
+// two phases of 32 MFMAs per stage and wave with the two wave rows half a phase apart, A(half 1) of stage s+1 issued in
+// PA of stage s, W + A(half 0) of stage s+2 in PB, one vmcnt(8) per phase.  This kernel runs ONE tile per workgroup: past
+// the last stage the same pieces are issued again for the last stage's k range (rows that nobody reads any more), so the
+// counted waits stay uniform, and the pipeline is drained before the epilogue.
 #include <stdlib.h>
 
 #include "common.h"
@@ -31,8 +25,8 @@
 namespace {
 
 constexpr int BM = 256, BN = 256;
-constexpr int STG = 32768, WPART = 16384;
-constexpr int LDS_BYTES = 4 * STG;          // 131072 B
+constexpr int BUF = 65536, WREG = 32768;    // one K=64 stage: A region | W region
+constexpr int LDS_BYTES = 2 * BUF;          // 131072 B
 
 #define LDS_PTR(off) ((__attribute__((address_space(3))) void*)(smem + (off)))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -51,9 +45,10 @@ template <> struct Mfma<_Float16> {
   }
 };
 
-// one LDS-DMA instruction: 64 lanes x 16 B -> 1 KiB of LDS at `lds_off` (wave-uniform) + lane*16
-__device__ __forceinline__ void glds16(const char* g, char* smem, int lds_off) {
-  __builtin_amdgcn_global_load_lds(GLOBAL_PTR(g), LDS_PTR(lds_off), 16, 0, 0);
+// one LDS-DMA instruction: 64 lanes x 16 B from (uniform base + per-lane 32-bit offset) -> 1 KiB of LDS at lds_addr
+// (inline asm: the builtin builds a 64-bit VGPR address per piece; every wait on these pieces is hand-placed)
+__device__ __forceinline__ void glds16_at(const char* base, unsigned off, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_addr) : "memory");
 }
 
 template <typename T, int EPI>
@@ -103,43 +98,48 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
     const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
     const char* Ablk = (const char*)p.A + (size_t)m0 * lda_b;
     const char* Wblk = (const char*)p.W + (size_t)n0 * ldw_b;
-    // DMA instruction j of a part fills subtile 8j + w: rows 16(8j+w) + (lane>>2); LDS chunk lane&3 holds
-    // logical chunk (lane&3) ^ (2*((lane>>5)&1))
-    const int lrow = 16 * w + (lane >> 2);
-    const int lchunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);
-    int aoff[2], woff[2];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = 128 * j + lrow;
-      const int ra = min(m0 + r, p.M - 1) - m0;          // M edge: re-read the last valid row (masked at store)
-      aoff[j] = (int)(ra * lda_b) + lchunk * 16;
-      woff[j] = (int)(r * ldw_b) + lchunk * 16;
-    }
-    const int dma_lds = w * 1024;
-    const int rd = frow * 64 + (((lane >> 4) ^ ((frow >> 3) << 1)) << 4);
-    const int a_rd = wr * 8 * 1024 + rd;                 // + slot*STG + mt*1024
-    const int w_rd = WPART + wc * 4 * 1024 + rd;         // + slot*STG + nt*1024
-    frag_t fa[4], fb[4];
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(0));
+    // LDS-DMA lane mapping and fragment addresses: gemm_persist.hip
+    const int dg = lane >> 3;
+    const unsigned dchunk16 = (unsigned)(((lane & 7) ^ (dg & 6)) * 16);
+    const int arow0 = (w >> 2) * 128 + (2 * (w & 3)) * 8 + dg;
+    const int a_dma = ((w >> 2) * 16 + 2 * (w & 3)) * 1024;
+#define AOFF(r) ((unsigned)((min(m0 + (r), p.M - 1) - m0) * lda_b) + dchunk16)     /* M edge: re-read the last valid row */
+    const unsigned aoff00 = AOFF(arow0), aoff01 = AOFF(arow0 + 8), aoff10 = AOFF(arow0 + 64), aoff11 = AOFF(arow0 + 72);
+    const unsigned woff = (unsigned)((32 * w + dg) * ldw_b) + dchunk16;
+    const int w_dma = WREG + 4 * w * 1024;
+    const int rdl = (frow >> 3) * 1024 + (frow & 7) * 128 + ((((lane >> 4) ^ (frow & 6))) << 4);
+    const int a_rd0 = wr * 16 * 1024 + rdl, a_rd1 = a_rd0 ^ 64;
+    const int w_rd0 = WREG + wc * 8 * 1024 + rdl, w_rd1 = w_rd0 ^ 64;
+    frag_t fa[8], fb[8];
+    const int kend = p.K * 2;                // bytes along K; one stage = 128 B; K % 128 == 0
+    const int klast = kend - 128;
 
-#define STAGE_A(slot, kbyte)                                                                \
+#define ISSUE_AH0(b, kbyte)                                                                 \
   do {                                                                                      \
-    glds16(Ablk + (kbyte) + aoff[0], smem, (slot) * STG + dma_lds);                          \
-    glds16(Ablk + (kbyte) + aoff[1], smem, (slot) * STG + 8192 + dma_lds);                   \
+    glds16_at(Ablk + (kbyte), aoff00, lds0 + (unsigned)((b) * BUF + a_dma));                \
+    glds16_at(Ablk + (kbyte), aoff01, lds0 + (unsigned)((b) * BUF + a_dma + 1024));         \
   } while (0)
-#define STAGE_W(slot, kbyte)                                                                \
+#define ISSUE_AH1(b, kbyte)                                                                 \
   do {                                                                                      \
-    glds16(Wblk + (kbyte) + woff[0], smem, (slot) * STG + WPART + dma_lds);                  \
-    glds16(Wblk + (kbyte) + woff[1], smem, (slot) * STG + WPART + 8192 + dma_lds);           \
+    glds16_at(Ablk + (kbyte), aoff10, lds0 + (unsigned)((b) * BUF + a_dma + 8192));         \
+    glds16_at(Ablk + (kbyte), aoff11, lds0 + (unsigned)((b) * BUF + a_dma + 9216));         \
   } while (0)
-#define LD_W(slot) _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (slot) * STG + w_rd + j * 1024);
-#define LD_A(slot, half) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (slot) * STG + a_rd + ((half) * 4 + i) * 1024);
-#define MMA(half)                                                                           \
+#define ISSUE_W(b, kbyte)                                                                   \
   do {                                                                                      \
-    __builtin_amdgcn_s_setprio(1);                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                        \
+      glds16_at(Wblk + (kbyte) + (size_t)i_ * 8 * ldw_b, woff, lds0 + (unsigned)((b) * BUF + w_dma + i_ * 1024)); \
+  } while (0)
+#define LD_W2(b) _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (b) * BUF + w_rd0 + j * 2048);  \
+                 _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[4 + j] = *(const frag_t*)(smem + (b) * BUF + w_rd1 + j * 2048);
+#define LD_A2(b, half) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (b) * BUF + a_rd0 + ((half) * 8 + i * 2) * 1024);  \
+                       _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[4 + i] = *(const frag_t*)(smem + (b) * BUF + a_rd1 + ((half) * 8 + i * 2) * 1024);
+#define MMA2(half)                                                                          \
+  do {                                                                                      \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
-      acc[(half) * 4 + i][j] = Mfma<T>::run(fb[j], fa[i], acc[(half) * 4 + i][j]);          \
-    __builtin_amdgcn_s_setprio(0);                                                          \
+      acc[(half) * 4 + i][j] = Mfma<T>::run(fb[kh * 4 + j], fa[kh * 4 + i], acc[(half) * 4 + i][j]); \
   } while (0)
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
 #define WAIT_LDS()                                                                          \
@@ -147,32 +147,38 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
-#define STAGE(slot, kb)                                                                     \
+#define SYNC_MMA(half)                                                                      \
   do {                                                                                      \
-    /* phase a */                                                                           \
-    LD_W(slot) __builtin_amdgcn_sched_barrier(0); LD_A(slot, 0)                             \
-    if ((kb) + 128 < kend) STAGE_W(((slot) + 2) & 3, (kb) + 128);                           \
-    BARRIER(); WAIT_LDS(); MMA(0); BARRIER();                                               \
-    /* phase b */                                                                           \
-    LD_A(slot, 1)                                                                           \
-    if ((kb) + 192 < kend) { STAGE_A(((slot) + 3) & 3, (kb) + 192); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); } \
-    else if ((kb) + 128 < kend) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
-    BARRIER(); WAIT_LDS(); MMA(1); BARRIER();                                               \
+    WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0);                               \
+    __builtin_amdgcn_s_setprio(1); MMA2(half); __builtin_amdgcn_s_setprio(0);               \
+    BARRIER();                                                                              \
+  } while (0)
+#define VM8 asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+  // stage at byte offset kb on buffer b: PA issues A(half 1) of the next stage, PB issues W + A(half 0) of the one after
+  // (both clamped to the last stage's k range once the tile runs out: harmless re-fetches into rows that are dead)
+#define STAGE(b, kb)                                                                        \
+  do {                                                                                      \
+    LD_W2(b) __builtin_amdgcn_sched_barrier(0); LD_A2(b, 0)                                 \
+    ISSUE_AH1((b) ^ 1, min((kb) + 128, klast));                                             \
+    VM8;                                                                                    \
+    SYNC_MMA(0);                                                                            \
+    LD_A2(b, 1)                                                                             \
+    { const int k2_ = min((kb) + 256, klast); ISSUE_W(b, k2_); ISSUE_AH0(b, k2_); }         \
+    VM8;                                                                                    \
+    SYNC_MMA(1);                                                                            \
   } while (0)
 
-    const int kend = p.K * 2;                // bytes along K; one stage = 64 B; K % 128 == 0 -> >= 4 stages
-    STAGE_A(0, 0); STAGE_W(0, 0); STAGE_A(1, 64); STAGE_W(1, 64); STAGE_A(2, 128);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    ISSUE_W(0, 0); ISSUE_AH0(0, 0); ISSUE_AH1(0, 0);
+    { const int k1_ = min(128, klast); ISSUE_W(1, k1_); ISSUE_AH0(1, k1_); }
+    VM8;                                     // W and A(half 0) of stage 0 have landed
     BARRIER();
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
     for (int kb = 0; kb < kend; kb += 256) {
       STAGE(0, kb);
-      STAGE(1, kb + 64);
-      STAGE(2, kb + 128);
-      STAGE(3, kb + 192);
+      STAGE(1, kb + 128);                    // K % 128 == 0: stages come in pairs
     }
     if (wr == 0) BARRIER();                  // re-align the two wave rows
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the redundant tail pieces land before the LDS is released
   }
 
   // ---------------------------------- epilogue ----------------------------------
