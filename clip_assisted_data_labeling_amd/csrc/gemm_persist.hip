@@ -65,11 +65,11 @@ __device__ __forceinline__ void glds16_at(const char* base, unsigned off, unsign
 
 struct TileId { int m0, n0, tn; };
 
-__device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n) {
+__device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n, bool deep_narrow) {
   const int nwg = tiles_m * tiles_n;
   const int q = nwg >> 3, r = nwg & 7, xcd = idx & 7, pos = idx >> 3;
   const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;   // XCD-aware, bijective
-  constexpr int GM = 8;
+  const int GM = deep_narrow ? 2 : 8;         // tiles along M per group; FC2's shape (4 N-tiles, K = 4096) measured 2.3 % faster with 2
   const int group = bid / (GM * tiles_n);
   const int first_m = group * GM;
   const int gsz = min(tiles_m - first_m, GM);
@@ -91,6 +91,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
   const int nwg = tiles_m * tiles_n;
+  const bool deep_narrow = tiles_n <= 4 && p.K >= 2048;
   const int G = gridDim.x;
   const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
   const int kend = p.K * 2;                  // bytes along K; one stage = 128 B; K % 128 == 0 (stages come in pairs)
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 #define TW_ADDR(nt) (tr + tw_base + ((((nt) * 2 + (qd >> 1)) ^ tw_sw) << 4))
 
   int idx = blockIdx.x;
-  TileId cur = decode_tile(idx, tiles_m, tiles_n);
+  TileId cur = decode_tile(idx, tiles_m, tiles_n, deep_narrow);
   const char* Ablk = (const char*)p.A + (size_t)cur.m0 * lda_b;
   const char* Wblk = (const char*)p.W + (size_t)cur.n0 * ldw_b;
 #define AOFF(m0v, r) ((unsigned)((min((m0v) + (r), p.M - 1) - (m0v)) * lda_b) + dchunk16)
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
     if (has_next) {
-      nxt = decode_tile(nidx, tiles_m, tiles_n);
+      nxt = decode_tile(nidx, tiles_m, tiles_n, deep_narrow);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
     }
