@@ -38,9 +38,6 @@ namespace {
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 constexpr int BM = 256, BN = 256;
-#ifndef RES_EARLY
-#define RES_EARLY 4                            // residual pieces (of 8 in flight) that leave one stage ahead of the epilogue
-#endif
 constexpr int BUF = 65536, WREG = 32768;    // one K=64 stage: A region | W region
 constexpr int RING = 2 * BUF;               // 131072
 constexpr int AUX_OFF = RING;               // 16 KiB
@@ -248,7 +245,6 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     // stages; without a next tile nxt == cur and they are recomputed to the same values).  They are re-derived from an
     // opaque copy of the lane id: as loop invariants the constants would be kept (spilled) across the main loop, and a
     // spill reload here carries a compiler-counted vmcnt wait that drains the DMA pipeline.
-    uint4 rres[8];                            // residual rows, 8 x 16 B per lane in flight (EPI_RESID)
     int lane_b = lane;
     asm volatile("" : "+v"(lane_b));
     const int dg_b = lane_b >> 3;
@@ -263,20 +259,6 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       if (has_next) STAGE_STATS((tile_iter + 1) & 1, nxt.m0);
       STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Anext, Wnext, aoff00, aoff01, 0));
       aoff10 = AOFF_B(arow_b + 64); aoff11 = AOFF_B(arow_b + 72);
-      if constexpr (EPI == EPI_RESID) {
-        // the first residual rows of the epilogue leave one stage ahead of it: their HBM latency (the rows were written a
-        // whole layer ago) would otherwise be paid with the matrix pipe idle at the head of every epilogue.  (Compiler-
-        // visible loads: its counted waits at their use see fewer outstanding operations than there are -- the DMA is
-        // asm -- and so over-wait, which is safe; the hand-placed vmcnt(8) keep covering what they must, every piece they
-        // retire being older than the 8 newest operations whatever those are.)
-        const unsigned rb_ = (unsigned)p.ldo * 2u;
-        const int tb_ = min(p.M - cur.m0, BM) * (int)rb_;
-        const __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc((char*)p.resid + (size_t)cur.m0 * rb_, 0, tb_, 0x00020000);
-        const unsigned lc_ = (unsigned)(cur.n0 + wc * 64 + (lane_b & 7) * 8) * 2u;
-#pragma unroll
-        for (int k = 0; k < RES_EARLY; ++k)
-          rres[k] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rr_, (unsigned)(wr * 128 + k * 8 + (lane_b >> 3)) * rb_ + lc_, 0, 0));
-      }
       STAGE(1, VM8, ISSUE_AH1(0, Anext, aoff10, aoff11, 0), ISSUE_WAH0(1, Anext, Wnext, aoff00, aoff01, 128));
     }
 #undef AOFF_B
@@ -336,14 +318,15 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     }
 
     // residual rows, 8 x 16 B per lane in flight (four 16-row blocks ahead of their use)
+    uint4 rres[8];
 #define LOAD_RES(k)                                                                           \
   do {                                                                                        \
     const unsigned off_ = (unsigned)(wr * 128 + (k) * 8 + row_l) * row_bytes + lcol_b;        \
     rres[(k) & 7] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off_, 0, 0)); \
   } while (0)
-    if constexpr (EPI == EPI_RESID) {          // (the first RES_EARLY were issued between the tile's last two stages)
+    if constexpr (EPI == EPI_RESID) {
 #pragma unroll
-      for (int k = RES_EARLY; k < 8; ++k) LOAD_RES(k);
+      for (int k = 0; k < 8; ++k) LOAD_RES(k);
     }
 
 #pragma unroll
