@@ -16,19 +16,23 @@
 // (applied to the per-lane SOURCE address of the DMA and to the read address), which makes every ds_read_b128 of a
 // 16-row x 4-chunk fragment conflict-free (checked exhaustively against the lane-group table).
 //
-// One K=64 stage = 4 phases, each {fragment reads, DMA issue} lgkmcnt(0) s_barrier {16 MFMA} s_barrier, the two wave
-// rows half a phase apart (one extra barrier) so that one issues MFMAs while the other reads LDS:
-//   P1: W(k 0..31), A(rows half 0, k 0..31)   P2: A(half 1, k 0..31)   P3: W(k 32..63), A(half 1, k 32..63)
-//   P4: A(half 0, k 32..63)
-// so the W rows and the A rows of half 1 of a buffer are last read in P3, the A rows of half 0 in P4.  Stage s+2 is
-// fetched into the buffer of stage s: W and A(half 1) in P4 of stage s, A(half 0) right behind P4; one counted wait
-// (vmcnt(6), before the first barrier of P4) retires stage s+1 one phase before its first read.
+// One K=64 stage = 2 phases, each {fragment reads, DMA issue, counted wait} lgkmcnt(0) s_barrier {32 MFMA} s_barrier, the
+// two wave rows (the two waves of every SIMD) half a phase apart (one extra barrier) so that one issues MFMAs while the
+// other reads LDS:
+//   PA: W of both k halves (8 fragments, kept in registers for the whole stage) + A(row half 0) of both k halves
+//   PB: A(row half 1) of both k halves
+// (the first version ran four phases of 16 MFMAs: twice the barrier hand-overs, each an idle matrix pipe for a barrier
+// round trip).  W and A(half 0) of a buffer are last read in PA, A(half 1) in PB, so stage s+2's W + A(half 0) are
+// fetched into the buffer of stage s in PB of stage s (6 pieces per wave) and A(half 1) of stage s+1 in PA of stage s
+// (2 pieces).  Each phase ends its read section with ONE counted wait, vmcnt(8), behind its own pieces: the 8 newest
+// stay in flight and what retires is what the NEXT phase reads, so every piece has two phases to land.
 // Ordering: a phase's reads are retired by lgkmcnt(0) BEFORE its first barrier, so rows are re-staged one phase after
 // their last read: when a wave issues DMA in phase p it has passed the second barrier of p-1, which the other wave row
 // only reaches after the first barrier of its own p-1, i.e. after its reads of p-1 have returned.  A stage is read one
 // phase after the wait that retired it (the later wave row waits one barrier later and reads one barrier later).
-// Across a tile boundary stages 0 and 1 of the next tile are complete in the pipeline BEFORE the epilogue's stores are
-// issued, so the first counted wait of the new tile may leave those 16-17 stores outstanding (vmcnt retires in order).
+// Across a tile boundary stage 0 and W/A(half 0) of stage 1 of the next tile are in the pipeline BEFORE the epilogue's
+// stores are issued, so the first two counted waits of the new tile may leave those 16-17 stores outstanding (vmcnt
+// retires in order).
 #include <stdlib.h>
 
 #include "common.h"
