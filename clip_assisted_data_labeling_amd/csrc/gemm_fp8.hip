@@ -12,9 +12,9 @@
 // Same structure as gemm_persist.hip (read its header for the pipeline and its ordering argument): persistent 256x256
 // tiles, 8 waves as 2(M) x 4(N), two LDS buffers of 128-BYTE row stages (K = 128 fp8 elements per stage) filled by
 // LDS-DMA pieces of 8 rows x 128 B = 8 whole cache lines (the earlier 64-byte-row ring issued twice the L1->L2 read
-// requests for the same bytes), four phases per stage with the half-phase stagger of the two wave rows, stages 0-1 of
+// requests for the same bytes), two phases per stage with the half-phase stagger of the two wave rows, stages 0-1 of
 // the next tile in the pipeline before the epilogue's stores, bf16 / e4m3 output through a wave-private LDS image.
-// Per stage and wave: 4 phases x 4 MFMAs of 64 cycles.  Buffer image: 1-KiB blocks of 8 rows x 128 B, 16-B chunk c of
+// Per stage and wave: 2 phases x 8 MFMAs of 64 cycles.  Buffer image: 1-KiB blocks of 8 rows x 128 B, 16-B chunk c of
 // row r at position c ^ ((r >> 1) & 7); a lane reads chunks (4kh + 2h, 4kh + 2h + 1) of its row: conflict-free for the
 // 32-row fragments (checked against the ds_read_b128 lane groups).  Every wave stages blocks of ONE parity (block index
 // = wave + 8i), so the swizzle term of the block parity is a per-wave constant of the DMA source offset.
@@ -130,8 +130,6 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                        \
       glds16((blk) + (kbyte) + (size_t)i_ * 64 * ldw_b, woff, smem, (b) * BUF + w_dma + i_ * 8192); \
   } while (0)
-#define ISSUE_P4(b, ablk, wblk, o10, o11, kbyte)                                            \
-  do { ISSUE_W(b, wblk, kbyte); ISSUE_AH1(b, ablk, o10, o11, kbyte); } while (0)
 #define LD_FRAG(dst, off, kh)                                                               \
   do {                                                                                      \
     const uint4 lo_ = *(const uint4*)(smem + (off) + (rd0 ^ ((kh) * 64)));                  \
