@@ -378,10 +378,14 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
           v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
           v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
           pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          const float r0 = __uint_as_float(pk[nt].x << 16), r1 = __uint_as_float(pk[nt].x & 0xffff0000u);
-          const float r2 = __uint_as_float(pk[nt].y << 16), r3 = __uint_as_float(pk[nt].y & 0xffff0000u);
-          s += (r0 + r1) + (r2 + r3);
-          ss += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+          // sum and sum of squares of the ROUNDED values, straight from the packed pairs: v_dot2c_f32_bf16 (products of
+          // bf16 are exact in fp32) instead of unpack + add + multiply-add, a third of the instructions
+          const bf16x2_t p0 = __builtin_bit_cast(bf16x2_t, pk[nt].x), p1 = __builtin_bit_cast(bf16x2_t, pk[nt].y);
+          const bf16x2_t one2 = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+          s = __builtin_amdgcn_fdot2_f32_bf16(p0, one2, s, false);
+          s = __builtin_amdgcn_fdot2_f32_bf16(p1, one2, s, false);
+          ss = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, ss, false);
+          ss = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, ss, false);
         }
         if (mw0 + mt * 16 + frow_e >= p.M) { s = 0.f; ss = 0.f; }
         s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
