@@ -157,12 +157,15 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
                  _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[4 + j] = *(const frag_t*)(smem + (b) * BUF + w_rd1 + j * 2048);
 #define LD_A2(b, half) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (b) * BUF + a_rd0 + ((half) * 8 + i * 2) * 1024);  \
                        _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[4 + i] = *(const frag_t*)(smem + (b) * BUF + a_rd1 + ((half) * 8 + i * 2) * 1024);
-#define MMA2(half)                                                                          \
+  // ZC: the first MFMA of every accumulator of a tile takes the constant 0 as its C operand instead of a zeroed register
+  // (128 v_mov per wave and tile with the matrix pipe idle otherwise)
+#define MMA2(half, ZC)                                                                      \
   do {                                                                                      \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
-      acc[(half) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kh * 4 + j], fa[kh * 4 + i], acc[(half) * 4 + i][j], 0, 0, 0); \
+      acc[(half) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kh * 4 + j], fa[kh * 4 + i],               \
+                                   ((ZC) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(half) * 4 + i][j], 0, 0, 0); \
   } while (0)
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
 #define WAIT_LDS()                                                                          \
@@ -173,10 +176,10 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   // {reads retired} barrier {32 MFMA} barrier; the sched_barrier keeps the register-only MFMAs behind the s_barrier.
   // (Handing over early -- the second barrier in front of the last four MFMAs, so that the other wave row starts while
   // these drain -- measured 7-8 % SLOWER end to end, with 16- and with 32-MFMA phases.)
-#define SYNC_MMA(half)                                                                      \
+#define SYNC_MMA(half, ZC)                                                                  \
   do {                                                                                      \
     WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0);                               \
-    __builtin_amdgcn_s_setprio(1); MMA2(half); __builtin_amdgcn_s_setprio(0);               \
+    __builtin_amdgcn_s_setprio(1); MMA2(half, ZC); __builtin_amdgcn_s_setprio(0);           \
     BARRIER();                                                                              \
   } while (0)
   // The counted wait of a phase, issued behind the phase's own pieces: PA has just issued 2, PB 6, and the pieces that
@@ -198,17 +201,18 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   do { ISSUE_W(b, wblk, kbyte); ISSUE_AH0(b, ablk, o00, o01, kbyte); } while (0)
   // one K=64 stage on buffer b = two phases of 32 MFMAs per wave.  PA: W (both k halves) and A(half 0), PA_ISSUE = the
   // A(half 1) rows of stage s+1 into the other buffer; PB: A(half 1), PB_ISSUE = W and A(half 0) of stage s+2 into this one
-#define STAGE(b, VMWAIT, PA_ISSUE, PB_ISSUE)                                                \
+#define STAGE_Z(b, ZC, VMWAIT, PA_ISSUE, PB_ISSUE)                                          \
   do {                                                                                      \
     LD_W2(b) __builtin_amdgcn_sched_barrier(0); LD_A2(b, 0)                                 \
     PA_ISSUE;                                                                               \
     VMWAIT;                                                                                 \
-    SYNC_MMA(0);                                                                            \
+    SYNC_MMA(0, ZC);                                                                        \
     LD_A2(b, 1)                                                                             \
     PB_ISSUE;                                                                               \
     VMWAIT;                                                                                 \
-    SYNC_MMA(1);                                                                            \
+    SYNC_MMA(1, ZC);                                                                        \
   } while (0)
+#define STAGE(b, VMWAIT, PA_ISSUE, PB_ISSUE) STAGE_Z(b, 0, VMWAIT, PA_ISSUE, PB_ISSUE)
 
   // ---- cold prologue of the first tile ----
   int tile_iter = 0;
@@ -222,18 +226,33 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 
   for (;;) {
     f32x4_t acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     frag_t fa[8], fb[8];
 
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 4] = __builtin_amdgcn_s_memtime(); }
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
-    for (int kb = 0; kb < kend - 256; kb += 256) {
-      STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
-      STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
+    // (not in the LayerNorm + activation instantiations: they sit at the register limit, and the extra copy of the stage
+    // pair made hipcc spill with reloads between stages)
+    constexpr bool ZERO_C = !(EPI == EPI_LNFOLD && ACT >= 0);
+    if (ZERO_C && kend > 256) {
+      // first stage pair of the tile: every accumulator starts from the constant 0 in its first MFMA
+      STAGE_Z(0, 1, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 256));
+      STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 384));
+      for (int kb = 256; kb < kend - 256; kb += 256) {
+        STAGE(0, VM8, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
+        STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
+      }
+    } else {                                 // (K = 128: the tile is its last stage pair)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+      if constexpr (!ZERO_C) {
+        for (int kb = 0; kb < kend - 256; kb += 256) {
+          STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
+          STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
+        }
+      }
     }
     // ---- last two stages: the DMA crosses into the next tile ----
     const int nidx = idx + G;
