@@ -21,6 +21,9 @@
 #include "common.h"
 #include "gemm.h"
 
+// instantiations with the register room for the peeled zero-C first stage pair (the others spill with it)
+#define ZERO_C_SET(EPI, ACT) ((EPI) == 2 && (ACT) <= 0)
+
 namespace {
 
 constexpr int BM = 256, BN = 256;
@@ -69,6 +72,7 @@ __device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n)
 //      2 = scale + bias (+ activation), then * out_inv_scale[n] -> e4m3 (the next GEMM's operand, no bf16 round trip)
 template <int EPI, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
+  constexpr bool ZERO_C_OK = ZERO_C_SET(EPI, ACT);
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -140,13 +144,15 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   // one A row half for both k halves (fa[2 kh + i])
 #define LD_W2(b) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int j = 0; j < 2; ++j) LD_FRAG(fb[kh * 2 + j], (b) * BUF + w_base + j * 4096, kh);
 #define LD_A2(b, half) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int i = 0; i < 2; ++i) LD_FRAG(fa[kh * 2 + i], (b) * BUF + a_base + ((half) * 2 + i) * 4096, kh);
-#define MMA(half)                                                                           \
+  // ZC: the first MFMA of every accumulator of a tile takes the constant 0 as C (gemm_persist.hip)
+#define MMA(half, ZC)                                                                       \
   do {                                                                                      \
     __builtin_amdgcn_s_setprio(1);                                                          \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                        \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                           \
     _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
-      acc[(half) * 2 + i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[kh * 2 + j], fa[kh * 2 + i], acc[(half) * 2 + i][j], 0, 0, \
+      acc[(half) * 2 + i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[kh * 2 + j], fa[kh * 2 + i],      \
+                                   ((ZC) && kh == 0) ? zero16 : acc[(half) * 2 + i][j], 0, 0,                        \
                                                                               0, 0x7f7f7f7f, 0, 0x7f7f7f7f);        \
     __builtin_amdgcn_s_setprio(0);                                                          \
   } while (0)
@@ -156,25 +162,26 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
-#define SYNC_MMA(half)                                                                      \
+#define SYNC_MMA(half, ZC)                                                                  \
   do {                                                                                      \
-    WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0); MMA(half); BARRIER();         \
+    WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0); MMA(half, ZC); BARRIER();     \
   } while (0)
 #define ISSUE_WAH0(b, ablk, wblk, o00, o01, kbyte)                                          \
   do { ISSUE_W(b, wblk, kbyte); ISSUE_AH0(b, ablk, o00, o01, kbyte); } while (0)
   // one K=128 stage on buffer b = two phases of 8 MFMAs (512 cycles) per wave (gemm_persist.hip).  PA: W (both k halves)
   // and A(half 0), PA_ISSUE = the A(half 1) rows of stage s+1 into the other buffer; PB: A(half 1), PB_ISSUE = W and
   // A(half 0) of stage s+2 into this one; each phase's counted wait sits behind its own pieces (the 8 newest stay in flight)
-#define STAGE(b, VMWAIT, PA_ISSUE, PB_ISSUE)                                                \
+#define STAGE(b, VMWAIT, PA_ISSUE, PB_ISSUE) STAGE_Z(b, 0, VMWAIT, PA_ISSUE, PB_ISSUE)
+#define STAGE_Z(b, ZC, VMWAIT, PA_ISSUE, PB_ISSUE)                                          \
   do {                                                                                      \
     LD_W2(b) __builtin_amdgcn_sched_barrier(0); LD_A2(b, 0)                                 \
     PA_ISSUE;                                                                               \
     VMWAIT;                                                                                 \
-    SYNC_MMA(0);                                                                            \
+    SYNC_MMA(0, ZC);                                                                        \
     LD_A2(b, 1)                                                                             \
     PB_ISSUE;                                                                               \
     VMWAIT;                                                                                 \
-    SYNC_MMA(1);                                                                            \
+    SYNC_MMA(1, ZC);                                                                        \
   } while (0)
 #define VM8 asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
   // First two waits after an epilogue: what they need was issued before the epilogue's stores and vmcnt retires in order,
@@ -202,19 +209,31 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
 
   for (;;) {
     f32x16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     i32x8_t fa[4], fb[4];
 
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
-    for (int kb = 0; kb < kend - 256; kb += 256) {
-      STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
-      STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
+    constexpr bool ZERO_C = ZERO_C_OK;
+    if (ZERO_C && kend > 256) {
+      // first stage pair of the tile: every accumulator starts from the constant 0 in its first MFMA
+      STAGE_Z(0, 1, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 256));
+      STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 384));
+      for (int kb = 256; kb < kend - 256; kb += 256) {
+        STAGE(0, VM8, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
+        STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = zero16;
+      if constexpr (!ZERO_C) {
+        for (int kb = 0; kb < kend - 256; kb += 256) {
+          STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
+          STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
+        }
+      }
     }
     // ---- last two stages: the DMA crosses into the next tile (or re-fetches this one into dead buffers) ----
     const int nidx = idx + G;
