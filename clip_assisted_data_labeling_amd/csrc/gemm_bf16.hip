@@ -88,10 +88,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
   const int m0 = tm * BM, n0 = tn * BN;
 
   f32x4_t acc[8][4];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15;
 
   {
@@ -134,12 +130,14 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
                  _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[4 + j] = *(const frag_t*)(smem + (b) * BUF + w_rd1 + j * 2048);
 #define LD_A2(b, half) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (b) * BUF + a_rd0 + ((half) * 8 + i * 2) * 1024);  \
                        _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[4 + i] = *(const frag_t*)(smem + (b) * BUF + a_rd1 + ((half) * 8 + i * 2) * 1024);
-#define MMA2(half)                                                                          \
+  // ZC: the first MFMA of every accumulator takes the constant 0 as C (no zeroed registers)
+#define MMA2(half, ZC)                                                                      \
   do {                                                                                      \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
-      acc[(half) * 4 + i][j] = Mfma<T>::run(fb[kh * 4 + j], fa[kh * 4 + i], acc[(half) * 4 + i][j]); \
+      acc[(half) * 4 + i][j] = Mfma<T>::run(fb[kh * 4 + j], fa[kh * 4 + i],                 \
+                                            ((ZC) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(half) * 4 + i][j]); \
   } while (0)
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
 #define WAIT_LDS()                                                                          \
@@ -147,25 +145,26 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
     __builtin_amdgcn_sched_barrier(0);                                                      \
   } while (0)
-#define SYNC_MMA(half)                                                                      \
+#define SYNC_MMA(half, ZC)                                                                  \
   do {                                                                                      \
     WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0);                               \
-    __builtin_amdgcn_s_setprio(1); MMA2(half); __builtin_amdgcn_s_setprio(0);               \
+    __builtin_amdgcn_s_setprio(1); MMA2(half, ZC); __builtin_amdgcn_s_setprio(0);           \
     BARRIER();                                                                              \
   } while (0)
 #define VM8 asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
   // stage at byte offset kb on buffer b: PA issues A(half 1) of the next stage, PB issues W + A(half 0) of the one after
   // (both clamped to the last stage's k range once the tile runs out: harmless re-fetches into rows that are dead)
-#define STAGE(b, kb)                                                                        \
+#define STAGE(b, kb) STAGE_Z(b, kb, 0)
+#define STAGE_Z(b, kb, ZC)                                                                  \
   do {                                                                                      \
     LD_W2(b) __builtin_amdgcn_sched_barrier(0); LD_A2(b, 0)                                 \
     ISSUE_AH1((b) ^ 1, min((kb) + 128, klast));                                             \
     VM8;                                                                                    \
-    SYNC_MMA(0);                                                                            \
+    SYNC_MMA(0, ZC);                                                                        \
     LD_A2(b, 1)                                                                             \
     { const int k2_ = min((kb) + 256, klast); ISSUE_W(b, k2_); ISSUE_AH0(b, k2_); }         \
     VM8;                                                                                    \
-    SYNC_MMA(1);                                                                            \
+    SYNC_MMA(1, ZC);                                                                        \
   } while (0)
 
     ISSUE_W(0, 0); ISSUE_AH0(0, 0); ISSUE_AH1(0, 0);
@@ -173,9 +172,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_kernel(const GemmParams p) {
     VM8;                                     // W and A(half 0) of stage 0 have landed
     BARRIER();
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
-    for (int kb = 0; kb < kend; kb += 256) {
+    STAGE_Z(0, 0, 1);                        // first stage: the accumulators start from the constant 0
+    STAGE(1, 128);                           // K % 128 == 0: stages come in pairs
+    for (int kb = 256; kb < kend; kb += 256) {
       STAGE(0, kb);
-      STAGE(1, kb + 128);                    // K % 128 == 0: stages come in pairs
+      STAGE(1, kb + 128);
     }
     if (wr == 0) BARRIER();                  // re-align the two wave rows
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the redundant tail pieces land before the LDS is released
