@@ -112,8 +112,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   const int w_dma = WREG + 4 * w * 1024;                               // + i*1024 (+ buffer)
   // fragment reads: row frow, k-chunk kq of a 16-row block; the second k half (k 32..63) is the address ^ 64
   const int rdl = (frow >> 3) * 1024 + (frow & 7) * 128 + ((((lane >> 4) ^ (frow & 6))) << 4);
-  const int a_rd0 = wr * 16 * 1024 + rdl, a_rd1 = a_rd0 ^ 64;
-  const int w_rd0 = WREG + wc * 8 * 1024 + rdl, w_rd1 = w_rd0 ^ 64;
+  const int a_rd0 = wr * 16 * 1024 + rdl;
+  const int w_rd0 = WREG + wc * 8 * 1024 + rdl;
 
 #define TW_ADDR(nt) (tr + tw_base + ((((nt) * 2 + (qd >> 1)) ^ tw_sw) << 4))
 
@@ -153,10 +153,15 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   } while (0)
   // fragments of one phase: W for both k halves (fb[4 kh + j], kept for both phases of the stage) and one A row half for
   // both k halves (fa[4 kh + i]); the k 0..31 fragments are read first, they feed the first MFMAs
-#define LD_W2(b) _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (b) * BUF + w_rd0 + j * 2048);  \
-                 _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[4 + j] = *(const frag_t*)(smem + (b) * BUF + w_rd1 + j * 2048);
-#define LD_A2(b, half) _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (b) * BUF + a_rd0 + ((half) * 8 + i * 2) * 1024);  \
-                       _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[4 + i] = *(const frag_t*)(smem + (b) * BUF + a_rd1 + ((half) * 8 + i * 2) * 1024);
+  // (the address of the second k half is re-derived where it is used -- one v_xor in an asm statement that hipcc cannot
+  // hoist: kept across the whole kernel these two addresses were what the register-tight instantiations spilled)
+#define XOR64(dst, src) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(dst) : "v"(src))
+#define LD_W2(b) { int w_rd1_; XOR64(w_rd1_, w_rd0);                                                                                \
+                   _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (b) * BUF + w_rd0 + j * 2048);      \
+                   _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[4 + j] = *(const frag_t*)(smem + (b) * BUF + w_rd1_ + j * 2048); }
+#define LD_A2(b, half) { int a_rd1_; XOR64(a_rd1_, a_rd0);                                                                          \
+                         _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (b) * BUF + a_rd0 + ((half) * 8 + i * 2) * 1024);  \
+                         _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[4 + i] = *(const frag_t*)(smem + (b) * BUF + a_rd1_ + ((half) * 8 + i * 2) * 1024); }
   // ZC: the first MFMA of every accumulator of a tile takes the constant 0 as its C operand instead of a zeroed register
   // (128 v_mov per wave and tile with the matrix pipe idle otherwise)
 #define MMA2(half, ZC)                                                                      \
@@ -231,10 +236,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 4] = __builtin_amdgcn_s_memtime(); }
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
-    // (not in the LayerNorm + activation instantiations: they sit at the register limit, and the extra copy of the stage
-    // pair made hipcc spill with reloads between stages)
-    constexpr bool ZERO_C = !(EPI == EPI_LNFOLD && ACT >= 0);
-    if (ZERO_C && kend > 256) {
+    if (kend > 256) {
       // first stage pair of the tile: every accumulator starts from the constant 0 in its first MFMA
       STAGE_Z(0, 1, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 256));
       STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 384));
@@ -247,12 +249,6 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-      if constexpr (!ZERO_C) {
-        for (int kb = 0; kb < kend - 256; kb += 256) {
-          STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
-          STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
-        }
-      }
     }
     // ---- last two stages: the DMA crosses into the next tile ----
     const int nidx = idx + G;
