@@ -178,13 +178,73 @@ def _from_transformers(hf: Dict[str, torch.Tensor], cfg: ViTConfig) -> Dict[str,
     return sd
 
 
+# file names open_clip leaves in `cache_dir` for pretrained='openai' (its download keeps the URL's basename; these are
+# OpenAI's TorchScript archives) [upstream: open_clip pretrained.py]
+_OPENAI_JIT_NAMES = {"ViT-B-32": "ViT-B-32.pt", "ViT-B-16": "ViT-B-16.pt", "ViT-L-14": "ViT-L-14.pt",
+                     "ViT-L-14-336": "ViT-L-14-336px.pt"}
+_HUB_FILES = ("open_clip_model.safetensors", "open_clip_pytorch_model.bin", "model.safetensors", "pytorch_model.bin")
+_TIMM_ARCH = {"ViT-B-32": "vit_base_patch32_clip_224", "ViT-B-16": "vit_base_patch16_clip_224",
+              "ViT-L-14": "vit_large_patch14_clip_224", "ViT-L-14-336": "vit_large_patch14_clip_336"}
+
+
+def _read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
+    """One checkpoint file -> flat {name: tensor}.  Handles safetensors, plain `torch.save`d state dicts (optionally
+    wrapped in {'state_dict': ...}) and TorchScript archives (OpenAI's `ViT-L-14.pt` is one: `torch.load` with
+    `weights_only=True` rejects it, so the archive is opened with `torch.jit.load` and only its state dict is kept --
+    the scripted code is never run)."""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    try:
+        raw = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as plain_err:                 # TorchScript archive (RuntimeError) or pickled non-tensor objects
+        try:
+            raw = torch.jit.load(path, map_location="cpu").state_dict()
+        except Exception as jit_err:
+            raise RuntimeError(f"cannot read checkpoint {path}: not a state dict ({plain_err}) nor a TorchScript "
+                               f"archive ({jit_err})") from jit_err
+    if isinstance(raw, dict) and "state_dict" in raw and isinstance(raw["state_dict"], dict):
+        raw = raw["state_dict"]
+    if isinstance(raw, dict) and any(k.startswith("module.") for k in raw):      # DataParallel-saved training checkpoints
+        raw = {k[len("module."):] if k.startswith("module.") else k: v for k, v in raw.items()}
+    return {k: v for k, v in raw.items() if isinstance(v, torch.Tensor)}
+
+
+def _hub_snapshots(cache_dir: str, arch: str, pretrained: str):
+    """Checkpoint files inside a Hugging Face hub cache tree (`models--<org>--<repo>/snapshots/<rev>/<file>`), which is
+    what open_clip leaves in `cache_dir` for hf-hub hosted tags; best name match first."""
+    import glob
+    found = []
+    arch_l, tag_l = arch.lower(), pretrained.lower().replace("_", "-")
+    for repo in sorted(glob.glob(os.path.join(cache_dir, "models--*"))):
+        name = os.path.basename(repo).lower().replace("_", "-")
+        score = 0
+        if arch_l in name or _TIMM_ARCH.get(arch, "~").replace("_", "-") in name:
+            score += 2
+        if tag_l and (tag_l in name or name.endswith("." + tag_l)):
+            score += 1
+        for fname in _HUB_FILES:
+            hits = sorted(glob.glob(os.path.join(repo, "snapshots", "*", fname)))
+            if hits:
+                found.append((-score, hits[-1]))
+                break
+    return [p for _, p in sorted(found)]
+
+
 def load_weights(model_name: str, model_path: Optional[str]) -> Dict[str, torch.Tensor]:
     """Resolve the weights the reference would have fetched through open_clip
     (/root/reference/utils/embedder.py:66-73, `cache_dir=model_path`).
 
     * pretrained tag 'seed<N>'  -> seeded synthetic weights (bench / parity);
-    * otherwise a local file `<model_path>/<arch>-<pretrained>.{pt,pth,bin,safetensors}` (or
-      `model_path` itself when it is a file) holding an OpenAI/open_clip/transformers state dict.
+    * `model_path` is a file     -> that file;
+    * `model_path` is a directory, searched in this order:
+        1. what open_clip's own download leaves there for the `openai` tag: `ViT-L-14.pt`, `ViT-L-14-336px.pt`,
+           `ViT-B-32.pt`, `ViT-B-16.pt` (TorchScript archives, fp16);
+        2. a Hugging Face hub cache tree `models--*/snapshots/*/open_clip_model.safetensors|open_clip_pytorch_model.bin`
+           (hf-hub hosted tags, and `openai` in newer open_clip releases);
+        3. `<arch>-<pretrained>.{pt,pth,bin,safetensors}` / `<arch>_<pretrained>.*` (a hand-placed file).
+      Files may hold an OpenAI / open_clip state dict (with or without the `visual.` prefix), a `transformers`
+      CLIPVisionModelWithProjection dict, in any float dtype (fp16 archives are up-cast).
     No download is attempted: a missing file raises FileNotFoundError.
     """
     cfg = config_for(model_name)
@@ -195,19 +255,22 @@ def load_weights(model_name: str, model_path: Optional[str]) -> Dict[str, torch.
     if model_path and os.path.isfile(model_path):
         candidates.append(model_path)
     elif model_path:
+        if pretrained == "openai" and arch in _OPENAI_JIT_NAMES:
+            candidates.append(os.path.join(model_path, _OPENAI_JIT_NAMES[arch]))
+        candidates += _hub_snapshots(model_path, arch, pretrained)
         for ext in ("pt", "pth", "bin", "safetensors"):
             candidates.append(os.path.join(model_path, f"{arch}-{pretrained}.{ext}"))
             candidates.append(os.path.join(model_path, f"{arch}_{pretrained}.{ext}"))
+    errors = []
     for path in candidates:
-        if os.path.isfile(path):
-            if path.endswith(".safetensors"):
-                from safetensors.torch import load_file
-                raw = load_file(path)
-            else:
-                raw = torch.load(path, map_location="cpu", weights_only=True)
-                if isinstance(raw, dict) and "state_dict" in raw:
-                    raw = raw["state_dict"]
-            return normalise_state_dict(raw, cfg)
+        if not os.path.isfile(path):
+            continue
+        try:
+            return normalise_state_dict(_read_checkpoint(path), cfg)
+        except (KeyError, ValueError) as e:          # another architecture's checkpoint in the same cache: keep looking
+            errors.append(f"{path}: {e}")
+    if errors:
+        raise ValueError(f"No checkpoint under {model_path!r} fits {model_name!r}: " + "; ".join(errors))
     raise FileNotFoundError(
         f"No local weights for {model_name!r}: looked for {candidates or '(no model_path given)'}; "
         "this build never downloads checkpoints. Pass model_path=<dir or file>, or use the "

@@ -128,6 +128,80 @@ def test_state_dict_round_trip_through_file(tmp_path):
     assert all(torch.equal(back[k], sd[k]) for k in sd)
 
 
+def _module_tree(named_tensors, half=True):
+    """An nn.Module whose state dict has exactly the given dotted names (nested containers), like the CLIP object inside
+    OpenAI's TorchScript archives: parameters in fp16, `visual.` prefix, plus non-visual entries that must be ignored."""
+    root = torch.nn.Module()
+    for name, t in named_tensors.items():
+        mod = root
+        parts = name.split(".")
+        for p_ in parts[:-1]:
+            if not hasattr(mod, p_):
+                mod.add_module(p_, torch.nn.Module())
+            mod = getattr(mod, p_)
+        mod.register_parameter(parts[-1], torch.nn.Parameter((t.half() if half else t).clone(), requires_grad=False))
+    return root
+
+
+def test_load_weights_from_what_open_clip_leaves_in_cache_dir(tmp_path):
+    """/root/reference/utils/embedder.py:66-73 passes `cache_dir=model_path`; open_clip then leaves there either OpenAI's
+    TorchScript archive named after the download URL (`ViT-L-14.pt`, `ViT-L-14-336px.pt`, ...: fp16, whole CLIP model) or
+    a Hugging Face hub tree `models--*/snapshots/*/open_clip_*`.  Both must load, and `weights_only=True` alone cannot
+    open the first kind."""
+    cfg = vit_config.ARCHS["ViT-tiny-test"]
+    sd = {k: v.half().float() for k, v in vit_config.seeded_state_dict(cfg, 9).items()}    # representable in fp16
+    full = {"visual." + k: v for k, v in sd.items()}
+    full["logit_scale"] = torch.tensor(4.6)                                  # non-visual entries of the real archives
+    full["token_embedding.weight"] = torch.zeros(8, 4)
+
+    # OpenAI's archive holds the model itself (keys start at `visual.`)
+    tree = _module_tree(full)
+    jit_dir = tmp_path / "jit"
+    jit_dir.mkdir()
+    vit_config._OPENAI_JIT_NAMES["ViT-tiny-test"] = "ViT-tiny-test.pt"
+    try:
+        scripted = torch.jit.trace(_TraceWrap(tree), torch.zeros(1), check_trace=False)
+        scripted.save(str(jit_dir / "ViT-tiny-test.pt"))
+        with pytest.raises(Exception):
+            torch.load(str(jit_dir / "ViT-tiny-test.pt"), map_location="cpu", weights_only=True)   # what round 1 did
+        back = vit_config.load_weights("ViT-tiny-test/openai", str(jit_dir))
+        assert all(back[k].dtype == torch.float32 and torch.equal(back[k], sd[k]) for k in sd)
+    finally:
+        del vit_config._OPENAI_JIT_NAMES["ViT-tiny-test"]
+    # HF hub tree, safetensors and .bin, next to ANOTHER architecture's checkpoint that must be skipped
+    from safetensors.torch import save_file
+    hub = tmp_path / "hub"
+    snap = hub / "models--laion--CLIP-ViT-tiny-test-laion2B-s32B-b82K" / "snapshots" / "0123abcd"
+    snap.mkdir(parents=True)
+    save_file({k: v.contiguous() for k, v in full.items()}, str(snap / "open_clip_model.safetensors"))
+    other_cfg = vit_config.ARCHS["ViT-small-test"]
+    other = hub / "models--laion--CLIP-ViT-small-test-laion2B-s32B-b82K" / "snapshots" / "ffff"
+    other.mkdir(parents=True)
+    torch.save({"visual." + k: v for k, v in vit_config.seeded_state_dict(other_cfg, 1).items()},
+               str(other / "open_clip_pytorch_model.bin"))
+    back = vit_config.load_weights("ViT-tiny-test/laion2b_s32b_b82k", str(hub))
+    assert all(torch.equal(back[k], sd[k]) for k in sd)
+    back2 = vit_config.load_weights("ViT-small-test/laion2b_s32b_b82k", str(hub))
+    assert back2["conv1.weight"].shape[0] == other_cfg.width
+    with pytest.raises(ValueError):                                           # files exist, none fits
+        vit_config.load_weights("ViT-long-test/laion2b_s32b_b82k", str(hub))
+    with pytest.raises(FileNotFoundError):
+        vit_config.load_weights("ViT-tiny-test/openai", str(tmp_path / "empty"))
+
+
+class _TraceWrap(torch.nn.Module):
+    """Gives the parameter tree a traceable forward while keeping the state-dict names unprefixed."""
+    def __init__(self, tree):
+        super().__init__()
+        for n, c in tree.named_children():
+            self.add_module(n, c)
+        for n, p_ in tree.named_parameters(recurse=False):
+            self.register_parameter(n, p_)
+
+    def forward(self, x):
+        return x + self.logit_scale.float()
+
+
 def test_crop_geometry_matches_survey_appendix_c():
     boxes = {n: (k, b) for n, k, b in crop_boxes(224, 224)}
     assert boxes["centre_crop"] == ("crop", (0, 0, 224, 224))
