@@ -63,10 +63,10 @@ SIGNATURES = {
     "preproc_axis_tables": (c_int, [c_int, c_int, c_int, c_int, POINTER(c_int), POINTER(c_int), c_int, POINTER(c_int)]),
     "clipenc_profile_enable": (c_int, [c_void_p, c_int]),
     "clipenc_profile_kinds": (c_int, []),
+    "clipenc_clock_probe": (c_int, [c_int, c_void_p, c_int, c_void_p]),
     "clipenc_profile_read": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(ctypes.c_double), POINTER(c_longlong),
                                      POINTER(ctypes.c_double), c_int]),
     "clipenc_op_gemm_nt": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "clipenc_op_gemm_nt_stamps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "clipenc_op_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fctrain_create": (c_int, [c_int, POINTER(c_int), c_float_pp, c_float_pp, c_float, c_int, POINTER(c_void_p)]),
     "fctrain_destroy": (c_int, [c_void_p]),
@@ -88,7 +88,12 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p]),
     "clipenc_op_gemm_fp8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p]),
-    "clipenc_debug_run_layers": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "clipenc_forward_tokens": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+}
+
+# include/clipenc_diag.h: only in libclipenc_hip_diag.so (`make diag`), bound when present (developer tools)
+DIAG_SIGNATURES = {
+    "clipenc_op_gemm_nt_stamps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None
@@ -115,6 +120,11 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library drift: fail loudly
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in DIAG_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 

@@ -630,17 +630,9 @@ template <int NKT, int CT, int NCW>
 hipError_t launch_attn_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
                               const float* out_inv, hipStream_t stream) {
   const int lds = 2 * 2 * NKT * 32 * 128 + NCW * (NCW <= 7 ? 2048 : 1024) + 2048;
-  static bool attr_set = false;
-  static int n_cu = 256;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_stream_kernel<NKT, CT, NCW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  static DeviceKernelSetup setup;             // per device: LDS opt-in + CU count (common.h)
+  int n_cu = 256;
+  if (hipError_t e = setup.ensure((const void*)attn_stream_kernel<NKT, CT, NCW>, lds, &n_cu); e != hipSuccess) return e;
   const int n_tasks = n_crops * heads;
   int grid = n_tasks < n_cu ? n_tasks : n_cu;
   while ((n_tasks + grid - 1) / grid > 496) grid *= 2;      // per-workgroup task counters live in 2 KiB of LDS
@@ -655,12 +647,8 @@ template <int NKT>
 hipError_t launch_attn(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
                        const float* out_inv, hipStream_t stream) {
   const int lds = NKT * 32 * 128 * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)attn_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static DeviceKernelSetup setup;
+  if (hipError_t e = setup.ensure((const void*)attn_kernel<NKT>, lds, nullptr); e != hipSuccess) return e;
   const float scale_log2e = 0.125f * 1.44269504088896340736f;   // 64^-0.5 * log2(e)
   hipLaunchKernelGGL((attn_kernel<NKT>), dim3(n_crops * heads), dim3(256), lds, stream, qkv, out, n_tok, width,
                      heads, scale_log2e, out_inv);

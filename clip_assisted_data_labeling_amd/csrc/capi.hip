@@ -1,6 +1,9 @@
 // C ABI of libclipenc_hip.so (see include/clipenc.h): handle management, weight preparation
 // (bf16 conversion + LayerNorm folding), workspace, and the kernel chain of the ViT tower.
 #include "../../include/clipenc.h"
+#ifdef CLIPENC_DIAG
+#include "../../include/clipenc_diag.h"
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -176,9 +179,12 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-int ensure_workspace(clipenc_s* e, int n_crops) {
-  const int c = std::min(n_crops, e->chunk);
-  if (c <= e->ws_chunk && e->ws_precision == e->precision) return 0;
+// (Re)allocates the workspace of one pass of `chunk` crops at the handle's precision.  Called by clipenc_create,
+// clipenc_set_chunk and clipenc_set_precision only (hipMalloc / hipFree synchronise the device): the encode calls never
+// allocate.
+int ensure_workspace(clipenc_s* e) {
+  const int c = e->chunk;
+  if (c == e->ws_chunk && e->ws_precision == e->precision) return 0;
   const clipenc_config& g = e->cfg;
   const size_t T = (size_t)c * e->tokens, P = (size_t)c * (e->tokens - 1);
   const size_t parts = g.width / 256;
@@ -329,7 +335,9 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
   if (g.heads * 64 != g.width) return fail("only head dim 64 is built (width %d, heads %d)", g.width, g.heads);
   if (g.patch <= 0 || g.image_size % g.patch != 0) return fail("image_size %d not divisible by patch %d", g.image_size, g.patch);
   if (g.embed_dim <= 0 || g.embed_dim > 1024) return fail("embed_dim %d out of range (1..1024)", g.embed_dim);
-  if (g.width > 2048) return fail("width %d > 2048 not built", g.width);
+  if (g.width > 1024)
+    return fail("width %d > 1024 not built: the LayerNorm-folded GEMM keeps one row-statistics part per 256 columns of the "
+                "residual stream and its LDS layout holds 4 parts (ViT-B = 768, ViT-L = 1024)", g.width);
   if (g.layers < 1) return fail("layers %d < 1", g.layers);
   if (g.act != CLIPENC_ACT_QUICK_GELU && g.act != CLIPENC_ACT_GELU_ERF) return fail("unknown activation %d", g.act);
   const int grid = g.image_size / g.patch, tokens = grid * grid + 1;
@@ -419,6 +427,7 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
     d.cs_qkv = (float*)(db + lo[l].cs_qkv); d.b_qkv = (float*)(db + lo[l].b_qkv); d.b_out = (float*)(db + lo[l].b_out);
     d.cs_fc = (float*)(db + lo[l].cs_fc); d.b_fc = (float*)(db + lo[l].b_fc); d.b_proj = (float*)(db + lo[l].b_proj);
   }
+  if (int rc = ensure_workspace(e)) { clipenc_destroy(e); return rc; }
   *out = e;
   return 0;
 }
@@ -496,13 +505,16 @@ int clipenc_set_precision(clipenc_t e, int precision) {
     e->layers8.swap(l8);
   }
   e->precision = precision;
-  return 0;
+  return ensure_workspace(e);                              // the fp8 operand buffers belong to the workspace
 }
 
 int clipenc_set_chunk(clipenc_t e, int chunk_crops) {
   if (!e) return fail("NULL handle");
   if (chunk_crops < 1) return fail("chunk_crops %d < 1", chunk_crops);
+  HIP_TRY(hipSetDevice(e->device));
+  const int old_chunk = e->chunk;
   e->chunk = chunk_crops;
+  if (int rc = ensure_workspace(e)) { e->chunk = old_chunk; return rc; }
   return 0;
 }
 
@@ -524,7 +536,7 @@ int clipenc_encode(clipenc_t e, const void* crops_dev, int n_crops, int in_dtype
   if (in_dtype != CLIPENC_IN_F32 && in_dtype != CLIPENC_IN_F16 && in_dtype != CLIPENC_IN_U8) return fail("unknown in_dtype %d", in_dtype);
   if ((in_dtype != CLIPENC_IN_U8 && ((uintptr_t)crops_dev & 1)) || ((uintptr_t)emb_dev & 3)) return fail("misaligned device pointer");
   HIP_TRY(hipSetDevice(e->device));
-  if (int rc = ensure_workspace(e, n_crops)) return rc;
+  if (e->ws_chunk != e->chunk || e->ws_precision != e->precision) return fail("workspace not allocated (internal error)");
   hipStream_t st = (hipStream_t)stream;
   const clipenc_config& g = e->cfg;
   const size_t cb = crop_bytes(g, in_dtype);
@@ -544,6 +556,14 @@ int clipenc_profile_enable(clipenc_t e, int on) {
   HIP_TRY(hipSetDevice(e->device));
   e->prof.collect();
   e->prof.on = on != 0;
+  return 0;
+}
+
+int clipenc_clock_probe(int device, unsigned long long* out2_dev, int spin_us, void* stream) {
+  if (!out2_dev) return fail("clock_probe: NULL device pointer");
+  if (spin_us < 1 || spin_us > 10000) return fail("clock_probe: spin_us %d outside 1..10000", spin_us);
+  HIP_TRY(hipSetDevice(device));
+  HIP_TRY(ce_clock_probe(out2_dev, spin_us * 100, (hipStream_t)stream));
   return 0;
 }
 
@@ -567,13 +587,13 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
   return 0;
 }
 
-int clipenc_debug_run_layers(clipenc_t e, const void* crops_dev, int n_crops, int in_dtype, int n_layers,
+int clipenc_forward_tokens(clipenc_t e, const void* crops_dev, int n_crops, int in_dtype, int n_layers,
                              void* x_out, void* stream) {
   if (!e || !crops_dev || !x_out) return fail("NULL argument");
   if (n_crops < 1 || n_crops > e->chunk) return fail("n_crops %d outside 1..chunk(%d)", n_crops, e->chunk);
   if (n_layers < 0 || n_layers > e->cfg.layers) return fail("n_layers %d out of range", n_layers);
   HIP_TRY(hipSetDevice(e->device));
-  if (int rc = ensure_workspace(e, n_crops)) return rc;
+  if (e->ws_chunk != e->chunk || e->ws_precision != e->precision) return fail("workspace not allocated (internal error)");
   hipStream_t st = (hipStream_t)stream;
   if (int rc = run_tower(e, crops_dev, n_crops, in_dtype, n_layers, st)) return rc;
   HIP_TRY(hipMemcpyAsync(x_out, e->x, (size_t)n_crops * e->tokens * e->cfg.width * 2, hipMemcpyDeviceToDevice, st));
@@ -584,8 +604,12 @@ int fcreg_create(int n_layers, const int* sizes, const float* const* W, const fl
                  int device, fcreg_t* out) {
   if (!sizes || !W || !b || !out) return fail("fcreg_create: NULL argument");
   if (n_layers < 1 || n_layers > CE_FC_MAX_LAYERS) return fail("n_layers %d outside 1..%d", n_layers, CE_FC_MAX_LAYERS);
-  for (int l = 0; l <= n_layers; ++l)
+  for (int l = 0; l <= n_layers; ++l) {
     if (sizes[l] < 1) return fail("layer size %d at %d", sizes[l], l);
+    if (sizes[l] > CE_FC_MAX_WIDTH)
+      return fail("layer %d is %d wide; the fused regressor kernel keeps a row block of every layer in LDS and takes at most %d "
+                  "(e.g. 6 crops x 768 = 4608)", l, sizes[l], CE_FC_MAX_WIDTH);
+  }
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail("device %d out of range (%d visible)", device, ndev);
@@ -869,6 +893,7 @@ int preproc_axis_tables(int in_size, int out_size, int out0, int n_out, int* bou
   return 0;
 }
 
+#ifdef CLIPENC_DIAG
 int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n, int k, void* out_dev,
                               unsigned long long* stamps_dev, void* stream) {
   GemmParams p{};
@@ -878,6 +903,7 @@ int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n
   if (err != hipSuccess) return fail("gemm_nt_stamps failed: %s", hipGetErrorString(err));
   return 0;
 }
+#endif
 
 int clipenc_op_attention(const void* qkv_dev, void* out_dev, int n_crops, int n_tok, int width, int heads, void* stream) {
   hipError_t err = ce_attention(qkv_dev, out_dev, n_crops, n_tok, width, heads, nullptr, (hipStream_t)stream);

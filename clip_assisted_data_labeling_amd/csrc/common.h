@@ -36,3 +36,28 @@ static inline float host_bf16_to_f32(uint16_t h) {
 
 #define CE_ACT_QUICK_GELU 0
 #define CE_ACT_GELU_ERF 1
+
+// One-time launch setup of a kernel PER DEVICE: opts it into `lds_bytes` of dynamic LDS on the current device and returns
+// that device's CU count.  The C ABI takes a device per handle, so one process may launch the same kernel on several
+// GPUs: a single function-local `static bool` would set the attribute on the first device only and reuse its grid size.
+// Thread-safe: plain atomics on a small table, the (idempotent) setup may run twice under a race.
+#include <atomic>
+struct DeviceKernelSetup {
+  static constexpr int kMaxDevices = 64;
+  std::atomic<int> cu[kMaxDevices];
+  hipError_t ensure(const void* func, int lds_bytes, int* n_cu) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
+    int c = cu[dev].load(std::memory_order_acquire);
+    if (c == 0) {
+      if (lds_bytes > 0 && (e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes)) != hipSuccess) return e;
+      if ((e = hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+      if (c <= 0) c = 256;
+      cu[dev].store(c, std::memory_order_release);
+    }
+    if (n_cu) *n_cu = c;
+    return hipSuccess;
+  }
+};

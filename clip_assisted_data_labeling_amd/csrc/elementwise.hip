@@ -240,3 +240,29 @@ hipError_t ce_head(const void* x, const float* gamma, const float* beta, const f
                      (const bf16_t*)x, gamma, beta, proj, emb, n_crops, n_tok, width, embed, eps, normalize);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Clock probe (measurement support, not on the hot path): one wave reads the shader-cycle counter (s_memtime) and the
+// constant 100 MHz counter (s_memrealtime) around a short spin; cycles / ticks x 100 = the shader clock in MHz that the
+// chip is holding at that moment.  bench.py launches it on a second stream while the encoder runs, so that it lands in
+// the gaps between the persistent kernels and reads the clock the board grants UNDER that load (DVFS moves on a
+// millisecond scale; MI355X_MICROARCH.md 'DVFS give-back' item 6).  Its result goes to a buffer of its own.
+__global__ void clock_probe_kernel(unsigned long long* out, int spin_ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = r0;
+  for (int guard = 0; guard < (1 << 20) && (long long)(r1 - r0) < spin_ticks; ++guard) {   // bounded spin
+    __builtin_amdgcn_s_sleep(8);
+    r1 = __builtin_amdgcn_s_memrealtime();
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  r1 = __builtin_amdgcn_s_memrealtime();
+  out[0] = c1 - c0;
+  out[1] = r1 - r0;
+}
+
+hipError_t ce_clock_probe(unsigned long long* out2, int spin_ticks, hipStream_t stream) {
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, stream, out2, spin_ticks);
+  return hipGetLastError();
+}

@@ -31,7 +31,9 @@ struct GemmParams {
   const float* scale_a;          // [M] per-token activation scale (NULL: 1)
   const float* scale_w;          // [N] per-output-channel weight scale
   const float* out_inv_scale;    // [N] EPI_STORE_FP8: out8[m][n] = e4m3(value * out_inv_scale[n])  (static per-column scale)
-  unsigned long long* dbg;       // optional [tiles][8] timing stamps (diagnostic entry point only)
+#ifdef CLIPENC_DIAG                // diagnostic build only (make diag -> libclipenc_hip_diag.so, used by tools/): the product
+  unsigned long long* dbg;       // kernels carry no stamp hooks.  Optional [tiles][8] timing stamps.
+#endif
 };
 
 hipError_t ce_gemm_nt(const GemmParams& p, int dtype, int epi, hipStream_t stream);

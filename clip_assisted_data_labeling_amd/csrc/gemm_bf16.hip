@@ -229,12 +229,8 @@ template <typename T, int EPI>
 hipError_t launch_t(const GemmParams& p, hipStream_t stream) {
   int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
   if (EPI == EPI_THRESH) { const int nt = p.N / BN; tiles = nt * (nt + 1) / 2; }
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_nt_kernel<T, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_set = true;
-  }
+  static DeviceKernelSetup setup;             // per device: LDS opt-in (common.h)
+  if (hipError_t e = setup.ensure((const void*)gemm_nt_kernel<T, EPI>, LDS_BYTES, nullptr); e != hipSuccess) return e;
   hipLaunchKernelGGL((gemm_nt_kernel<T, EPI>), dim3(tiles), dim3(512), LDS_BYTES, stream, p);
   return hipGetLastError();
 }

@@ -393,18 +393,9 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
 
 template <int EPI, int ACT>
 hipError_t launch_fp8(const GemmParams& p, hipStream_t stream) {
-  static int n_cu = 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_fp8_kernel<EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return e;
-    n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  static DeviceKernelSetup setup;             // per device: LDS opt-in + CU count (common.h)
+  int n_cu = 0;
+  if (hipError_t e = setup.ensure((const void*)gemm_fp8_kernel<EPI, ACT>, LDS_BYTES, &n_cu); e != hipSuccess) return e;
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
   int grid = n_cu > 0 ? n_cu : 256;
   grid -= grid % 8;

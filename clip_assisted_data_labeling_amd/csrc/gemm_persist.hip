@@ -233,7 +233,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     f32x4_t acc[8][4];
     frag_t fa[8], fb[8];
 
+#ifdef CLIPENC_DIAG
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 4] = __builtin_amdgcn_s_memtime(); }
+#endif
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
     if (kend > 256) {
@@ -282,7 +284,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     }
 #undef AOFF_B
     if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
+#ifdef CLIPENC_DIAG
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 5] = __builtin_amdgcn_s_memtime(); }
+#endif
 
     // ------------------------------- epilogue of tile `cur` -------------------------------
     // epilogue lane mapping: 16-row x 128-B image per wave, 16-B chunk index XOR row&7 -- derived here from an opaque copy
@@ -434,13 +438,19 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       __syncthreads();                       // AUX is rewritten by the next tile's epilogue
     }
 
+#ifdef CLIPENC_DIAG
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 3] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 0] = blockIdx.x; }
+#endif
     if (!has_next) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant DMA before the LDS is released
       break;
     }
     // all 256 rows valid: every guarded store above was issued (the waves of EPI_RESID that store statistics issued 17)
-    relax = (cur.m0 + BM <= p.M && p.dbg == nullptr) ? 2 : 0;   // the first two waits of the coming tile
+#ifdef CLIPENC_DIAG
+    relax = (cur.m0 + BM <= p.M && p.dbg == nullptr) ? 2 : 0;   // (the stamps add stores: no relaxed waits then)
+#else
+    relax = (cur.m0 + BM <= p.M) ? 2 : 0;      // the first two waits of the coming tile
+#endif
     idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
     ++tile_iter;
   }
@@ -448,20 +458,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 
 template <int EPI, int ACT>
 hipError_t launch_persist(const GemmParams& p, hipStream_t stream) {
-  static int n_cu = 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)gemm_persist_kernel<EPI, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return e;
-    int dev = 0;
-    e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    hipDeviceProp_t prop;
-    e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) return e;
-    n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  static DeviceKernelSetup setup;             // per device: LDS opt-in + CU count (common.h)
+  int n_cu = 0;
+  if (hipError_t e = setup.ensure((const void*)gemm_persist_kernel<EPI, ACT>, LDS_BYTES, &n_cu); e != hipSuccess) return e;
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
   int grid = n_cu > 0 ? n_cu : 256;
   grid -= grid % 8;                           // keep tile index mod 8 == workgroup index mod 8 (XCD affinity)

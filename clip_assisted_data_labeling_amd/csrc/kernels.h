@@ -13,6 +13,7 @@ hipError_t ce_patchify(const void* crops, int in_dtype, void* a_patch, int n_cro
 hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float* pos, const float* gamma,
                            const float* beta, void* x, float* stats, int n_crops, int n_tok, int width, float eps,
                            hipStream_t stream);
+hipError_t ce_clock_probe(unsigned long long* out2, int spin_ticks, hipStream_t stream);   // {shader cycles, 100 MHz ticks}
 hipError_t ce_head(const void* x, const float* gamma, const float* beta, const float* proj, float* emb, int n_crops,
                    int n_tok, int width, int embed, float eps, int normalize, hipStream_t stream);
 
@@ -46,6 +47,7 @@ hipError_t ce_diversity_order(const float* emb, long n, int d, long ld, int firs
 // fcreg.hip
 #define CE_FC_MAX_LAYERS 8
 #define CE_FC_MAX_SEG 16
+#define CE_FC_MAX_WIDTH 5120            // widest layer (input included): 2 x FC_ROWS x width fp32 must fit the 160 KiB LDS
 struct FcRegParams {
   int n_layers;
   int sizes[CE_FC_MAX_LAYERS + 1];

@@ -109,9 +109,10 @@ def already_embedded(feature_path: str, model_name: str) -> bool:
 class Feature_Dataset:
     def __init__(self, root_dir, model_name, batch_size, model_path=None, force_reencode=False,
                  shuffle_filenames=True, num_workers=0, crop_names=None, encoder=None, device="cuda",
-                 gpu_preprocess=False, packed_store=None):
+                 gpu_preprocess=False, packed_store=None, shard_images=8192):
         self.device = device
         self.packed_store = packed_store
+        self.shard_images = int(shard_images)     # images per sealed shard = the most a killed rank can lose
         self.root_dir = root_dir
         self.model_name = model_name
         self.force_reencode = force_reencode
@@ -190,7 +191,8 @@ class Feature_Dataset:
                 if any(n != len(self.crop_names) for n in counts):
                     raise RuntimeError("packed store needs every image to carry all crops " + str(self.crop_names))
                 if writer is None:
-                    writer = PackedStoreWriter(self.packed_store, self.model_name, self.crop_names, features.shape[-1], rank)
+                    writer = PackedStoreWriter(self.packed_store, self.model_name, self.crop_names, features.shape[-1], rank,
+                                               rotate_every=self.shard_images)
                 writer.append([image_key(b[2], self.root_dir) for b in batch],
                               features.view(len(batch), len(self.crop_names), features.shape[-1]))
                 n_embedded += len(batch)
@@ -232,33 +234,41 @@ class Feature_Dataset:
             if acc:
                 yield acc
 
-        for ok in encode_batches():
-            if self.cropper:
-                # all images of the batch go through the GPU front end in three launches (crop geometry on the host,
-                # uploads from page-locked memory are asynchronous)
-                stacked, names_all = self.cropper.batch([b[0] for b in ok])
-                per = [len(n) for n in names_all]
-                ok = [(_Shape(k), ",".join(n), b[2], True) for k, n, b in zip(per, names_all, ok)]
-            else:
-                stacked = torch.cat([b[0] for b in ok], 0).to(self.device, non_blocking=True)   # [sum crops, 3, R, R], row = image-major
-            features = self.encoder.encode_image(stacked).float()                            # :130
-            counts_only = [(_Shape(b[0].shape[0]), b[1], b[2], b[3]) for b in ok]           # the crop tensors are not kept: only their counts
-            if on_gpu:
-                host = torch.empty(features.shape, dtype=torch.float32, pin_memory=True)
-                host.copy_(features, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record()
-                if pending is not None:
-                    pending[2].synchronize()
-                    finish(pending[0], pending[1])
-                pending = (counts_only, host, ev)
-            else:
-                finish(counts_only, features.cpu())
-        if pending is not None:
-            pending[2].synchronize()
-            finish(pending[0], pending[1])
-        if writer is not None:
-            writer.close()
+        def run():
+            nonlocal pending
+            for ok in encode_batches():
+                if self.cropper:
+                    # all images of the batch go through the GPU front end in three launches (crop geometry on the host,
+                    # uploads from page-locked memory are asynchronous)
+                    stacked, names_all = self.cropper.batch([b[0] for b in ok])
+                    per = [len(n) for n in names_all]
+                    ok = [(_Shape(k), ",".join(n), b[2], True) for k, n, b in zip(per, names_all, ok)]
+                else:
+                    stacked = torch.cat([b[0] for b in ok], 0).to(self.device, non_blocking=True)   # [sum crops, 3, R, R], row = image-major
+                features = self.encoder.encode_image(stacked).float()                            # :130
+                counts_only = [(_Shape(b[0].shape[0]), b[1], b[2], b[3]) for b in ok]           # the crop tensors are not kept: only their counts
+                if on_gpu:
+                    host = torch.empty(features.shape, dtype=torch.float32, pin_memory=True)
+                    host.copy_(features, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    if pending is not None:
+                        pending[2].synchronize()
+                        finish(pending[0], pending[1])
+                    pending = (counts_only, host, ev)
+                else:
+                    finish(counts_only, features.cpu())
+            if pending is not None:
+                pending[2].synchronize()
+                finish(pending[0], pending[1])
+
+        try:
+            run()
+        finally:
+            # seal the shard on EVERY exit path (an exception in the loop, Ctrl-C, a failed write): an unsealed shard is
+            # invisible to readers and to the resume check, i.e. every image already embedded into it would be lost
+            if writer is not None:
+                writer.close()
         print("\n--- Feature encoding done! ---\n")
         print(f"Embedded {n_embedded} images ({n_skipped} images were already embedded, {n_failed} unreadable). "
               f"Features saved with model key '{self.model_name}'.")

@@ -125,13 +125,17 @@ class HipViT:
         return out
 
     @torch.no_grad()
-    def debug_run_layers(self, crops: torch.Tensor, n_layers: int) -> torch.Tensor:
+    def forward_tokens(self, crops: torch.Tensor, n_layers: Optional[int] = None) -> torch.Tensor:
+        """Token-level features: the bf16 residual stream [n, tokens, width] after `n_layers` blocks (default: all)."""
         crops, dt = self._check_crops(crops)
         n = crops.shape[0]
+        n_layers = self.cfg.layers if n_layers is None else n_layers
         x = torch.empty((n, self.cfg.tokens, self.cfg.width), dtype=torch.bfloat16, device=self.device)
-        _lib.check(self.lib.clipenc_debug_run_layers(self.handle, crops.data_ptr(), n, dt, n_layers, x.data_ptr(),
-                                                     _lib.current_stream_ptr(self.device)), "clipenc_debug_run_layers")
+        _lib.check(self.lib.clipenc_forward_tokens(self.handle, crops.data_ptr(), n, dt, n_layers, x.data_ptr(),
+                                                   _lib.current_stream_ptr(self.device)), "clipenc_forward_tokens")
         return x
+
+    debug_run_layers = forward_tokens      # name used by the parity tests
 
     @torch.no_grad()
     def encode_score(self, crops: torch.Tensor, regressor, crops_per_image: int, crop_select):

@@ -125,6 +125,7 @@ class PackedStore:
     def __init__(self, store_dir: str):
         self.store_dir = store_dir
         self._shards: Dict[str, List[dict]] = {}
+        self._cache: Dict[str, tuple] = {}
         if os.path.isdir(store_dir):
             for name in sorted(os.listdir(store_dir)):
                 if not name.endswith(".json"):
@@ -151,54 +152,83 @@ class PackedStore:
             out.update(s["keys"])
         return out
 
-    def load(self, model_name: str) -> Tuple[List[str], np.ndarray, List[str]]:
-        """(keys, float32 [N, n_crops, E], crop_names) with every key once (newest shard wins), in first-seen order."""
+    def _index(self, model_name: str):
+        """Cached per model: (crop_names, E, [memmap per shard], {key: (shard, row)} newest shard wins, keys in first-seen
+        order).  Built once per PackedStore: nothing is concatenated and no shard is read until rows are asked for."""
+        cached = self._cache.get(model_name)
+        if cached is not None:
+            return cached
         shards = self._shards.get(model_name, [])
         if not shards:
             raise KeyError(f"no shards for model {model_name!r} in {self.store_dir}")
-        crop_names, E = shards[0]["crop_names"], shards[0]["embed_dim"]
-        blocks = []
-        for s in shards:
+        crop_names, E = list(shards[0]["crop_names"]), shards[0]["embed_dim"]
+        maps, where, order = [], {}, []
+        for si, s in enumerate(shards):                       # oldest first: later shards override
             if s["crop_names"] != crop_names or s["embed_dim"] != E:
                 raise ValueError(f"shards of {model_name!r} disagree on crop names / embedding width")
-            blocks.append(np.memmap(s["_data"], dtype="<f4", mode="r", shape=(s["n"], len(crop_names), E)))
-        all_keys = [k for s in shards for k in s["keys"]]
-        last = {}
-        for i, k in enumerate(all_keys):
-            last[k] = i                                         # newest occurrence
-        order = sorted(last.values()) if len(last) != len(all_keys) else None
-        data = np.concatenate(blocks, axis=0) if len(blocks) > 1 else blocks[0]
-        if order is None:
-            return all_keys, data, list(crop_names)
-        # keep first-seen key order, newest data
-        first = {}
-        for i, k in enumerate(all_keys):
-            first.setdefault(k, i)
-        keys = sorted(first, key=first.get)
-        return keys, np.asarray(data[[last[k] for k in keys]]), list(crop_names)
+            maps.append(np.memmap(s["_data"], dtype="<f4", mode="r", shape=(s["n"], len(crop_names), E)))
+            for row, k in enumerate(s["keys"]):
+                if k not in where:
+                    order.append(k)
+                where[k] = (si, row)
+        cached = self._cache[model_name] = (crop_names, E, maps, where, order)
+        return cached
+
+    def crop_names(self, model_name: str) -> List[str]:
+        return list(self._index(model_name)[0])
+
+    def rows(self, model_name: str, keys: Sequence[str]):
+        """(found bool[n], float32 [n_found, n_crops, E]) for `keys`, read shard by shard."""
+        crop_names, E, maps, where, _ = self._index(model_name)
+        loc = [where.get(k) for k in keys]
+        found = np.array([l is not None for l in loc], dtype=bool)
+        sel = [l for l in loc if l is not None]
+        out = np.empty((len(sel), len(crop_names), E), np.float32)
+        if sel:
+            sh = np.array([l[0] for l in sel], dtype=np.int64)
+            rw = np.array([l[1] for l in sel], dtype=np.int64)
+            for si in np.unique(sh):
+                m = sh == si
+                out[m] = _gather_rows(maps[si], rw[m])
+        return found, out
+
+    def load(self, model_name: str) -> Tuple[List[str], np.ndarray, List[str]]:
+        """(keys, float32 [N, n_crops, E], crop_names) with every key once (newest shard wins), in first-seen order.
+        A single shard without overwritten keys is returned as its memory map (no copy)."""
+        crop_names, E, maps, where, order = self._index(model_name)
+        if len(maps) == 1 and len(order) == maps[0].shape[0]:
+            return list(order), maps[0], list(crop_names)
+        _, data = self.rows(model_name, order)
+        return list(order), data, list(crop_names)
 
     def features(self, clip_models: Sequence[str], crop_names: Sequence[str], keys: Sequence[str]):
         """Regressor input rows, assembled as _5_predict_labels.py:75-82 does: [model][crop in crop_names][E] flattened.
-        Returns (found bool[n], float32 [n_found, sum]) for `keys`."""
-        per_model = []
+        Returns (found bool[n], float32 [n_found, n_models * n_crops * E]) for `keys`.
+
+        A requested crop that the store does not hold raises ValueError naming it: the feature row is never narrowed
+        silently (the reference's trainer raises 'Missing crops' and drops the sample, _4_train_model.py:52-54; in a
+        packed store the crop set is store-wide, so every sample would be dropped)."""
         found = np.ones(len(keys), dtype=bool)
+        cols_of = {}
         for m in clip_models:
-            mk, data, names = self.load(m)
-            pos = {k: i for i, k in enumerate(mk)}
-            rows = np.array([pos.get(k, -1) for k in keys], dtype=np.int64)
-            found &= rows >= 0
-            cols = [names.index(c) for c in crop_names if c in names]
-            per_model.append((data, rows, cols))
+            names = self._index(m)[0]
+            missing = [c for c in crop_names if c not in names]
+            if missing:
+                raise ValueError(f"Missing crops {missing} for model {m!r}: the packed store {self.store_dir} holds {names}")
+            cols_of[m] = [names.index(c) for c in crop_names]
+            where = self._index(m)[3]
+            found &= np.array([k in where for k in keys], dtype=bool)
+        sel_keys = [k for k, ok in zip(keys, found) if ok]
         out = []
-        sel = np.nonzero(found)[0]
-        for data, rows, cols in per_model:
-            block = _gather_rows(data, rows[sel])
-            if cols != list(range(data.shape[1])):
+        for m in clip_models:
+            _, block = self.rows(m, sel_keys)
+            cols = cols_of[m]
+            if cols != list(range(block.shape[1])):
                 block = block[:, cols, :]
-            out.append(block.reshape(len(sel), -1))
+            out.append(block.reshape(len(sel_keys), -1))
         if len(out) == 1:
             return found, out[0]
-        return found, (np.concatenate(out, axis=1) if out else np.zeros((len(sel), 0), np.float32))
+        return found, (np.concatenate(out, axis=1) if out else np.zeros((len(sel_keys), 0), np.float32))
 
 
 def _gather_rows(data: np.ndarray, rows: np.ndarray) -> np.ndarray:

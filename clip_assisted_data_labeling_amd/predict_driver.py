@@ -86,7 +86,9 @@ def predict_labels(args, device="cuda"):
     store = None
     if getattr(args, "packed_store", None):                 # features from the packed shards: no per-image torch.load
         from .packed_store import PackedStore, image_key
-        store = PackedStore(args.packed_store)
+        store = getattr(args, "_store", None)               # main() opens the store ONCE for all sub-directories; its
+        if store is None:                                   # per-model key index is built once and cached inside it
+            store = args._store = PackedStore(args.packed_store)
         store_root = getattr(args, "store_root", None) or args.root_dir
     for b0 in range(0, len(img_files), args.batch_size):
         uuids, img_paths, feats = [], [], []

@@ -8,7 +8,8 @@
  * gives the message for the calling thread); nothing aborts the process.  `*_dev` pointers are
  * device (HBM) addresses owned by the CALLER (e.g. torch tensors); the library owns only the weights
  * and workspace inside its handles.  `stream` is a hipStream_t (NULL = default stream); calls are
- * asynchronous on it and never synchronise the device.  One caller thread per handle at a time.
+ * asynchronous on it and never synchronise the device: all device memory a handle needs is allocated by its
+ * create / set_chunk / set_precision call, never by an encode / forward call.  One caller thread per handle at a time.
  */
 #ifndef CLIPENC_H
 #define CLIPENC_H
@@ -76,7 +77,8 @@ int clipenc_set_pixel_norm(clipenc_t enc, const float* mean3, const float* std3)
 #define CLIPENC_PREC_FP8 1
 int clipenc_set_precision(clipenc_t enc, int precision);
 
-/* Crops pushed through the 24-layer chain per pass (workspace is sized for it; default 2048). */
+/* Crops pushed through the layer chain per pass (default 2048).  The workspace for one pass is (re)allocated HERE and in
+ * clipenc_create / clipenc_set_precision -- these three calls may synchronise the device -- so that clipenc_encode never does. */
 int clipenc_set_chunk(clipenc_t enc, int chunk_crops);
 int clipenc_get_info(clipenc_t enc, int* tokens, int* embed_dim, int* chunk_crops, size_t* workspace_bytes);
 
@@ -85,6 +87,12 @@ int clipenc_get_info(clipenc_t enc, int* tokens, int* embed_dim, int* chunk_crop
  *   emb_dev    float32 [n_crops][embed_dim]; L2-normalised rows when `normalize` != 0 (:99). */
 int clipenc_encode(clipenc_t enc, const void* crops_dev, int n_crops, int in_dtype, float* emb_dev,
                    int normalize, void* stream);
+
+/* Token-level features: the residual stream [n_crops][tokens][width] (bf16) after `n_layers` transformer blocks
+ * (0 = after ln_pre, cfg.layers = what ln_post + proj pool in clipenc_encode) -- open_clip's "output tokens" of the same
+ * tower (/root/reference/utils/embedder.py:98 only ever takes the pooled output).  n_crops <= chunk_crops. */
+int clipenc_forward_tokens(clipenc_t enc, const void* crops_dev, int n_crops, int in_dtype, int n_layers,
+                           void* x_out_bf16_dev, void* stream);
 
 /* Replaces `torch.load(model_file)` of a pickled SimpleFC as far as its arithmetic goes
  * (/root/reference/_5_predict_labels.py:107, utils/embedder.py:290; layer list utils/nn_model.py:21-33).
@@ -210,6 +218,12 @@ int clipenc_profile_kinds(void);
 int clipenc_profile_read(clipenc_t enc, int kind, const char** name, double* total_ms, long long* launches,
                          double* algorithmic_flops, int reset);
 
+/* Clock the chip holds right now: a one-wave kernel that spins for spin_us microseconds and writes
+ * out2_dev[0] = shader cycles (s_memtime), out2_dev[1] = 100 MHz ticks (s_memrealtime) elapsed; MHz = 100 * [0] / [1].
+ * Launched by bench.py on a side stream beside the encoder to report the clock the board sustains under that load
+ * (roofline.frac_at_sustained_clock); touches no handle and no product buffer. */
+int clipenc_clock_probe(int device, unsigned long long* out2_dev, int spin_us, void* stream);
+
 /* Operator-level entry points (used by the parity tests to pin each kernel on its own). */
 #define CLIPENC_DT_BF16 0
 #define CLIPENC_DT_F16 1
@@ -233,21 +247,12 @@ int clipenc_op_gemm_fp8(const void* a8_dev, const void* w8_dev, int m, int n, in
 int clipenc_op_gemm_fp8_q(const void* a8_dev, const void* w8_dev, int m, int n, int k, const float* scale_a_dev,
                           const float* scale_w_dev, const float* bias_dev, int act, const float* out_inv_scale_dev,
                           void* out8_dev, void* stream);
-/* Diagnostic: bf16-store GEMM that also writes, per workgroup, 100 MHz timestamps
- * {entry, prologue done, main loop done, stores issued, stores retired, hw id} into stamps_dev[tiles][8]. */
-int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n, int k, void* out_dev,
-                              unsigned long long* stamps_dev, void* stream);
 /* qkv bf16 [n_crops*n_tok][3*width] -> out bf16 [n_crops*n_tok][width]; head dim 64, n_tok <= 640 */
 int clipenc_op_attention(const void* qkv_dev, void* out_dev, int n_crops, int n_tok, int width, int heads,
                          void* stream);
 /* Same, stored as e4m3 with a static per-channel scale: out8[t][c] = fp8(O[t][c] * out_inv_scale[c]) (CLIPENC_PREC_FP8) */
 int clipenc_op_attention_q(const void* qkv_dev, void* out8_dev, int n_crops, int n_tok, int width, int heads,
                            const float* out_inv_scale_dev, void* stream);
-/* Residual stream after `layer` blocks (layer = 0: after ln_pre) of the LAST clipenc_encode chunk:
- * copies bf16 [n_rows][width] from the handle's workspace into out_dev (test hook). */
-int clipenc_debug_run_layers(clipenc_t enc, const void* crops_dev, int n_crops, int in_dtype, int n_layers,
-                             void* x_out_bf16_dev, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,20 @@
+/* Diagnostic entry points of libclipenc_hip_diag.so -- NOT part of the product ABI.
+ *
+ * Built only by `make -C clip_assisted_data_labeling_amd/csrc diag` (every source compiled with -DCLIPENC_DIAG); used by the
+ * developer tools under tools/ (gemm_stamps.py).  The product library exports none of these and its kernels carry no
+ * stamp hooks. */
+#ifndef CLIPENC_DIAG_H
+#define CLIPENC_DIAG_H
+#include "clipenc.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* bf16-store GEMM that also writes, per tile, in-kernel stamps into stamps_dev[tiles][8]:
+ * {workgroup, main loop start, main loop end, epilogue stores issued} in 100 MHz ticks (s_memrealtime) and the shader
+ * cycle counter (s_memtime) at main loop start / end. */
+int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n, int k, void* out_dev,
+                              unsigned long long* stamps_dev, void* stream);
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLIPENC_DIAG_H */

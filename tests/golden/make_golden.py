@@ -18,6 +18,11 @@ What is pinned against what:
   train_small.npz        the reference's SimpleFC trained by torch.optim.Adam + CosineAnnealingWarmRestarts + MSELoss (the
                          objects /root/reference/_4_train_model.py:125-130 builds) at dropout 0 on a seeded regression set
                          with an explicit batch order: learning rates, per-epoch train loss, final parameters.
+  crop_boxes.json        (W, H) -> the four crop boxes, from a literal integer-only restatement of
+                         /root/reference/utils/embedder.py:196-245 written in THIS file (independent of
+                         clip_assisted_data_labeling_amd/preprocess.py, which the tests compare with it).  Parity unpinned at
+                         the reference boundary: utils/embedder.py imports torchvision / open_clip / cv2, none of which is
+                         installed here, so the reference's own extract_crops cannot be executed.
 None of the reference's source travels: only arrays are written.
 """
 import os
@@ -280,8 +285,42 @@ def make_encoder(arch, n_crops, seed, in_seed):
     print(f"encoder_{arch}: oracle vs transformers max-abs {err:.2e}")
 
 
+def make_crop_boxes():
+    """(W, H) -> boxes, integer arithmetic only, following /root/reference/utils/embedder.py:196-245 statement by statement
+    (the CenterCrop at :199 is torchvision's: top = int(round((H - s) / 2.0)), left likewise [upstream])."""
+    import json
+    sizes = [(224, 224), (640, 480), (480, 640), (100, 400), (400, 100), (1000, 37), (37, 1000), (333, 777), (777, 333),
+             (1, 1), (2, 3), (3, 2), (5, 5), (7, 9), (13, 8), (64, 65), (65, 64), (225, 224), (224, 225), (1023, 769),
+             (4000, 3000), (3000, 4000), (1920, 1080), (1080, 1920), (5, 1000), (1000, 5), (51, 49), (49, 51), (10, 4), (4, 10)]
+    table = []
+    for (W, H) in sizes:
+        entry = {"size": [W, H]}
+        s = min(W, H)                                                            # :197
+        top, left = int(round((H - s) / 2.0)), int(round((W - s) / 2.0))         # :199 [upstream CenterCrop]
+        entry["centre_crop"] = [left, top, left + s, top + s]
+        s = max(W, H)                                                            # :204
+        entry["square_padded_crop"] = [s, (s - W) // 2, (s - H) // 2]            # side, paste x (:209), paste y (:208)
+        w1 = int((W * H * 0.15) ** 0.5)                                          # :218
+        w2 = int((W * H * 0.1) ** 0.5)                                           # :220
+        if W >= H:                                                               # :223
+            centers = [(W // 4, H // 2), (W // 4 * 3, H // 2)]
+        else:
+            centers = [(W // 2, H // 4), (W // 2, H // 4 * 3)]
+        for name, (cw, ch), side in zip(["subcrop1", "subcrop2"], centers, [w1, w2]):
+            l = max(0, cw - side // 2)                                           # :233
+            t = max(0, ch - side // 2)                                           # :234
+            r = min(W, l + side)                                                 # :235
+            b = min(H, t + side)                                                 # :236
+            entry[name] = [l, t, r, b] if (r - l > 0 and b - t > 0) else None    # :243 zero-size crops are dropped
+        table.append(entry)
+    with open(os.path.join(HERE, "crop_boxes.json"), "w") as f:
+        json.dump({"note": "restatement of utils/embedder.py:196-245; parity unpinned (torchvision absent)", "table": table}, f, indent=0)
+    print(f"crop_boxes: {len(table)} sizes")
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
+    make_crop_boxes()
     make_regressor()
     make_dedup()
     make_simsearch()

@@ -78,6 +78,32 @@ def test_embed_driver_schema_resume_and_merge(tmp_path):
         embed_driver.Feature_Dataset(root, "no-slash-name", 2)
 
 
+def test_packed_store_shard_is_sealed_when_the_encode_loop_dies(tmp_path):
+    """A killed / failing rank must not lose what it has already embedded: the open shard is sealed on every exit path
+    and the resume check then skips exactly those images."""
+    from clip_assisted_data_labeling_amd.packed_store import PackedStore
+    root, sd = str(tmp_path / "data"), str(tmp_path / "store")
+    os.makedirs(root)
+    _make_images(root, 9)
+
+    class Dying(FakeEncoder):
+        def encode_image(self, x):
+            if self.calls == 2:
+                raise RuntimeError("simulated GPU failure in the third batch")
+            return super().encode_image(x)
+
+    with pytest.raises(RuntimeError, match="simulated"):
+        embed_driver.Feature_Dataset(root, "Fake-A/test", 3, shuffle_filenames=False, encoder=Dying(), device="cpu",
+                                     packed_store=sd).process()
+    done = PackedStore(sd).keys("Fake-A/test")
+    assert len(done) == 6                                    # two complete batches survived in a SEALED shard
+    enc = FakeEncoder()
+    n_emb, n_skip, _ = embed_driver.Feature_Dataset(root, "Fake-A/test", 3, shuffle_filenames=False, encoder=enc, device="cpu",
+                                                    packed_store=sd).process()
+    assert (n_emb, n_skip) == (3, 6)
+    assert len(PackedStore(sd).keys("Fake-A/test")) == 9
+
+
 def test_feature_assembly_order(tmp_path):
     E = 4
     d = {"M1/x": {c: torch.full((1, E), float(i)) for i, c in enumerate(CROP_NAMES)},

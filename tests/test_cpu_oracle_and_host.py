@@ -74,6 +74,12 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/clipenc.h but not exported"
     assert lib.clipenc_last_error() is not None
+    # diagnostics live in include/clipenc_diag.h and in the separately built libclipenc_hip_diag.so only
+    diag = open(os.path.join(ROOT, "include", "clipenc_diag.h")).read()
+    for name in re.findall(r"\b(clipenc_[a-z_0-9]+)\s*\(", diag):
+        assert name in _lib.DIAG_SIGNATURES and name not in _lib.SIGNATURES
+        if "diag" not in os.path.basename(_lib.LIB_PATH):
+            assert not hasattr(lib, name), f"diagnostic entry point {name} exported by the product library"
 
 
 def test_library_argument_errors_without_gpu():
@@ -126,6 +132,29 @@ def test_state_dict_round_trip_through_file(tmp_path):
     torch.save({"visual." + k: v for k, v in sd.items()}, tmp_path / "ViT-tiny-test-openai.pt")
     back = vit_config.load_weights("ViT-tiny-test/openai", str(tmp_path))
     assert all(torch.equal(back[k], sd[k]) for k in sd)
+
+
+def test_crop_geometry_matches_committed_box_table(golden_dir):
+    """tests/golden/crop_boxes.json: 30 image sizes (square, wide, tall, odd, sub-crops clipped at the border, sizes whose
+    sub-crop side is 0) from the statement-by-statement restatement of utils/embedder.py:196-245 in make_golden.py."""
+    import json
+    table = json.load(open(os.path.join(golden_dir, "crop_boxes.json")))["table"]
+    assert len(table) >= 30
+    clipped = dropped = 0
+    for e in table:
+        W, H = e["size"]
+        got = {n: (k, tuple(b)) for n, k, b in crop_boxes(W, H)}
+        assert got["centre_crop"] == ("crop", tuple(e["centre_crop"])), (W, H)
+        assert got["square_padded_crop"] == ("pad", tuple(e["square_padded_crop"])), (W, H)
+        for n in ("subcrop1", "subcrop2"):
+            if e[n] is None:
+                assert n not in got, (W, H, n)
+                dropped += 1
+            else:
+                assert got[n] == ("crop", tuple(e[n])), (W, H, n)
+                l, t, r, b = e[n]
+                clipped += (r - l) != (b - t)
+    assert clipped >= 4 and dropped >= 2               # the table does exercise the clipped and the zero-size branches
 
 
 def _module_tree(named_tensors, half=True):

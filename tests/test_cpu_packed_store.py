@@ -102,9 +102,48 @@ def test_store_features_match_pt_feature_assembly(tmp_path):
     root = str(tmp_path / "data")
     os.makedirs(root)
     export_pt(sd, root)
-    want_crops = ["subcrop2", "centre_crop", "missing_crop"]
-    found, mat = PackedStore(sd).features(["M2/y", "M1/x"], want_crops, ["u0", "u1", "u2", "nope"])
+    want_crops = ["subcrop2", "centre_crop"]
+    store = PackedStore(sd)
+    found, mat = store.features(["M2/y", "M1/x"], want_crops, ["u0", "u1", "u2", "nope"])
     assert found.tolist() == [True, False, True, False]                          # u1 lacks M2/y
+    assert mat.shape == (2, 2 * 2 * E)
     for row, k in zip(mat, ["u0", "u2"]):
         ref = predict_driver.assemble_features(os.path.join(root, k + ".pt"), ["M2/y", "M1/x"], want_crops)
         assert torch.equal(torch.from_numpy(row.copy()), ref)
+    # a crop the store does not hold is an error naming it, never a silently narrower feature row
+    with pytest.raises(ValueError, match="missing_crop"):
+        store.features(["M1/x"], ["centre_crop", "missing_crop"], ["u0"])
+    # the key index is built once per store object and reused by every call (predict_driver calls features() per batch)
+    idx = store._index("M1/x")
+    store.features(["M1/x"], want_crops, ["u2"])
+    assert store._index("M1/x") is idx
+
+
+def test_train_set_from_store_equals_pt_path_and_rejects_unknown_crops(tmp_path):
+    """train_driver --packed_store must assemble the rows the .pt path assembles, and a crop list the store cannot
+    satisfy (the reference's stale default 'subcrop2_0.1', _4_train_model.py:266-267) must fail loudly instead of
+    training on fewer crops than `model.crop_names` will claim."""
+    import argparse
+    import pandas as pd
+    from clip_assisted_data_labeling_amd import train_driver
+    E, crops = 4, list(CROP_NAMES)
+    root = tmp_path / "data"
+    (root / "setA").mkdir(parents=True)
+    sd = str(tmp_path / "store")
+    rs = np.random.RandomState(0)
+    uuids = [f"img{i:02d}" for i in range(9)]
+    with PackedStoreWriter(sd, "M1/x", crops, E, rank=0) as w0, PackedStoreWriter(sd, "M1/x", crops, E, rank=1) as w1:
+        for i, u in enumerate(uuids):                              # two ranks -> two shards
+            (w0 if i % 2 == 0 else w1).append([f"setA/{u}"], rs.randn(1, len(crops), E).astype(np.float32))
+    export_pt(sd, str(root))
+    pd.DataFrame({"uuid": uuids + ["ghost"], "label": list(np.linspace(0, 0.9, 9)) + [0.5],
+                  "timestamp": 0}).to_csv(root / "setA.csv", index=False)
+    base = dict(train_data_dir=str(root), train_data_names=["setA"], clip_models_to_use=["M1/x"], random_seed=3)
+    want = ["centre_crop", "subcrop2"]
+    f_pt, l_pt = train_driver.load_training_set(argparse.Namespace(packed_store=None, **base), want)
+    f_st, l_st = train_driver.load_training_set(argparse.Namespace(packed_store=sd, **base), want)
+    assert f_pt.shape == (9, 2 * E) and torch.equal(f_pt, f_st) and torch.equal(l_pt, l_st)
+    with pytest.raises(ValueError, match="subcrop2_0.1"):
+        train_driver.load_training_set(argparse.Namespace(packed_store=sd, **base), ["centre_crop", "subcrop2_0.1"])
+    with pytest.raises(RuntimeError):                               # the .pt path skips every sample ('Missing crops')
+        train_driver.load_training_set(argparse.Namespace(packed_store=None, **base), ["centre_crop", "subcrop2_0.1"])

@@ -3,7 +3,10 @@
 each workgroup: [1] main loop start, [2] main loop end, [3] epilogue stores issued; [0] = workgroup)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# needs the diagnostic build (make -C clip_assisted_data_labeling_amd/csrc diag): the product library has no stamp hooks
+os.environ.setdefault("CLIPENC_LIB_PATH", os.path.join(ROOT, "clip_assisted_data_labeling_amd", "libclipenc_hip_diag.so"))
 from clip_assisted_data_labeling_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda", 0); st = _lib.current_stream_ptr(dev)
 M = 131584
