@@ -223,7 +223,7 @@ def dedup_100k(dev):
 def cpu_baseline(cfg, sd, Ws, bs):
     """The oracle (a port of the reference's CPU encode_image + SimpleFC) timed on this box's host cores, as BASELINE.md
     section 4 lays out: fp32, no_grad, one warm-up, >= 3 timed repetitions, median; ViT-L/14 on 32 images (128 crops) -- fewer
-    only when one repetition would take longer than ~35 s, and then the sample says so -- plus BASELINE.json configs[0]
+    only when one repetition would take longer than ~20 s, and then the sample says so -- plus BASELINE.json configs[0]
     (ViT-B/32, 64 images x 4 crops) once in full."""
     from oracle import fcreg_oracle, vit_oracle          # checker only: never on the product path
     from clip_assisted_data_labeling_amd import vit_config
@@ -259,7 +259,7 @@ def cpu_baseline(cfg, sd, Ws, bs):
     run_l14(warm)
     per_img = (time.perf_counter() - t0) / 2
     n_img = 32
-    while n_img > 4 and per_img * n_img > 35.0:
+    while n_img > 4 and per_img * n_img > 20.0:
         n_img //= 2
     crops = synthetic_crops(n_img * CROPS_PER_IMAGE, cfg.image_size, 99, "cpu")
     times = []

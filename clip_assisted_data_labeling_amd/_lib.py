@@ -93,6 +93,8 @@ SIGNATURES = {
 
 # include/clipenc_diag.h: only in libclipenc_hip_diag.so (`make diag`), bound when present (developer tools)
 DIAG_SIGNATURES = {
+    "clipenc_op_gemm_lnfold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                       c_void_p, c_void_p, c_void_p]),
     "clipenc_op_gemm_nt_stamps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -894,6 +894,18 @@ int preproc_axis_tables(int in_size, int out_size, int out0, int n_out, int* bou
 }
 
 #ifdef CLIPENC_DIAG
+int clipenc_op_gemm_lnfold(const void* a_dev, const void* w_dev, int m, int n, int k, const float* colsum_dev,
+                           const float* bias_dev, const float* stats_dev, int parts, int stats_ld, int act, void* out_dev,
+                           unsigned long long* stamps_dev, void* stream) {
+  GemmParams p{};
+  p.A = a_dev; p.lda = k; p.W = w_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out_dev; p.ldo = n;
+  p.bias = bias_dev; p.colsum = colsum_dev; p.stats_in = stats_dev; p.stats_in_parts = parts; p.stats_ld = stats_ld;
+  p.inv_width = 1.0f / k; p.eps = 1e-5f; p.act = act; p.dbg = stamps_dev;
+  hipError_t err = ce_gemm_nt(p, CE_DT_BF16, EPI_LNFOLD, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("gemm_lnfold failed: %s", hipGetErrorString(err));
+  return 0;
+}
+
 int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n, int k, void* out_dev,
                               unsigned long long* stamps_dev, void* stream) {
   GemmParams p{};

@@ -14,6 +14,12 @@ extern "C" {
  * cycle counter (s_memtime) at main loop start / end. */
 int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n, int k, void* out_dev,
                               unsigned long long* stamps_dev, void* stream);
+/* The LayerNorm-folded GEMM on its own (QKV / FC1 of a block): out = act(rstd_m (A.W'^T - mean_m colsum_n) + bias_n), bf16;
+ * stats_dev = [parts][stats_ld][2] raw (sum, sum of squares) of the rows of A; act -1 / 0 (QuickGELU) / 1 (erf GELU);
+ * stamps_dev may be NULL. */
+int clipenc_op_gemm_lnfold(const void* a_dev, const void* w_dev, int m, int n, int k, const float* colsum_dev,
+                           const float* bias_dev, const float* stats_dev, int parts, int stats_ld, int act, void* out_dev,
+                           unsigned long long* stamps_dev, void* stream);
 #ifdef __cplusplus
 }
 #endif

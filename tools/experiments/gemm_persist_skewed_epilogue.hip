@@ -1,0 +1,721 @@
+// Persistent bf16 "NT" GEMM (tile, MFMA mapping and epilogues as in gemm_bf16.hip; this file changes WHO runs
+// the tiles and HOW the operands are staged): one workgroup per CU walks a strided list of 256x256 tiles and keeps a
+// double-buffered K=64 stage pipeline running ACROSS tile boundaries (the last two stages of a tile already fetch
+// stages 0 and 1 of the next tile), so a tile costs main loop + epilogue only.
+//
+// Staging: every LDS-DMA instruction fetches 8 rows x 128 B = 8 WHOLE cache lines (8 consecutive lanes per line).
+// The earlier K=32 ring fetched 16 rows x 64 B per instruction, i.e. half lines: same bytes, but twice the L1->L2 read
+// requests (rocprofv3 TCP_TCC_READ_REQ: 100.8 M vs 50.3 M per launch for the vendor kernel on the same shapes), and at
+// ~87 requests per clock the L2's request throughput, not the MFMA issue stream, set the pace of every variant of the
+// main loop that was tried.
+//
+// LDS (160 KiB): 2 buffers x (A 256 rows x 128 B | W 256 rows x 128 B) = 128 KiB | [128K,144K) AUX: EPI_LNFOLD raw row
+// statistics, 2 x [4 parts][256 rows][sum,sumsq] landed by LDS-DMA one tile ahead; EPI_RESID per-wave row partial sums
+// | [144K,160K) 8 wave-private 2 KiB images for the epilogue's layout change.
+// Buffer image: 1-KiB blocks of 8 rows x 128 B; 16-B chunk c of row r is stored at position c ^ (r & 6) of its row
+// (applied to the per-lane SOURCE address of the DMA and to the read address), which makes every ds_read_b128 of a
+// 16-row x 4-chunk fragment conflict-free (checked exhaustively against the lane-group table).
+//
+// One K=64 stage = 2 phases, each {fragment reads, DMA issue, counted wait} lgkmcnt(0) s_barrier {32 MFMA} s_barrier, the
+// two wave rows (the two waves of every SIMD) half a phase apart (one extra barrier) so that one issues MFMAs while the
+// other reads LDS:
+//   PA: W of both k halves (8 fragments, kept in registers for the whole stage) + A(row half 0) of both k halves
+//   PB: A(row half 1) of both k halves
+// (the first version ran four phases of 16 MFMAs: twice the barrier hand-overs, each an idle matrix pipe for a barrier
+// round trip).  W and A(half 0) of a buffer are last read in PA, A(half 1) in PB, so stage s+2's W + A(half 0) are
+// fetched into the buffer of stage s in PB of stage s (6 pieces per wave) and A(half 1) of stage s+1 in PA of stage s
+// (2 pieces).  Each phase ends its read section with ONE counted wait, vmcnt(8), behind its own pieces: the 8 newest
+// stay in flight and what retires is what the NEXT phase reads, so every piece has two phases to land.
+// Ordering: a phase's reads are retired by lgkmcnt(0) BEFORE its first barrier, so rows are re-staged one phase after
+// their last read: when a wave issues DMA in phase p it has passed the second barrier of p-1, which the other wave row
+// only reaches after the first barrier of its own p-1, i.e. after its reads of p-1 have returned.  A stage is read one
+// phase after the wait that retired it (the later wave row waits one barrier later and reads one barrier later).
+// Across a tile boundary stage 0 and W/A(half 0) of stage 1 of the next tile are in the pipeline BEFORE the epilogue's
+// stores are issued, so the first two counted waits of the new tile may leave those 16-17 stores outstanding (vmcnt
+// retires in order).
+#include <stdlib.h>
+#include <type_traits>
+
+#include "common.h"
+#include "gemm.h"
+
+namespace {
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+constexpr int BM = 256, BN = 256;
+constexpr int BUF = 65536, WREG = 32768;    // one K=64 stage: A region | W region
+constexpr int RING = 2 * BUF;               // 131072
+constexpr int AUX_OFF = RING;               // 16 KiB
+constexpr int TR_OFF = RING + 16384;        // 8 x 2 KiB (the skewed kernel: 4 x 2 KiB, shared by waves w and w + 4)
+constexpr int CB_OFF = TR_OFF + 8192;       // skewed kernel only: 2 x (256 column sums | 256 biases) fp32, landed by LDS-DMA
+constexpr int LDS_BYTES = RING + 32768;     // 163840
+
+#define LDS_PTR(off) ((__attribute__((address_space(3))) void*)(smem + (off)))
+#define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <int ACT>
+__device__ __forceinline__ float act_apply_t(float u) {
+  // compile-time activation: a run-time `act` makes hipcc evaluate BOTH activations per element and select
+  if constexpr (ACT == CE_ACT_QUICK_GELU) return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * u));
+  else if constexpr (ACT == CE_ACT_GELU_ERF) return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
+  else return u;
+}
+
+
+// One LDS-DMA piece: 64 lanes x 16 B from (uniform base in an SGPR pair + per-lane 32-bit offset) to 1 KiB of LDS at
+// lds_off.  Inline asm: the builtin makes a 64-bit VGPR address per piece (two VGPRs per offset plus temporaries, which
+// this kernel does not have), and every wait on these pieces is hand-placed anyway.
+__device__ __forceinline__ void glds16_at(const char* base, unsigned off, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_addr) : "memory");
+}
+
+struct TileId { int m0, n0, tn; };
+
+__device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n, bool deep_narrow) {
+  const int nwg = tiles_m * tiles_n;
+  const int q = nwg >> 3, r = nwg & 7, xcd = idx & 7, pos = idx >> 3;
+  const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;   // XCD-aware, bijective
+  const int GM = deep_narrow ? 2 : 8;         // tiles along M per group; FC2's shape (4 N-tiles, K = 4096) measured 2.3 % faster with 2
+  const int group = bid / (GM * tiles_n);
+  const int first_m = group * GM;
+  const int gsz = min(tiles_m - first_m, GM);
+  const int tm = first_m + (bid % (GM * tiles_n)) % gsz;
+  const int tn = (bid % (GM * tiles_n)) / gsz;
+  return TileId{tm * BM, tn * BN, tn};
+}
+
+// SKEW (EPI_LNFOLD): the two wave rows stay half a phase apart across tile boundaries and each runs its epilogue in two
+// halves INSIDE the read sections of the last phase of a tile and the first phase of the next one -- i.e. beside the
+// other wave row's MFMA phase on the same SIMDs -- instead of both rows stopping the matrix pipe for ~2 us per tile
+// ("skewed epilogue").  The LDS image stays (tools/experiments/README.md: direct stores lose).
+template <int EPI, int ACT>
+__global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p) {
+  constexpr bool SKEW = EPI == EPI_LNFOLD;
+  typedef bf16x8_t frag_t;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = w >> 2, wc = w & 3;
+  const int frow = lane & 15;
+
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
+  const int nwg = tiles_m * tiles_n;
+  const bool deep_narrow = tiles_n <= 4 && p.K >= 2048;
+  const int G = gridDim.x;
+  const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
+  const int kend = p.K * 2;                  // bytes along K; one stage = 128 B; K % 128 == 0 (stages come in pairs)
+
+  const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)LDS_PTR(0));   // LDS address of smem[0]
+  // LDS-DMA lane mapping: lane L fetches logical 16-B chunk (L&7) ^ ((L>>3)&6) of row L>>3 of an 8-row block
+  const int dg = lane >> 3;
+  const int dchunk16 = ((lane & 7) ^ (dg & 6)) * 16;
+  // A blocks of wave w (per row half h): q = 2w+i, i = 0,1 -> tile rows (w>>2)*128 + h*64 + (2(w&3)+i)*8 + dg
+  const int arow0 = (w >> 2) * 128 + (2 * (w & 3)) * 8 + dg;          // + h*64 + i*8
+  const int a_dma = ((w >> 2) * 16 + 2 * (w & 3)) * 1024;             // + (h*8 + i)*1024 (+ buffer)
+  // W blocks of wave w: rows 32w + 8i + dg, i = 0..3
+  const unsigned woff = (unsigned)((32 * w + dg) * ldw_b) + dchunk16;   // + i*8*ldw_b through the scalar base
+  const int w_dma = WREG + 4 * w * 1024;                               // + i*1024 (+ buffer)
+  // fragment reads: row frow, k-chunk kq of a 16-row block; the second k half (k 32..63) is the address ^ 64
+  const int rdl = (frow >> 3) * 1024 + (frow & 7) * 128 + ((((lane >> 4) ^ (frow & 6))) << 4);
+  const int a_rd0 = wr * 16 * 1024 + rdl;
+  const int w_rd0 = WREG + wc * 8 * 1024 + rdl;
+
+#define TW_ADDR(nt) (tr + tw_base + ((((nt) * 2 + (qd >> 1)) ^ tw_sw) << 4))
+
+  int idx = blockIdx.x;
+  TileId cur = decode_tile(idx, tiles_m, tiles_n, deep_narrow);
+  const char* Ablk = (const char*)p.A + (size_t)cur.m0 * lda_b;
+  const char* Wblk = (const char*)p.W + (size_t)cur.n0 * ldw_b;
+#define AOFF(m0v, r) ((unsigned)((min((m0v) + (r), p.M - 1) - (m0v)) * lda_b) + dchunk16)
+  unsigned aoff00 = AOFF(cur.m0, arow0), aoff01 = AOFF(cur.m0, arow0 + 8);            // half 0, i = 0,1
+  unsigned aoff10 = AOFF(cur.m0, arow0 + 64), aoff11 = AOFF(cur.m0, arow0 + 72);      // half 1
+
+  // DMA pieces of one stage (buffer b, operand block pointers, byte offset along K)
+#define ISSUE_AH0(b, blk, o0, o1, kbyte)                                                    \
+  do {                                                                                      \
+    glds16((blk) + (kbyte), (o0), smem, (b) * BUF + a_dma);                                 \
+    glds16((blk) + (kbyte), (o1), smem, (b) * BUF + a_dma + 1024);                          \
+  } while (0)
+#define ISSUE_AH1(b, blk, o0, o1, kbyte)                                                    \
+  do {                                                                                      \
+    glds16((blk) + (kbyte), (o0), smem, (b) * BUF + a_dma + 8192);                          \
+    glds16((blk) + (kbyte), (o1), smem, (b) * BUF + a_dma + 9216);                          \
+  } while (0)
+#define ISSUE_W(b, blk, kbyte)                                                              \
+  do {                                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                        \
+      glds16((blk) + (kbyte) + (size_t)i_ * 8 * ldw_b, woff, smem, (b) * BUF + w_dma + i_ * 1024); \
+  } while (0)
+  // raw row statistics of a tile's 256 rows: parts x 2 KiB, fetched by waves 0 and 1 (EPI_LNFOLD)
+#define glds16(base, off, smem_, lds_off) glds16_at((base), (off), lds0 + (unsigned)(lds_off))
+#define STAGE_STATS(buf, m0v)                                                               \
+  do {                                                                                      \
+    if (EPI == EPI_LNFOLD && w < 2) {                                                        \
+      const int sbuf_ = __builtin_amdgcn_readfirstlane(buf);      /* (an SGPR for the asm operand, provably) */ \
+      for (int part = 0; part < p.stats_in_parts; ++part)                                    \
+        glds16((const char*)p.stats_in + ((size_t)part * p.stats_ld + (m0v)) * 8, (unsigned)((w * 64 + lane) * 16), smem, \
+               AUX_OFF + sbuf_ * 8192 + part * 2048 + w * 1024);                             \
+    }                                                                                       \
+  } while (0)
+  // fragments of one phase: W for both k halves (fb[4 kh + j], kept for both phases of the stage) and one A row half for
+  // both k halves (fa[4 kh + i]); the k 0..31 fragments are read first, they feed the first MFMAs
+  // (the address of the second k half is re-derived where it is used -- one v_xor in an asm statement that hipcc cannot
+  // hoist: kept across the whole kernel these two addresses were what the register-tight instantiations spilled)
+#define XOR64(dst, src) asm volatile("v_xor_b32 %0, 64, %1" : "=v"(dst) : "v"(src))
+#define LD_W2(b) { int w_rd1_; XOR64(w_rd1_, w_rd0);                                                                                \
+                   _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[j] = *(const frag_t*)(smem + (b) * BUF + w_rd0 + j * 2048);      \
+                   _Pragma("unroll") for (int j = 0; j < 4; ++j) fb[4 + j] = *(const frag_t*)(smem + (b) * BUF + w_rd1_ + j * 2048); }
+#define LD_A2(b, half) { int a_rd1_; XOR64(a_rd1_, a_rd0);                                                                          \
+                         _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (b) * BUF + a_rd0 + ((half) * 8 + i * 2) * 1024);  \
+                         _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[4 + i] = *(const frag_t*)(smem + (b) * BUF + a_rd1_ + ((half) * 8 + i * 2) * 1024); }
+  // ZC: the first MFMA of every accumulator of a tile takes the constant 0 as its C operand instead of a zeroed register
+  // (128 v_mov per wave and tile with the matrix pipe idle otherwise)
+#define MMA2(half, ZC)                                                                      \
+  do {                                                                                      \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
+      acc[(half) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kh * 4 + j], fa[kh * 4 + i],               \
+                                   ((ZC) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(half) * 4 + i][j], 0, 0, 0); \
+  } while (0)
+#define BARRIER() asm volatile("s_barrier" ::: "memory")
+#define WAIT_LDS()                                                                          \
+  do {                                                                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  } while (0)
+  // {reads retired} barrier {32 MFMA} barrier; the sched_barrier keeps the register-only MFMAs behind the s_barrier.
+  // (Handing over early -- the second barrier in front of the last four MFMAs, so that the other wave row starts while
+  // these drain -- measured 7-8 % SLOWER end to end, with 16- and with 32-MFMA phases.)
+#define SYNC_MMA(half, ZC)                                                                  \
+  do {                                                                                      \
+    WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0);                               \
+    __builtin_amdgcn_s_setprio(1); MMA2(half, ZC); __builtin_amdgcn_s_setprio(0);           \
+    BARRIER();                                                                              \
+  } while (0)
+  // The counted wait of a phase, issued behind the phase's own pieces: PA has just issued 2, PB 6, and the pieces that
+  // must have landed are older than the 8 newest (vmcnt retires in order).  First two waits after an epilogue: what they
+  // need was issued BEFORE the epilogue's stores, so when every wave issued exactly its 16 row stores (17 for the waves
+  // that also store EPI_RESID statistics) those may stay outstanding as well and drain under the MFMAs instead of
+  // stalling the pipeline at the head of every tile.  One opaque instruction for the compiler (a real branch here splits
+  // the stage into basic blocks and costs ~20 spilled VGPRs): sel 0 -> vmcnt(8), 1 -> vmcnt(24), 2 -> vmcnt(25).
+#define VM8 asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define VM_RELAX                                                                            \
+  do {                                                                                      \
+    const int sel_ = __builtin_amdgcn_readfirstlane(relax > 0 ? relax_sel : 0);             \
+    relax = relax > 0 ? relax - 1 : 0;                                                      \
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lvm8_%=\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Lvm24_%=\n\t"          \
+                 "s_waitcnt vmcnt(25)\n\ts_branch .Lvmend_%=\n.Lvm24_%=:\n\ts_waitcnt vmcnt(24)\n\ts_branch .Lvmend_%=\n"       \
+                 ".Lvm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lvmend_%=:" : : "s"(sel_) : "memory", "scc");                                  \
+  } while (0)
+#define ISSUE_WAH0(b, ablk, wblk, o00, o01, kbyte)                                          \
+  do { ISSUE_W(b, wblk, kbyte); ISSUE_AH0(b, ablk, o00, o01, kbyte); } while (0)
+  // one K=64 stage on buffer b = two phases of 32 MFMAs per wave.  PA: W (both k halves) and A(half 0), PA_ISSUE = the
+  // A(half 1) rows of stage s+1 into the other buffer; PB: A(half 1), PB_ISSUE = W and A(half 0) of stage s+2 into this one
+#define STAGE_Z(b, ZC, VMWAIT, PA_ISSUE, PB_ISSUE)                                          \
+  do {                                                                                      \
+    LD_W2(b) __builtin_amdgcn_sched_barrier(0); LD_A2(b, 0)                                 \
+    PA_ISSUE;                                                                               \
+    VMWAIT;                                                                                 \
+    SYNC_MMA(0, ZC);                                                                        \
+    LD_A2(b, 1)                                                                             \
+    PB_ISSUE;                                                                               \
+    VMWAIT;                                                                                 \
+    SYNC_MMA(1, ZC);                                                                        \
+  } while (0)
+#define STAGE(b, VMWAIT, PA_ISSUE, PB_ISSUE) STAGE_Z(b, 0, VMWAIT, PA_ISSUE, PB_ISSUE)
+
+  if constexpr (SKEW) {
+    // =========================== skewed-epilogue tile loop (EPI_LNFOLD; K >= 256) ===========================
+    // Timeline of one SIMD (X = its wave of row 0, Y = its wave of row 1; Y runs one barrier behind X for the whole
+    // kernel; a "section" is the part of a phase in front of its first barrier -- fragment reads, DMA issue, counted wait):
+    //   X: .. mfma PA_L | S1: pieces, EPILOGUE rows 0..63,  reads | mfma PB_L | S2: pieces, EPILOGUE rows 64..127, reads | mfma PA_0' ..
+    //   Y: ..  section  | mfma PA_L                              | S1        | mfma PB_L                                 | S2 ..
+    // so an epilogue half of one row runs beside the other row's 32 MFMAs; sections of X and Y never overlap in time
+    // (each ends with lgkmcnt(0) + the barrier that releases the other row), which is also why waves w and w + 4 can share
+    // one 2 KiB LDS image.  acc[0..3] are final after PA_L and are first overwritten by PA_0' (constant-zero C operand);
+    // acc[4..7] are final after PB_L and first overwritten by PB_0'.
+    // Everything the epilogue needs is in LDS before it starts: the rows' (mean, rstd) (raw sums by LDS-DMA one tile
+    // ahead, converted by row X in the PA section of the last stage) and the tile's 256 column sums + biases (CB, LDS-DMA
+    // one tile ahead by waves 2 and 3) -- no global load, no workgroup-wide barrier of its own.
+    // Counted waits: an epilogue half issues exactly 8 row stores per wave (buffer stores are issued for the rows of a
+    // ragged tile too; the hardware drops them), always BEHIND the section's DMA pieces.  With p = pieces, s = stores the
+    // issue order around a tile boundary is  PA_L 2p | S1 6p 8s | S2 2p 8s | PB_0' 6p | PA_1' 2p | PB_1' 6p  and every
+    // wait must retire the pieces the NEXT phase reads (those issued two sections earlier) while leaving everything newer
+    // in flight: vmcnt 16 (S1), 24 (S2), 24 (PB_0'), 16 (PA_1'), then 8 again.  The stores so get three phases to drain.
+    // The cold prologue issues 8 dropped stores where S1 would have, so the first tile counts like every other.
+#define VMN(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#ifdef CLIPENC_DIAG
+    // diagnostic build: shader-cycle stamps of waves 0 (row X) and 4 (row Y) around the boundary behind the 3rd tile, kept in
+    // the 4 KiB of LDS this kernel does not use and written out once at the end (no vector-memory operation in between)
+#define STAMP(k)                                                                                                   \
+    do {                                                                                                             \
+      if (p.dbg && (tile_iter == 2 || tile_iter == 3)) {                                                             \
+        unsigned long long t_;                                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory");                               \
+        if (lane == 0) *(unsigned*)(smem + CB_OFF + 4096 + w * 256 + (tile_iter - 2) * 128 + (k) * 4) = (unsigned)t_; \
+      }                                                                                                              \
+    } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
+#define STAGE_COLS(buf, n0v)                                                                                                          \
+    do {                                                                                                                                 \
+      const int cbuf_ = __builtin_amdgcn_readfirstlane(buf);                                                                              \
+      if (w == 2) glds16((const char*)p.colsum + (size_t)(n0v) * 4, (unsigned)(lane * 16), smem, CB_OFF + cbuf_ * 2048);                \
+      if (w == 3) glds16((const char*)p.bias + (size_t)(n0v) * 4, (unsigned)(lane * 16), smem, CB_OFF + cbuf_ * 2048 + 1024);           \
+    } while (0)
+    f32x4_t acc[8][4];
+    frag_t fa[8], fb[8];
+    const unsigned row_bytes = (unsigned)p.ldo * 2u;
+#define SYNC_MMA_T(half, ZC, k1, k2)                                                        \
+    do {                                                                                      \
+      WAIT_LDS(); BARRIER(); __builtin_amdgcn_sched_barrier(0); STAMP(k1);                    \
+      __builtin_amdgcn_s_setprio(1); MMA2(half, ZC); __builtin_amdgcn_s_setprio(0);           \
+      STAMP(k2); BARRIER();                                                                   \
+    } while (0)
+
+    // one epilogue half: rows (wave row) * 128 + HALF * 64 + 0..63 of tile (m0t, n0t); par = the tile's LDS buffer parity
+    auto epi_half = [&](auto HALF_, int m0t, int n0t, int par, bool live) __attribute__((always_inline)) {
+      constexpr int HALF = decltype(HALF_)::value;
+#if defined(SKEW_EXP) && SKEW_EXP == 1
+      {
+        const __amdgpu_buffer_rsrc_t nul = __builtin_amdgcn_make_buffer_rsrc((char*)p.out, 0, 0, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, nul, (unsigned)(lane * 16 + k * 1024), 0, 0);
+        return;
+      }
+#endif
+#if defined(SKEW_EXP) && SKEW_EXP == 2
+      live = false;
+#endif
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));                     // lane constants re-derived here, not carried through the main loop
+      char* tr = smem + TR_OFF + (w & 3) * 2048;
+      const int frow_e = lane_e & 15, qd = lane_e >> 4;
+      const int tw_base = frow_e * 128 + (qd & 1) * 8;
+      const int tw_sw = frow_e & 7;
+#define TW_ADDR_S(nt) (tr + tw_base + ((((nt) * 2 + (qd >> 1)) ^ tw_sw) << 4))
+      const int tr_base = (lane_e >> 3) * 128 + (((lane_e & 7) ^ (lane_e >> 3)) << 4);   // + 1024 for rows 8..15
+      const int row_l = lane_e >> 3;
+      const unsigned tile_bytes = live ? (unsigned)min(p.M - m0t, BM) * row_bytes : 0u;     // 0: every store is dropped
+      const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (size_t)m0t * row_bytes, 0, (int)tile_bytes, 0x00020000);
+      const unsigned lcol_b = (unsigned)(n0t + wc * 64 + (lane_e & 7) * 8) * 2u;
+      const char* cb = smem + CB_OFF + par * 2048 + (wc * 64 + qd * 4) * 4;
+      f32x4_t cs[4], bs[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) { cs[nt] = *(const f32x4_t*)(cb + nt * 64); bs[nt] = *(const f32x4_t*)(cb + 1024 + nt * 64); }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int mt = HALF * 4 + i;
+        const float2 t = *(const float2*)(smem + AUX_OFF + par * 8192 + (wr * 128 + mt * 16 + frow_e) * 8);
+        const float mean = t.x, rstd = t.y;
+        uint2 pk[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          f32x4_t v = rstd * (acc[mt][nt] - mean * cs[nt]) + bs[nt];
+          if constexpr (ACT == CE_ACT_QUICK_GELU) {
+            f32x4_t e = v * -2.4554669595930156f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_exp2f(e[k]);
+            e = e + 1.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) e[k] = __builtin_amdgcn_rcpf(e[k]);
+            v = v * e;
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = act_apply_t<ACT>(v[k]);
+          }
+          pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+        // fragment layout -> row-major image -> two 16-B-per-lane stores of 8 full rows each (one wave, LDS in order)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) *(uint2*)TW_ADDR_S(nt) = pk[nt];
+        const uint4 v0 = *(const uint4*)(tr + tr_base);
+        const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
+        const unsigned oa = (unsigned)(wr * 128 + mt * 16 + row_l) * row_bytes + lcol_b;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v0), orsrc, oa, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v1), orsrc, oa + 8 * row_bytes, 0, 0);
+      }
+#undef TW_ADDR_S
+    };
+    // raw partial sums of the tile's 256 rows -> (mean, rstd), by the 256 threads of wave row 0
+    auto convert_stats = [&](int par) __attribute__((always_inline)) {
+      if (wr == 0) {
+        char* raw = smem + AUX_OFF + par * 8192;
+        float sm = 0.f, ss = 0.f;
+        for (int part = 0; part < p.stats_in_parts; ++part) {
+          const float2 t = *(const float2*)(raw + part * 2048 + tid * 8);
+          sm += t.x; ss += t.y;
+        }
+        const float mean = sm * p.inv_width;
+        const float var = fmaxf(ss * p.inv_width - mean * mean, 0.f);
+        *(float2*)(raw + tid * 8) = float2{mean, rsqrtf(var + p.eps)};
+      }
+    };
+    typedef std::integral_constant<int, 0> H0;
+    typedef std::integral_constant<int, 1> H1;
+
+    // ---- cold prologue ----
+    int tile_iter = 0;
+    STAGE_STATS(0, cur.m0);
+    STAGE_COLS(0, cur.n0);
+    ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 0); ISSUE_AH1(0, Ablk, aoff10, aoff11, 0);
+    ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 128);           // A(half 1) of stage 1 follows in PA of stage 0
+    VM8;                                                      // W and A(half 0) of stage 0, statistics and column constants have landed
+    {                                                         // the 8 stores S1 of a previous tile would have issued (all dropped)
+      const __amdgpu_buffer_rsrc_t nul = __builtin_amdgcn_make_buffer_rsrc((char*)p.out, 0, 0, 0x00020000);
+#pragma unroll
+      for (int k = 0; k < 8; ++k)                              // (distinct addresses: identical stores would be merged into one)
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{0u, 0u, 0u, 0u}, nul, (unsigned)(lane * 16 + k * 1024), 0, 0);
+    }
+    BARRIER();
+    if (wr == 1) BARRIER();                                    // second wave row runs half a phase behind -- for the whole kernel
+    TileId prv = cur;
+
+    for (;;) {
+      // ---- first stage pair: constant-zero C operand; S2 of the previous tile rides in the first section ----
+      STAMP(0);
+      ISSUE_AH1(1, Ablk, aoff10, aoff11, 128);
+      STAMP(1);
+      epi_half(H1{}, prv.m0, prv.n0, (tile_iter + 1) & 1, tile_iter > 0);
+      STAMP(2);
+      LD_W2(0) __builtin_amdgcn_sched_barrier(0); LD_A2(0, 0)
+      VMN(24); STAMP(3); SYNC_MMA_T(0, 1, 4, 5);
+      STAMP(6);
+      LD_A2(0, 1)
+      ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 256);
+      VMN(24); STAMP(7); SYNC_MMA_T(1, 1, 8, 9);
+      STAMP(10);
+      LD_W2(1) __builtin_amdgcn_sched_barrier(0); LD_A2(1, 0)
+      ISSUE_AH1(0, Ablk, aoff10, aoff11, 256);
+      VMN(16); STAMP(11); SYNC_MMA_T(0, 0, 12, 13);
+      LD_A2(1, 1)
+      ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 384);
+      VM8; STAMP(14); SYNC_MMA_T(1, 0, 15, 16);
+      STAMP(17);
+      for (int kb = 256; kb < kend - 256; kb += 256) {
+        STAGE(0, VM8, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
+        STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
+      }
+      // ---- last stage pair: the DMA crosses into the next tile; S1 of this tile rides in the last section ----
+      const int nidx = idx + G;
+      const bool has_next = nidx < nwg;
+      TileId nxt = cur;
+      const char *Anext = Ablk, *Wnext = Wblk;
+      if (has_next) {
+        nxt = decode_tile(nidx, tiles_m, tiles_n, deep_narrow);
+        Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
+        Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
+      }
+      int lane_b = lane;
+      asm volatile("" : "+v"(lane_b));
+      const int dg_b = lane_b >> 3;
+      const unsigned dch_b = (unsigned)(((lane_b & 7) ^ (dg_b & 6)) * 16);
+      const int arow_b = (w >> 2) * 128 + (2 * (w & 3)) * 8 + dg_b;
+#define AOFF_B(r) ((unsigned)((min(nxt.m0 + (r), p.M - 1) - nxt.m0) * lda_b) + dch_b)
+      aoff00 = AOFF_B(arow_b); aoff01 = AOFF_B(arow_b + 8);
+      const int kb = kend - 256;
+      if (has_next) { STAGE_STATS((tile_iter + 1) & 1, nxt.m0); STAGE_COLS((tile_iter + 1) & 1, nxt.n0); }
+      LD_W2(0) __builtin_amdgcn_sched_barrier(0); LD_A2(0, 0)
+      ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128);
+      convert_stats(tile_iter & 1);
+      VM8; SYNC_MMA(0, 0);
+      LD_A2(0, 1)
+      ISSUE_WAH0(0, Anext, Wnext, aoff00, aoff01, 0);
+      VM8; SYNC_MMA(1, 0);
+      aoff10 = AOFF_B(arow_b + 64); aoff11 = AOFF_B(arow_b + 72);
+#undef AOFF_B
+      STAMP(20);
+      LD_W2(1) __builtin_amdgcn_sched_barrier(0); LD_A2(1, 0)
+      ISSUE_AH1(0, Anext, aoff10, aoff11, 0);
+      VM8; STAMP(21); SYNC_MMA_T(0, 0, 22, 23);
+      STAMP(24);
+      ISSUE_WAH0(1, Anext, Wnext, aoff00, aoff01, 128);
+      STAMP(25);
+      epi_half(H0{}, cur.m0, cur.n0, tile_iter & 1, true);
+      STAMP(26);
+      LD_A2(1, 1)
+      VMN(16); STAMP(27); SYNC_MMA_T(1, 0, 28, 29);
+      STAMP(30);
+      if (!has_next) break;
+      prv = cur; idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
+      ++tile_iter;
+    }
+    epi_half(H1{}, cur.m0, cur.n0, tile_iter & 1, true);      // rows 64..127 of the last tile
+    if (wr == 0) BARRIER();                                    // balances the extra barrier wave row 1 took at the start
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the redundant DMA lands before the LDS is released
+#ifdef CLIPENC_DIAG
+    if (p.dbg && (w == 0 || w == 4) && lane < 64) {           // [workgroup][row X | row Y][tile 2 | tile 3][32 stamps]
+      p.dbg[(size_t)blockIdx.x * 128 + (w >> 2) * 64 + lane] = *(const unsigned*)(smem + CB_OFF + 4096 + w * 256 + lane * 4);
+    }
+#endif
+    return;
+  }
+
+  // ---- cold prologue of the first tile ----
+  int tile_iter = 0;
+  STAGE_STATS(0, cur.m0);
+  ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 0); ISSUE_AH1(0, Ablk, aoff10, aoff11, 0);
+  ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 128);           // A(half 1) of stage 1 follows in PA of stage 0
+  VM8;                                                      // W and A(half 0) of stage 0 have landed
+  BARRIER();
+  int relax = 0;                             // waits of the coming tile that may leave the previous tile's stores in flight
+  const int relax_sel = (EPI == EPI_RESID && w < 4) ? 2 : 1;   // those waves also store the row statistics: 17 stores, not 16
+
+  for (;;) {
+    f32x4_t acc[8][4];
+    frag_t fa[8], fb[8];
+
+#ifdef CLIPENC_DIAG
+    if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 4] = __builtin_amdgcn_s_memtime(); }
+#endif
+    if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
+
+    if (kend > 256) {
+      // first stage pair of the tile: every accumulator starts from the constant 0 in its first MFMA
+      STAGE_Z(0, 1, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 256));
+      STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 384));
+      for (int kb = 256; kb < kend - 256; kb += 256) {
+        STAGE(0, VM8, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
+        STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
+      }
+    } else {                                 // (K = 128: the tile is its last stage pair)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- last two stages: the DMA crosses into the next tile ----
+    const int nidx = idx + G;
+    const bool has_next = nidx < nwg;
+    TileId nxt = cur;
+    const char *Anext = Ablk, *Wnext = Wblk;
+    if (has_next) {
+      nxt = decode_tile(nidx, tiles_m, tiles_n, deep_narrow);
+      Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
+      Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
+    }
+    // The next tile's A offsets take over this tile's registers as they die (half 0 here, half 1 between the last two
+    // stages; without a next tile nxt == cur and they are recomputed to the same values).  They are re-derived from an
+    // opaque copy of the lane id: as loop invariants the constants would be kept (spilled) across the main loop, and a
+    // spill reload here carries a compiler-counted vmcnt wait that drains the DMA pipeline.
+    int lane_b = lane;
+    asm volatile("" : "+v"(lane_b));
+    const int dg_b = lane_b >> 3;
+    const unsigned dch_b = (unsigned)(((lane_b & 7) ^ (dg_b & 6)) * 16);
+    const int arow_b = (w >> 2) * 128 + (2 * (w & 3)) * 8 + dg_b;
+#define AOFF_B(r) ((unsigned)((min(nxt.m0 + (r), p.M - 1) - nxt.m0) * lda_b) + dch_b)
+    aoff00 = AOFF_B(arow_b); aoff01 = AOFF_B(arow_b + 8);
+    {
+      const int kb = kend - 256;
+      // ONE code path: without a next tile the DMA harmlessly re-fetches this tile's first stages into dead
+      // buffers (two variants of this block made hipcc spill ~270 VGPRs)
+      if (has_next) STAGE_STATS((tile_iter + 1) & 1, nxt.m0);
+      STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Anext, Wnext, aoff00, aoff01, 0));
+      aoff10 = AOFF_B(arow_b + 64); aoff11 = AOFF_B(arow_b + 72);
+      STAGE(1, VM8, ISSUE_AH1(0, Anext, aoff10, aoff11, 0), ISSUE_WAH0(1, Anext, Wnext, aoff00, aoff01, 128));
+    }
+#undef AOFF_B
+    if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
+#ifdef CLIPENC_DIAG
+    if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 5] = __builtin_amdgcn_s_memtime(); }
+#endif
+
+    // ------------------------------- epilogue of tile `cur` -------------------------------
+    // epilogue lane mapping: 16-row x 128-B image per wave, 16-B chunk index XOR row&7 -- derived here from an opaque copy
+    // of the lane id, so that hipcc does not carry these constants through the main loop
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    char* tr = smem + TR_OFF + w * 2048;
+    const int frow_e = lane_e & 15, qd = lane_e >> 4;
+    const int tw_base = frow_e * 128 + (qd & 1) * 8;
+    const int tw_sw = frow_e & 7;
+    const int tr_base = (lane_e >> 3) * 128 + (((lane_e & 7) ^ (lane_e >> 3)) << 4);   // + 1024 for rows 8..15
+    const int row_l = lane_e >> 3;
+    const int q4 = qd * 4;
+    const int ncol0 = cur.n0 + wc * 64 + q4;         // + nt*16
+    const int mw0 = cur.m0 + wr * 128;               // first row of the wave tile
+    // Row stores and residual loads go through buffer descriptors that cover exactly the tile's existing rows: the hardware
+    // drops (stores) / zero-fills (loads) the rows of a ragged last tile, so the blocks below are straight-line code
+    // without per-row exec-mask branches.  Descriptors are built from wave-uniform values only (SGPRs, no waterfall loop).
+    const unsigned row_bytes = (unsigned)p.ldo * 2u;
+    const unsigned tile_bytes = (unsigned)min(p.M - cur.m0, BM) * row_bytes;                  // <= 256 rows x 8 KiB
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((char*)p.out + (size_t)cur.m0 * row_bytes, 0, (int)tile_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((char*)p.resid + (size_t)cur.m0 * row_bytes, 0, (int)tile_bytes, 0x00020000);
+    const unsigned lcol_b = (unsigned)(cur.n0 + wc * 64 + (lane_e & 7) * 8) * 2u;              // byte column of the lane's 16-B piece
+
+    if constexpr (EPI == EPI_LNFOLD) {
+      // (mean, rstd) of the tile's rows from the raw partial sums that the DMA left in AUX[buf]
+      char* raw = smem + AUX_OFF + (tile_iter & 1) * 8192;
+      if (tid < 256) {
+        float s = 0.f, ss = 0.f;
+        for (int part = 0; part < p.stats_in_parts; ++part) {
+          const float2 t = *(const float2*)(raw + part * 2048 + tid * 8);
+          s += t.x; ss += t.y;
+        }
+        const float mean = s * p.inv_width;
+        const float var = fmaxf(ss * p.inv_width - mean * mean, 0.f);
+        *(float2*)(raw + tid * 8) = float2{mean, rsqrtf(var + p.eps)};
+      }
+      __syncthreads();
+    }
+
+    f32x4_t cs[4], bs[4];
+    if constexpr (EPI == EPI_LNFOLD) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) cs[nt] = *(const f32x4_t*)(p.colsum + ncol0 + nt * 16);
+    }
+    if (EPI != EPI_STORE_BF16 || p.bias) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(p.bias + ncol0 + nt * 16);
+    } else {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) bs[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // residual rows, 8 x 16 B per lane in flight (four 16-row blocks ahead of their use)
+    uint4 rres[8];
+#define LOAD_RES(k)                                                                           \
+  do {                                                                                        \
+    const unsigned off_ = (unsigned)(wr * 128 + (k) * 8 + row_l) * row_bytes + lcol_b;        \
+    rres[(k) & 7] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off_, 0, 0)); \
+  } while (0)
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) LOAD_RES(k);
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      uint2 pk[4];
+      if constexpr (EPI == EPI_STORE_BF16) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const f32x4_t v = acc[mt][nt] + bs[nt];
+          pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+      } else if constexpr (EPI == EPI_LNFOLD) {
+        const float2 t = *(const float2*)(smem + AUX_OFF + (tile_iter & 1) * 8192 + (wr * 128 + mt * 16 + frow_e) * 8);
+        const float mean = t.x, rstd = t.y;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          // whole-vector arithmetic so that hipcc emits v_pk_fma / v_pk_mul / v_pk_add (two elements per instruction);
+          // only exp2 and rcp stay per element
+          f32x4_t v = rstd * (acc[mt][nt] - mean * cs[nt]) + bs[nt];
+          if constexpr (ACT == CE_ACT_QUICK_GELU) {
+            f32x4_t t = v * -2.4554669595930156f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_exp2f(t[e]);
+            t = t + 1.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_rcpf(t[e]);
+            v = v * t;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_apply_t<ACT>(v[e]);
+          }
+          pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        }
+      } else {
+        // residual rows of this 16-row block: row-major image -> fragment layout
+        *(uint4*)(tr + tr_base) = rres[(mt * 2) & 7];
+        *(uint4*)(tr + 1024 + tr_base) = rres[(mt * 2 + 1) & 7];
+        // (no wait: the LDS serves one wave's accesses in order, so the fragment-layout reads below see these writes)
+        if (mt + 4 < 8) { LOAD_RES(mt * 2 + 8); LOAD_RES(mt * 2 + 9); }
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+          const uint2 rr = *(const uint2*)TW_ADDR(nt);
+          f32x4_t v = acc[mt][nt] + bs[nt];
+          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+          pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+          // sum and sum of squares of the ROUNDED values, straight from the packed pairs: v_dot2c_f32_bf16 (products of
+          // bf16 are exact in fp32) instead of unpack + add + multiply-add, a third of the instructions
+          const bf16x2_t p0 = __builtin_bit_cast(bf16x2_t, pk[nt].x), p1 = __builtin_bit_cast(bf16x2_t, pk[nt].y);
+          const bf16x2_t one2 = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+          s = __builtin_amdgcn_fdot2_f32_bf16(p0, one2, s, false);
+          s = __builtin_amdgcn_fdot2_f32_bf16(p1, one2, s, false);
+          ss = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, ss, false);
+          ss = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, ss, false);
+        }
+        if (mw0 + mt * 16 + frow_e >= p.M) { s = 0.f; ss = 0.f; }
+        s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
+        s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+        if (lane_e < 16)
+          *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane_e) * 8) = float2{s, ss};
+        // (in order again: the image may be rewritten right behind the fragment reads)
+      }
+      // fragment layout -> row-major image -> two 16-B-per-lane stores of 8 full rows each
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) *(uint2*)TW_ADDR(nt) = pk[nt];
+      // (no wait between the image writes and the row-major reads, nor before the next block's writes: one wave, in order)
+      const uint4 v0 = *(const uint4*)(tr + tr_base);
+      const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
+      const unsigned oa = (unsigned)(wr * 128 + mt * 16 + row_l) * row_bytes + lcol_b;
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v0), orsrc, oa, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v1), orsrc, oa + 8 * row_bytes, 0, 0);
+    }
+
+    if constexpr (EPI == EPI_RESID) {
+      __syncthreads();
+      if (tid < 256 && cur.m0 + tid < p.M) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float2 t = *(const float2*)(smem + AUX_OFF + ((size_t)c * 256 + tid) * 8);
+          s += t.x; ss += t.y;
+        }
+        *(float2*)(p.stats_out + ((size_t)cur.tn * p.stats_ld + cur.m0 + tid) * 2) = float2{s, ss};
+      }
+      __syncthreads();                       // AUX is rewritten by the next tile's epilogue
+    }
+
+#ifdef CLIPENC_DIAG
+    if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 3] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 0] = blockIdx.x; }
+#endif
+    if (!has_next) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant DMA before the LDS is released
+      break;
+    }
+    // all 256 rows valid: every guarded store above was issued (the waves of EPI_RESID that store statistics issued 17)
+#ifdef CLIPENC_DIAG
+    relax = (cur.m0 + BM <= p.M && p.dbg == nullptr) ? 2 : 0;   // (the stamps add stores: no relaxed waits then)
+#else
+    relax = (cur.m0 + BM <= p.M) ? 2 : 0;      // the first two waits of the coming tile
+#endif
+    idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
+    ++tile_iter;
+  }
+}
+
+template <int EPI, int ACT>
+hipError_t launch_persist(const GemmParams& p, hipStream_t stream) {
+  static DeviceKernelSetup setup;             // per device: LDS opt-in + CU count (common.h)
+  int n_cu = 0;
+  if (hipError_t e = setup.ensure((const void*)gemm_persist_kernel<EPI, ACT>, LDS_BYTES, &n_cu); e != hipSuccess) return e;
+  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  int grid = n_cu > 0 ? n_cu : 256;
+  grid -= grid % 8;                           // keep tile index mod 8 == workgroup index mod 8 (XCD affinity)
+  if (grid < 8) grid = 8;
+  if (tiles < grid) grid = tiles;
+  hipLaunchKernelGGL((gemm_persist_kernel<EPI, ACT>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
+  return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream) {
+  switch (epi) {
+    case EPI_STORE_BF16: return launch_persist<EPI_STORE_BF16, -1>(p, stream);
+    case EPI_LNFOLD:     // the activation is a template parameter: a run-time switch made hipcc evaluate both GELUs per element
+      if (p.act == CE_ACT_QUICK_GELU) return launch_persist<EPI_LNFOLD, CE_ACT_QUICK_GELU>(p, stream);
+      if (p.act == CE_ACT_GELU_ERF) return launch_persist<EPI_LNFOLD, CE_ACT_GELU_ERF>(p, stream);
+      return launch_persist<EPI_LNFOLD, -1>(p, stream);
+    case EPI_RESID: return launch_persist<EPI_RESID, -1>(p, stream);
+    default: return hipErrorInvalidValue;
+  }
+}
