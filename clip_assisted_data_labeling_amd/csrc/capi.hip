@@ -173,6 +173,7 @@ struct fcreg_s {
   DevBuf slab;
   const float* Wt[CE_FC_MAX_LAYERS];
   const float* b[CE_FC_MAX_LAYERS];
+  const float* Wr[CE_FC_MAX_LAYERS];                     // zero-padded nn.Linear-layout copies for the store-scale kernel
 };
 
 namespace {
@@ -617,19 +618,25 @@ int fcreg_create(int n_layers, const int* sizes, const float* const* W, const fl
   fcreg_s* r = new fcreg_s();
   r->device = device; r->n_layers = n_layers; r->negative_slope = negative_slope;
   size_t off = 0;
-  std::vector<size_t> ow(n_layers), ob(n_layers);
+  std::vector<size_t> ow(n_layers), ob(n_layers), orr(n_layers);
   for (int l = 0; l <= n_layers; ++l) r->sizes[l] = sizes[l];
+  auto tiles32 = [](int n) { return (size_t)((n + 31) / 32) * 32; };
   for (int l = 0; l < n_layers; ++l) {
     ow[l] = off; off += align_up((size_t)sizes[l] * sizes[l + 1] * 4, 256);
     ob[l] = off; off += align_up((size_t)sizes[l + 1] * 4, 256);
+    // store-scale kernel: [out rounded up to 32][in (layer 0) | in rounded up to 32 (later layers)], zero padded
+    orr[l] = off; off += align_up(tiles32(sizes[l + 1]) * (l == 0 ? (size_t)sizes[0] : tiles32(sizes[l])) * 4, 256);
   }
-  std::vector<char> host(off);
+  std::vector<char> host(off, 0);
   for (int l = 0; l < n_layers; ++l) {
     const int in = sizes[l], on = sizes[l + 1];
     float* wt = (float*)(host.data() + ow[l]);
     for (int j = 0; j < on; ++j)
       for (int k = 0; k < in; ++k) wt[(size_t)k * on + j] = W[l][(size_t)j * in + k];     // transpose to [in][out]
     memcpy(host.data() + ob[l], b[l], (size_t)on * 4);
+    float* wr = (float*)(host.data() + orr[l]);
+    const size_t ldr = l == 0 ? (size_t)in : tiles32(in);
+    for (int j = 0; j < on; ++j) memcpy(wr + (size_t)j * ldr, W[l] + (size_t)j * in, (size_t)in * 4);
   }
   hipError_t err = r->slab.alloc(off);
   if (err == hipSuccess) err = hipMemcpy(r->slab.p, host.data(), off, hipMemcpyHostToDevice);
@@ -637,6 +644,7 @@ int fcreg_create(int n_layers, const int* sizes, const float* const* W, const fl
   for (int l = 0; l < n_layers; ++l) {
     r->Wt[l] = (const float*)((char*)r->slab.p + ow[l]);
     r->b[l] = (const float*)((char*)r->slab.p + ob[l]);
+    r->Wr[l] = (const float*)((char*)r->slab.p + orr[l]);
   }
   *out = r;
   return 0;
@@ -663,7 +671,7 @@ int fcreg_forward(fcreg_t r, const float* x_dev, int n_rows, long row_stride, in
   FcRegParams p{};
   p.n_layers = r->n_layers;
   for (int l = 0; l <= r->n_layers; ++l) p.sizes[l] = r->sizes[l];
-  for (int l = 0; l < r->n_layers; ++l) { p.Wt[l] = r->Wt[l]; p.b[l] = r->b[l]; }
+  for (int l = 0; l < r->n_layers; ++l) { p.Wt[l] = r->Wt[l]; p.b[l] = r->b[l]; p.Wr[l] = r->Wr[l]; }
   p.negative_slope = r->negative_slope;
   p.x = x_dev; p.row_stride = row_stride; p.n_seg = n_seg; p.seg_len = seg_len;
   for (int s = 0; s < n_seg; ++s) p.seg_off[s] = seg_off[s];

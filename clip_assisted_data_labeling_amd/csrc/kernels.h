@@ -58,7 +58,11 @@ struct FcRegParams {
   int n_seg, seg_len; int seg_off[CE_FC_MAX_SEG];
   float* y;                            // [n_rows][sizes[n_layers]]
   int n_rows;
+  // store-scale path (fcreg_mfma_kernel): nn.Linear-layout copies, zero-padded to whole 32 x 32 tiles:
+  // Wr[0] = [tiles(sizes[1]) * 32][sizes[0]]; Wr[l >= 1] = [tiles(sizes[l+1]) * 32][tiles(sizes[l]) * 32]; NULL: not available
+  const float* Wr[CE_FC_MAX_LAYERS];
 };
+#define CE_FC_MFMA_MIN_ROWS 4096        // below this the 4-rows-per-workgroup kernel has more workgroups to offer
 hipError_t ce_fcreg_forward(const FcRegParams& p, hipStream_t stream);
 
 // preproc.hip
