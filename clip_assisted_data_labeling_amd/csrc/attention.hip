@@ -43,7 +43,7 @@ __device__ __forceinline__ int v_swz(int row, int chunk) { return row * 128 + ((
 template <int NKT>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                       int n_tok, int width, int heads, float scale_log2e,
-                                                     const float* __restrict__ out_inv) {
+                                                     const float* __restrict__ out_inv, int q_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWS = NKT * 32;
   char* Ks = smem;
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__
   __syncthreads();
 
   const int r = lane & 31, h = lane >> 5;
-  const int n_qb = (n_tok + 31) >> 5;
+  const int n_qb = min((n_tok + 31) >> 5, q_blocks);           // q_blocks: only the first 32-query blocks (CLS-only last layer)
   for (int qb = wave; qb < n_qb; qb += 4) {
     // ---- Q fragments straight from global: lane (r,h) holds Q[q0+r][16*step + 8h .. +7] ----
     const int q = qb * 32 + r;
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__
 template <int CT>
 __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                            int n_tok, int width, int heads, float scale_log2e, int nkt,
-                                                           const float* __restrict__ out_inv) {
+                                                           const float* __restrict__ out_inv, int q_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int rows = nkt * 32;
   char* Ks = smem;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
   __syncthreads();
 
   const int r = lane & 31, h = lane >> 5;
-  const int n_qb = (n_tok + 31) >> 5;
+  const int n_qb = min((n_tok + 31) >> 5, q_blocks);
   for (int qb = wave; qb < n_qb; qb += 8) {
     const int q = qb * 32 + r;
     const bf16_t* qrow = base + (size_t)min(q, n_tok - 1) * ld;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
 }
 
 hipError_t launch_attn_long(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
-                            const float* out_inv, hipStream_t stream) {
+                            const float* out_inv, int q_blocks, hipStream_t stream) {
   constexpr int CT = 7;
   const int nkt = (n_tok + 31) / 32;
   const int lds = nkt * 32 * 128 * 2;
@@ -343,7 +343,7 @@ hipError_t launch_attn_long(const bf16_t* qkv, bf16_t* out, int n_crops, int n_t
   if (e != hipSuccess) return e;
   const float scale_log2e = 0.125f * 1.44269504088896340736f;
   hipLaunchKernelGGL((attn_long_kernel<CT>), dim3(n_crops * heads), dim3(512), lds, stream, qkv, out, n_tok, width,
-                     heads, scale_log2e, nkt, out_inv);
+                     heads, scale_log2e, nkt, out_inv, q_blocks);
   return hipGetLastError();
 }
 
@@ -368,7 +368,7 @@ __device__ __forceinline__ unsigned lds_load_u32(const char* p) {
 template <int NKT, int CT, int NCW>
 __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n_tok, int width, int heads, float scale_log2e,
-    int n_tasks, int dbg_mode, const float* __restrict__ out_inv) {
+    int n_tasks, int dbg_mode, const float* __restrict__ out_inv, int q_blocks) {
   // NCW compute waves + 1 loader; keys walked in chunks of CT tiles (CT == NKT: one exact pass; CT < NKT:
   // online softmax, fewer live score registers -> 3 waves per SIMD).
   // dbg_mode (timing experiments only, results invalid): 1 = loader alone, 2 = compute alone
@@ -382,7 +382,7 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
   const int G = gridDim.x, wg = blockIdx.x;
   const int t0 = (int)(((long long)n_tasks * wg) / G), t1 = (int)(((long long)n_tasks * (wg + 1)) / G);
   const int ntask = t1 - t0;                                    // host guarantees 1 <= ntask <= 496
-  const int n_qb = (n_tok + 31) >> 5;
+  const int n_qb = min((n_tok + 31) >> 5, q_blocks);            // q_blocks: only the first 32-query blocks of every task
   const int total_blocks = ntask * n_qb;
   const size_t ld = (size_t)3 * width;
   const unsigned ldb = (unsigned)(ld * 2);
@@ -628,7 +628,7 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
 
 template <int NKT, int CT, int NCW>
 hipError_t launch_attn_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
-                              const float* out_inv, hipStream_t stream) {
+                              const float* out_inv, int q_blocks, hipStream_t stream) {
   const int lds = 2 * 2 * NKT * 32 * 128 + NCW * (NCW <= 7 ? 2048 : 1024) + 2048;
   static DeviceKernelSetup setup;             // per device: LDS opt-in + CU count (common.h)
   int n_cu = 256;
@@ -639,19 +639,19 @@ hipError_t launch_attn_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n
   const float scale_log2e = 0.125f * 1.44269504088896340736f;
   static const int dbg = [] { const char* e = getenv("CLIPENC_ATTN_DBG"); return e ? atoi(e) : 0; }();
   hipLaunchKernelGGL((attn_stream_kernel<NKT, CT, NCW>), dim3(grid), dim3((NCW + 1) * 64), lds, stream, qkv, out, n_tok, width, heads,
-                     scale_log2e, n_tasks, dbg, out_inv);
+                     scale_log2e, n_tasks, dbg, out_inv, q_blocks);
   return hipGetLastError();
 }
 
 template <int NKT>
 hipError_t launch_attn(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
-                       const float* out_inv, hipStream_t stream) {
+                       const float* out_inv, int q_blocks, hipStream_t stream) {
   const int lds = NKT * 32 * 128 * 2;
   static DeviceKernelSetup setup;
   if (hipError_t e = setup.ensure((const void*)attn_kernel<NKT>, lds, nullptr); e != hipSuccess) return e;
   const float scale_log2e = 0.125f * 1.44269504088896340736f;   // 64^-0.5 * log2(e)
   hipLaunchKernelGGL((attn_kernel<NKT>), dim3(n_crops * heads), dim3(256), lds, stream, qkv, out, n_tok, width,
-                     heads, scale_log2e, out_inv);
+                     heads, scale_log2e, out_inv, q_blocks);
   return hipGetLastError();
 }
 
@@ -660,24 +660,25 @@ hipError_t launch_attn(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, i
 // qkv: [n_crops*n_tok][3*width] bf16 ([q|k|v], head = 64-wide slice); out: [n_crops*n_tok][width] bf16, or, when
 // out_inv != NULL, e4m3 bytes: out8[t][c] = fp8(O[t][c] * out_inv[c])
 hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int width, int heads,
-                        const float* out_inv, hipStream_t stream) {
+                        const float* out_inv, int q_blocks, hipStream_t stream) {
+  if (q_blocks < 1) q_blocks = 1 << 20;                         // all query blocks
   if (width != heads * 64 || n_tok < 1 || n_crops < 1) return hipErrorInvalidValue;
   const int nkt = (n_tok + 31) / 32;
   const bf16_t* q = (const bf16_t*)qkv;
   bf16_t* o = (bf16_t*)out;
   static const int impl = [] { const char* e = getenv("CLIPENC_ATTN_IMPL"); return e ? atoi(e) : 2; }();
-  if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8, 8, 7>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
-  if (impl == 2 && nkt == 9 && n_crops * heads >= 64) return launch_attn_stream<9, 9, 7>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
+  if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8, 8, 7>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+  if (impl == 2 && nkt == 9 && n_crops * heads >= 64) return launch_attn_stream<9, 9, 7>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
   switch (nkt) {                 // NKT must equal ceil(n_tok/32): only the last key tile is masked
-    case 1: return launch_attn<1>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
-    case 2: return launch_attn<2>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
-    case 3: return launch_attn<3>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
-    case 4: return launch_attn<4>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
-    case 5: return launch_attn<5>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
-    case 6: return launch_attn<6>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
-    case 7: return launch_attn<7>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
-    case 8: return launch_attn<8>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
-    case 9: return launch_attn<9>(q, o, n_crops, n_tok, width, heads, out_inv, stream);
-    default: return launch_attn_long(q, o, n_crops, n_tok, width, heads, out_inv, stream);   // up to 640 tokens (K, V of one head in LDS)
+    case 1: return launch_attn<1>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+    case 2: return launch_attn<2>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+    case 3: return launch_attn<3>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+    case 4: return launch_attn<4>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+    case 5: return launch_attn<5>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+    case 6: return launch_attn<6>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+    case 7: return launch_attn<7>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+    case 8: return launch_attn<8>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+    case 9: return launch_attn<9>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+    default: return launch_attn_long(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);   // up to 640 tokens (K, V of one head in LDS)
   }
 }

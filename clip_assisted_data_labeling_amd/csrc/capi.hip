@@ -142,6 +142,7 @@ struct clipenc_s {
   float *ln_post_w = nullptr, *ln_post_b = nullptr, *proj = nullptr;
   std::vector<LayerDev> layers;
   int precision = CLIPENC_PREC_BF16;
+  bool cls_only_last = true;                             // last block on the class-token rows only (bf16 path; CLIPENC_FULL_LAST_BLOCK=1 disables)
   DevBuf weights8;                                       // fp8 copies of the block weights (made by clipenc_set_precision)
   std::vector<LayerDev8> layers8;
   uint8_t* a8 = nullptr;                                 // workspace: quantised GEMM operand [T][width] (the e4m3 MLP hidden
@@ -152,7 +153,7 @@ struct clipenc_s {
   int chunk = 2048, ws_chunk = 0;
   DevBuf ws;
   bf16_t *a_patch = nullptr, *pe = nullptr, *x = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr;
-  float *stats0 = nullptr, *stats_a = nullptr, *stats_b = nullptr;
+  float *stats0 = nullptr, *stats_a = nullptr, *stats_b = nullptr, *stats_c = nullptr;   // stats_c: [parts][chunk] of the CLS rows
 };
 
 struct preproc_s {
@@ -195,6 +196,7 @@ int ensure_workspace(clipenc_s* e) {
   const size_t o_qkv = take(T * 3 * g.width * 2), o_at = take(T * g.width * 2), o_h = take(T * g.mlp_dim * 2);
   const size_t Tp = align_up(T, 256);
   const size_t o_s0 = take(Tp * 8), o_sa = take(parts * Tp * 8), o_sb = take(parts * Tp * 8);
+  const size_t o_sc = take(parts * align_up((size_t)c, 256) * 8);
   const bool f8 = e->precision == CLIPENC_PREC_FP8;
   const size_t o_a8 = f8 ? take(T * (size_t)g.width) : 0, o_sa8 = f8 ? take(T * 4) : 0;
   HIP_TRY(hipSetDevice(e->device));
@@ -202,14 +204,15 @@ int ensure_workspace(clipenc_s* e) {
   char* b = (char*)e->ws.p;
   e->a_patch = (bf16_t*)(b + o_ap); e->pe = (bf16_t*)(b + o_pe); e->x = (bf16_t*)(b + o_x);
   e->qkv = (bf16_t*)(b + o_qkv); e->attn = (bf16_t*)(b + o_at); e->hid = (bf16_t*)(b + o_h);
-  e->stats0 = (float*)(b + o_s0); e->stats_a = (float*)(b + o_sa); e->stats_b = (float*)(b + o_sb);
+  e->stats0 = (float*)(b + o_s0); e->stats_a = (float*)(b + o_sa); e->stats_b = (float*)(b + o_sb); e->stats_c = (float*)(b + o_sc);
   e->a8 = f8 ? (uint8_t*)(b + o_a8) : nullptr; e->sa8 = f8 ? (float*)(b + o_sa8) : nullptr;
   e->ws_chunk = c; e->ws_precision = e->precision;
   return 0;
 }
 
 // runs patch-embed + ln_pre + `n_layers` blocks on `c` crops; leaves the residual stream in e->x
-int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers, hipStream_t st) {
+// cls_only_last: the caller only needs token 0 of the last block (clipenc_encode); false keeps every token (forward_tokens)
+int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers, hipStream_t st, bool cls_only_last = false) {
   const clipenc_config& g = e->cfg;
   const int T = c * e->tokens, P = c * (e->tokens - 1);
   const int parts = g.width / 256;
@@ -261,7 +264,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       HIP_TRY(gemm8(e->a8, e->sa8, Q.w_qkv, Q.s_qkv, L.b_qkv, 3 * g.width, g.width, -1, e->qkv, EPI_STORE_BF16, nullptr, PK_GEMM8_QKV, -1));
       pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * e->tokens * dD, st);
       // attention writes O as e4m3 directly (static per-channel scale from the V rows of w_qkv, folded into w_out)
-      HIP_TRY(ce_attention(e->qkv, e->a8, c, e->tokens, g.width, g.heads, Q.is_attn, st));
+      HIP_TRY(ce_attention(e->qkv, e->a8, c, e->tokens, g.width, g.heads, Q.is_attn, 0, st));
       pf.end(st);
       HIP_TRY(gemm8(e->a8, nullptr, Q.w_out, Q.s_out, L.b_out, g.width, g.width, -1, e->x, EPI_RESID, nullptr, PK_GEMM8_RESID, PK_SUB8_OUT));
       HIP_TRY(quant(e->x, D, 1));
@@ -273,6 +276,62 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
   }
   for (int l = 0; l < n_layers; ++l) {
     const LayerDev& L = e->layers[l];
+    if (cls_only_last && l == n_layers - 1) {
+      // ---- LAST block, class-token rows only.  The embedding is ln_post + proj of token 0 (SURVEY.md Appendix A.2 step 5,
+      // /root/reference/utils/embedder.py:98 takes the pooled output), and nothing after this block reads another token, so
+      // of this block only K and V are needed for every token; Q, attention, out-proj and the MLP run on the c CLS rows
+      // (row stride = tokens rows).  Same arithmetic per row as the full block -- the rows it leaves out are dead.
+      const int Dw = g.width, stride = e->tokens;
+      const int Tpc = (int)align_up((size_t)c, 256);
+      // K | V = LN1(x) . W[D:3D]^T + b, every token  -> columns D..3D of qkv
+      GemmParams kv{};
+      kv.A = e->x; kv.lda = Dw; kv.W = L.w_qkv + (size_t)Dw * Dw; kv.ldw = Dw; kv.M = T; kv.N = 2 * Dw; kv.K = Dw;
+      kv.out = e->qkv + Dw; kv.ldo = 3 * Dw; kv.bias = L.b_qkv + Dw; kv.colsum = L.cs_qkv + Dw;
+      kv.stats_in = stats_in; kv.stats_in_parts = stats_parts; kv.stats_ld = Tp; kv.inv_width = 1.0f / Dw; kv.eps = g.ln_eps; kv.act = -1;
+      pf.begin(PK_GEMM_QKV, 2.0 * dT * 2.0 * dD * dD, st);
+      HIP_TRY(ce_gemm_nt(kv, CE_DT_BF16, EPI_LNFOLD, st));
+      pf.end(st);
+      // statistics of the CLS rows, compact (row i = crop i)
+      float* stats_c = e->stats_c;
+      pf.begin(PK_EMBED_LN_PRE, 0.0, st);
+      HIP_TRY(ce_gather_row_stats(stats_in, Tp, stats_c, Tpc, stats_parts, c, stride, st));
+      pf.end(st);
+      // Q of the CLS rows -> their rows of qkv (columns 0..D)
+      GemmParams qc{};
+      qc.A = e->x; qc.lda = stride * Dw; qc.W = L.w_qkv; qc.ldw = Dw; qc.M = c; qc.N = Dw; qc.K = Dw;
+      qc.out = e->qkv; qc.ldo = stride * 3 * Dw; qc.bias = L.b_qkv; qc.colsum = L.cs_qkv;
+      qc.stats_in = stats_c; qc.stats_in_parts = stats_parts; qc.stats_ld = Tpc; qc.inv_width = 1.0f / Dw; qc.eps = g.ln_eps; qc.act = -1;
+      pf.begin(PK_GEMM_QKV, 2.0 * c * dD * dD, st);
+      HIP_TRY(ce_gemm_nt(qc, CE_DT_BF16, EPI_LNFOLD, st));
+      pf.end(st);
+      // attention of the first 32-query block of every (crop, head); only its row 0 is a real query here
+      pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * dD, st);
+      HIP_TRY(ce_attention(e->qkv, e->attn, c, e->tokens, Dw, g.heads, nullptr, 1, st));
+      pf.end(st);
+      // x[cls] += attn[cls] . Wo^T + bo
+      GemmParams o{};
+      o.A = e->attn; o.lda = stride * Dw; o.W = L.w_out; o.ldw = Dw; o.M = c; o.N = Dw; o.K = Dw;
+      o.out = e->x; o.ldo = stride * Dw; o.bias = L.b_out; o.resid = e->x; o.stats_out = e->stats_a; o.stats_ld = Tpc;
+      pf.begin(PK_GEMM_RESID, 2.0 * c * dD * dD, st, PK_SUB_OUT);
+      HIP_TRY(ce_gemm_nt(o, CE_DT_BF16, EPI_RESID, st));
+      pf.end(st);
+      // h[cls] = act(LN2(x[cls]) . Wfc^T + b)   (compact [c][mlp])
+      GemmParams f{};
+      f.A = e->x; f.lda = stride * Dw; f.W = L.w_fc; f.ldw = Dw; f.M = c; f.N = g.mlp_dim; f.K = Dw;
+      f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
+      f.stats_in = e->stats_a; f.stats_in_parts = parts; f.stats_ld = Tpc; f.inv_width = 1.0f / Dw; f.eps = g.ln_eps; f.act = g.act;
+      pf.begin(PK_GEMM_FC1, 2.0 * c * dD * g.mlp_dim, st);
+      HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
+      pf.end(st);
+      // x[cls] += h . Wproj^T + b
+      GemmParams r{};
+      r.A = e->hid; r.lda = g.mlp_dim; r.W = L.w_proj; r.ldw = g.mlp_dim; r.M = c; r.N = Dw; r.K = g.mlp_dim;
+      r.out = e->x; r.ldo = stride * Dw; r.bias = L.b_proj; r.resid = e->x; r.stats_out = e->stats_b; r.stats_ld = Tpc;
+      pf.begin(PK_GEMM_RESID, 2.0 * c * dD * g.mlp_dim, st, PK_SUB_FC2);
+      HIP_TRY(ce_gemm_nt(r, CE_DT_BF16, EPI_RESID, st));
+      pf.end(st);
+      break;
+    }
     // K3: qkv = LN1(x) . Wqkv^T + b   (LayerNorm folded into the GEMM epilogue)
     GemmParams q{};
     q.A = e->x; q.lda = g.width; q.W = L.w_qkv; q.ldw = g.width; q.M = T; q.N = 3 * g.width; q.K = g.width;
@@ -283,7 +342,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     pf.end(st);
     // K4
     pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * e->tokens * dD, st);
-    HIP_TRY(ce_attention(e->qkv, e->attn, c, e->tokens, g.width, g.heads, nullptr, st));
+    HIP_TRY(ce_attention(e->qkv, e->attn, c, e->tokens, g.width, g.heads, nullptr, 0, st));
     pf.end(st);
     // K5: x += attn . Wo^T + bo
     GemmParams o{};
@@ -350,6 +409,7 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
 
   clipenc_s* e = new clipenc_s();
   e->cfg = g; e->device = device; e->tokens = tokens;
+  e->cls_only_last = getenv("CLIPENC_FULL_LAST_BLOCK") == nullptr;      // developer A/B switch
   const int kreal = 3 * g.patch * g.patch;
   e->kpad = (int)align_up(kreal, 128);
   const int D = g.width, M = g.mlp_dim, L = g.layers, E = g.embed_dim;
@@ -543,7 +603,7 @@ int clipenc_encode(clipenc_t e, const void* crops_dev, int n_crops, int in_dtype
   const size_t cb = crop_bytes(g, in_dtype);
   for (int c0 = 0; c0 < n_crops; c0 += e->chunk) {
     const int c = std::min(e->chunk, n_crops - c0);
-    if (int rc = run_tower(e, (const char*)crops_dev + (size_t)c0 * cb, c, in_dtype, g.layers, st)) return rc;
+    if (int rc = run_tower(e, (const char*)crops_dev + (size_t)c0 * cb, c, in_dtype, g.layers, st, e->cls_only_last)) return rc;
     e->prof.begin(PK_HEAD, 2.0 * c * (double)g.width * g.embed_dim, st);
     HIP_TRY(ce_head(e->x, e->ln_post_w, e->ln_post_b, e->proj, emb_dev + (size_t)c0 * g.embed_dim, c, e->tokens,
                     g.width, g.embed_dim, g.ln_eps, normalize, st));
@@ -926,7 +986,7 @@ int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n
 #endif
 
 int clipenc_op_attention(const void* qkv_dev, void* out_dev, int n_crops, int n_tok, int width, int heads, void* stream) {
-  hipError_t err = ce_attention(qkv_dev, out_dev, n_crops, n_tok, width, heads, nullptr, (hipStream_t)stream);
+  hipError_t err = ce_attention(qkv_dev, out_dev, n_crops, n_tok, width, heads, nullptr, 0, (hipStream_t)stream);
   if (err != hipSuccess) return fail("attention(%d crops, %d tok) failed: %s", n_crops, n_tok, hipGetErrorString(err));
   return 0;
 }
@@ -934,7 +994,7 @@ int clipenc_op_attention(const void* qkv_dev, void* out_dev, int n_crops, int n_
 int clipenc_op_attention_q(const void* qkv_dev, void* out8_dev, int n_crops, int n_tok, int width, int heads,
                            const float* out_inv_scale_dev, void* stream) {
   if (!out_inv_scale_dev) return fail("attention_q: NULL out_inv_scale");
-  hipError_t err = ce_attention(qkv_dev, out8_dev, n_crops, n_tok, width, heads, out_inv_scale_dev, (hipStream_t)stream);
+  hipError_t err = ce_attention(qkv_dev, out8_dev, n_crops, n_tok, width, heads, out_inv_scale_dev, 0, (hipStream_t)stream);
   if (err != hipSuccess) return fail("attention_q(%d crops, %d tok) failed: %s", n_crops, n_tok, hipGetErrorString(err));
   return 0;
 }

@@ -4,8 +4,9 @@
 #include <stdint.h>
 
 // attention.hip
+// q_blocks > 0: only the first q_blocks 32-query blocks of every (crop, head) are computed and stored (the CLS-only last block)
 hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int width, int heads, const float* out_inv,
-                        hipStream_t stream);   // out_inv != NULL: out is e4m3 [T][width] = fp8(O * out_inv[c])
+                        int q_blocks, hipStream_t stream);   // out_inv != NULL: out is e4m3 [T][width] = fp8(O * out_inv[c])
 
 // elementwise.hip
 hipError_t ce_patchify(const void* crops, int in_dtype, void* a_patch, int n_crops, int image, int patch, int kpad,
@@ -13,6 +14,8 @@ hipError_t ce_patchify(const void* crops, int in_dtype, void* a_patch, int n_cro
 hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float* pos, const float* gamma,
                            const float* beta, void* x, float* stats, int n_crops, int n_tok, int width, float eps,
                            hipStream_t stream);
+// out[part][i] = in[part][i * row_stride] for i < n (float2 statistics of every row_stride-th row), parts x n
+hipError_t ce_gather_row_stats(const float* in, int in_ld, float* out, int out_ld, int parts, int n, int row_stride, hipStream_t stream);
 hipError_t ce_clock_probe(unsigned long long* out2, int spin_ticks, hipStream_t stream);   // {shader cycles, 100 MHz ticks}
 hipError_t ce_head(const void* x, const float* gamma, const float* beta, const float* proj, float* emb, int n_crops,
                    int n_tok, int width, int embed, float eps, int normalize, hipStream_t stream);
