@@ -368,7 +368,8 @@ def run_job(args, cfg, vit, reg, dev, rank, world, backend):
                        "parallelism": f"image-sharded x{world}"},
             "seconds": {"job": round(elapsed, 3), "generate_encode_score": round(t_enc, 3), "gather": round(t_gat, 4)},
             "end_to_end": {"tflops": round(value * flop_per_image / 1e12, 1),
-                           "frac_of_peak": round(value * flop_per_image / 1e12 / (peak * world), 4)},
+                           "frac_of_peak": round(value * flop_per_image / 1e12 / (peak * world), 4),
+                           "executed_tflops": round(value * 2.0 * cfg.macs_per_crop_executed() * CROPS_PER_IMAGE / 1e12, 1)},
             "result_bytes": int(emb.numel() * 4 + score.numel() * 4),
             "checks": {"finite": True, "max_abs_norm_minus_1": norm_err, "first_batch_reproduced_bitwise": same},
         }), flush=True)
@@ -487,7 +488,7 @@ def main():
         flop_per_image = 2.0 * cfg.macs_per_crop() * CROPS_PER_IMAGE + 2.0 * sum(
             REG_SIZES[i] * REG_SIZES[i + 1] for i in range(len(REG_SIZES) - 1))
         reg_flop = 2.0 * sum(REG_SIZES[i] * REG_SIZES[i + 1] for i in range(len(REG_SIZES) - 1))
-        exec_macs = cfg.macs_per_crop_executed() if args.dtype == "bf16" else cfg.macs_per_crop()
+        exec_macs = cfg.macs_per_crop_executed()
         flop_exec_per_image = 2.0 * exec_macs * CROPS_PER_IMAGE + reg_flop
         # dominant kernel = largest share of the step among the device kernels (names as rocprofv3 prints them)
         DOMINANT = max((k for k in prof if not k.startswith("shape:")), key=lambda k: prof[k][0])
@@ -513,7 +514,7 @@ def main():
                        "chunk_crops": args.chunk or 2048},
             "end_to_end": {"tflops": round(value * flop_per_image / 1e12, 1),
                            "frac_of_bf16_peak": round(value * flop_per_image / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
-                           # the bf16 path runs the LAST block's Q / attention / out-proj / MLP on the class-token row only
+                           # the LAST block's Q / attention / out-proj / MLP run on the class-token row only
                            # (dead rows are not computed); this is the rate of the arithmetic actually issued
                            "executed_tflops": round(value * flop_exec_per_image / 1e12, 1),
                            "flop_per_image": flop_per_image, "flop_per_image_executed": flop_exec_per_image},

@@ -241,15 +241,20 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     const size_t D = g.width;
     uint8_t* h8 = (uint8_t*)e->hid;
     // A8: operand rows (per-token scales sa, or NULL when its columns carry static scales folded into W8)
-    auto gemm8 = [&](const uint8_t* A8, const float* sa, const uint8_t* W8, const float* sw, const float* bias, int N, int K,
-                     int act, void* out, int epi, const float* out_inv, int kind, int sub) -> hipError_t {
+    // general form: M rows of A8 (row stride lda bytes), output rows ldo elements apart
+    auto gemm8x = [&](const uint8_t* A8, int M, int lda, const float* sa, const uint8_t* W8, const float* sw, const float* bias, int N,
+                      int K, int act, void* out, int ldo, int epi, const float* out_inv, int kind, int sub) -> hipError_t {
       GemmParams q{};
-      q.A = A8; q.lda = K; q.W = W8; q.ldw = K; q.M = T; q.N = N; q.K = K; q.out = out; q.ldo = N; q.bias = bias;
+      q.A = A8; q.lda = lda; q.W = W8; q.ldw = K; q.M = M; q.N = N; q.K = K; q.out = out; q.ldo = ldo; q.bias = bias;
       q.scale_a = sa; q.scale_w = sw; q.act = act; q.resid = epi == EPI_RESID ? out : nullptr; q.out_inv_scale = out_inv;
-      pf.begin(kind, 2.0 * dT * (double)N * (double)K, st, sub);
+      pf.begin(kind, 2.0 * (double)M * (double)N * (double)K, st, sub);
       hipError_t err = ce_gemm_fp8(q, epi, st);
       pf.end(st);
       return err;
+    };
+    auto gemm8 = [&](const uint8_t* A8, const float* sa, const uint8_t* W8, const float* sw, const float* bias, int N, int K,
+                     int act, void* out, int epi, const float* out_inv, int kind, int sub) -> hipError_t {
+      return gemm8x(A8, T, K, sa, W8, sw, bias, N, K, act, out, N, epi, out_inv, kind, sub);
     };
     auto quant = [&](const bf16_t* in, size_t K, int ln) -> hipError_t {
       pf.begin(ln ? PK_QUANT_LN : PK_QUANT, 0.0, st);
@@ -260,6 +265,36 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     for (int l = 0; l < n_layers; ++l) {
       const LayerDev& L = e->layers[l];
       const LayerDev8& Q = e->layers8[l];
+      if (cls_only_last && l == n_layers - 1) {
+        // LAST block on the class-token rows only (see the bf16 branch below for the argument): K | V for every token, then
+        // Q, attention, out-proj and the MLP on the c CLS rows (row stride = tokens rows).  The compact quantised CLS rows and
+        // their scales reuse the head of a8 / sa8 once the K|V GEMM has consumed the full operand (stream order).
+        const size_t Dw = D;
+        const int stride = e->tokens;
+        HIP_TRY(quant(e->x, D, 1));
+        HIP_TRY(gemm8x(e->a8, T, (int)Dw, e->sa8, Q.w_qkv + Dw * Dw, Q.s_qkv + Dw, L.b_qkv + Dw, 2 * g.width, g.width, -1,
+                       e->qkv + Dw, 3 * g.width, EPI_STORE_BF16, nullptr, PK_GEMM8_QKV, -1));
+        auto quant_cls = [&]() -> hipError_t {                 // LN + quantise the CLS rows of x -> a8[0..c), sa8[0..c)
+          pf.begin(PK_QUANT_LN, 0.0, st);
+          hipError_t err = ce_quant_rows_fp8(e->x, 0, (size_t)stride * Dw, e->a8, Dw, e->sa8, c, (int)Dw, 1, g.ln_eps, st);
+          pf.end(st);
+          return err;
+        };
+        HIP_TRY(quant_cls());
+        HIP_TRY(gemm8x(e->a8, c, (int)Dw, e->sa8, Q.w_qkv, Q.s_qkv, L.b_qkv, g.width, g.width, -1, e->qkv, stride * 3 * g.width,
+                       EPI_STORE_BF16, nullptr, PK_GEMM8_QKV, -1));
+        pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * dD, st);
+        HIP_TRY(ce_attention(e->qkv, e->a8, c, e->tokens, g.width, g.heads, Q.is_attn, 1, st));   // O of rows 0..31 of every crop, e4m3
+        pf.end(st);
+        HIP_TRY(gemm8x(e->a8, c, stride * g.width, nullptr, Q.w_out, Q.s_out, L.b_out, g.width, g.width, -1, e->x, stride * g.width,
+                       EPI_RESID, nullptr, PK_GEMM8_RESID, PK_SUB8_OUT));
+        HIP_TRY(quant_cls());
+        HIP_TRY(gemm8x(e->a8, c, (int)Dw, e->sa8, Q.w_fc, Q.s_fc, L.b_fc, g.mlp_dim, g.width, g.act, h8, g.mlp_dim, EPI_STORE_FP8,
+                       Q.is_hid, PK_GEMM8_FC1, -1));
+        HIP_TRY(gemm8x(h8, c, g.mlp_dim, nullptr, Q.w_proj, Q.s_proj, L.b_proj, g.width, g.mlp_dim, -1, e->x, stride * g.width,
+                       EPI_RESID, nullptr, PK_GEMM8_RESID, PK_SUB8_FC2));
+        break;
+      }
       HIP_TRY(quant(e->x, D, 1));
       HIP_TRY(gemm8(e->a8, e->sa8, Q.w_qkv, Q.s_qkv, L.b_qkv, 3 * g.width, g.width, -1, e->qkv, EPI_STORE_BF16, nullptr, PK_GEMM8_QKV, -1));
       pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * e->tokens * dD, st);
