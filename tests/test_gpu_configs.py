@@ -217,3 +217,38 @@ def test_config4_dedup_100k_planted_pairs(gpu):
     ref = np.array([s32[k, c + k] for k in range(c)])
     assert np.abs(v - ref).max() <= 1.0e-3                                 # fp16 rounding of the normalised rows and of the output
     assert v.min() > thr and v.max() <= 1.0005
+
+
+# ------------------------------------------------------------------------------------- configs[3]
+@pytest.mark.parametrize("precision", ["fp8", "bf16"])
+def test_config3_job_runner_small_job_on_the_gpu(vit_l14, gpu, precision):
+    """BASELINE.json configs[3] control flow with the real encoder: a 600-image job in batches of 256 (ragged last batch of
+    88), uint8 crops generated on the device per batch from the counter-based source, results kept in HBM.  Every stored row
+    must equal what a stand-alone call returns for the same generated crops, and a second run of the job must reproduce the
+    first bit for bit (deterministic encoder + reproducible source)."""
+    from clip_assisted_data_labeling_amd.job import run_embed_job, synthetic_u8_source
+    cfg, sd, vit = vit_l14
+    Ws, bs = np_fc_weights([4 * cfg.embed_dim, 264, 128, 64, 1], 21)
+    reg = HipRegressor([torch.from_numpy(w) for w in Ws], [torch.from_numpy(b) for b in bs], 0.01, gpu)
+    vit.set_precision(precision)
+    try:
+        def run():
+            src = synthetic_u8_source(cfg.image_size, 4, 777, 0, gpu)
+            return run_embed_job(600, 256, 4, cfg.embed_dim, 1, src, lambda c: vit.encode_score(c, reg, 4, [0, 1, 2, 3]), gpu,
+                                 sync=torch.cuda.synchronize)
+        a, b = run(), run()
+        assert a["batches"] == 3 and a["emb"].shape == (600, 4, cfg.embed_dim) and a["score"].shape == (600, 1)
+        assert torch.equal(a["emb"], b["emb"]) and torch.equal(a["score"], b["score"])
+        assert torch.isfinite(a["emb"]).all() and torch.allclose(a["emb"].norm(dim=-1), torch.ones(600, 4, device=gpu), atol=1e-5)
+        # the same crops outside the job: regenerate the stream and encode the ragged LAST batch on its own
+        src = synthetic_u8_source(cfg.image_size, 4, 777, 0, gpu)
+        src(0, 256); src(256, 256)
+        last = src(512, 88)
+        e, s = vit.encode_score(last, reg, 4, [0, 1, 2, 3])
+        assert torch.equal(e, a["emb"][512:]) and torch.equal(s, a["score"][512:])
+        # scores are the C oracle's on the stored embeddings (utils/nn_model.py:38-41)
+        ref = fcreg_oracle.forward_c(Ws, bs, a["emb"].cpu().numpy().reshape(600, -1))
+        assert np.abs(a["score"].cpu().numpy() - ref).max() < SCORE_TOL
+    finally:
+        vit.set_precision("bf16")
+        reg.close()
