@@ -482,16 +482,26 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
       constexpr int dummy = 0; (void)dummy;
       f32x16_t s[CT];
       // ---- S^T tiles of this chunk: s[c][reg] = <K[32(kt0+c) + krow(reg,h)], Q[q]> ----
+      // K fragments of tile c + 1 are read before the MFMAs of tile c are issued (register double buffer; hipcc otherwise reads
+      // each fragment right in front of its MFMA and waits: 29.6 -> 28.8 ms per step; the same for the V reads spills)
+      bf16x8_t kfa[4], kfb[4];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) kfa[st] = *(const bf16x8_t*)(Ks + k_swz(kt0 * 32 + r, st * 2 + h));
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         if (kt0 + c < NKT) {
+          if (c + 1 < CT && kt0 + c + 1 < NKT) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st) kfb[st] = *(const bf16x8_t*)(Ks + k_swz((kt0 + c + 1) * 32 + r, st * 2 + h));
+          }
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int e = 0; e < 16; ++e) s[c][e] = 0.f;
 #pragma unroll
-          for (int st = 0; st < 4; ++st) {
-            bf16x8_t kf = *(const bf16x8_t*)(Ks + k_swz((kt0 + c) * 32 + r, st * 2 + h));
-            s[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[c], 0, 0, 0);
-          }
+          for (int st = 0; st < 4; ++st) s[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[st], qf[st], s[c], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int st = 0; st < 4; ++st) kfa[st] = kfb[st];
         }
       }
       if (kt0 + CT >= NKT) {                                    // last chunk: next block's Q can start flying
@@ -533,15 +543,17 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {
             if (kt < NKT - 1 || s2 == 0 || kt * 32 + 16 < n_tok) {   // wave-uniform; skips an all-padding k-step
+              typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+              const int key0 = kt * 32 + s2 * 16 + 4 * h;
               float pv[8];
 #pragma unroll
               for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(fmaf(s[c][s2 * 8 + j], scale_log2e, -moff));
               const u32x4_t pw = {cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]),
                                   cvt_pk_bf16(pv[6], pv[7])};
               const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
-              // row sums of the ROUNDED weights on the matrix pipe: ones^T . P^T (every output row = the sum)
+              // row sums of the ROUNDED weights on the matrix pipe: ones^T . P^T (every output row = the sum); as VALU adds
+              // (18 fewer MFMAs, 144 more adds per block) it measured equal-to-slower and spilled in one instantiation
               lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
-              const int key0 = kt * 32 + s2 * 16 + 4 * h;
 #pragma unroll
               for (int dt = 0; dt < 2; ++dt) {
                 const int i = lane & 15, qq = i >> 2, pp = i & 3, g1 = (lane >> 4) & 1;
@@ -551,7 +563,6 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
                     (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(ra, dcol >> 3) + (dcol & 7) * 2));
                 s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
                     (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(rb, dcol >> 3) + (dcol & 7) * 2));
-                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
                 s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, o[dt], 0, 0, 0);
               }
