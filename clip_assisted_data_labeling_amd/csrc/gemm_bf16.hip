@@ -260,7 +260,7 @@ hipError_t ce_gemm_nt(const GemmParams& p, int dtype, int epi, hipStream_t strea
   }
   if (epi == EPI_THRESH) {
     if (!p.tri || p.M != p.N || p.A != p.W || !p.pairs || !p.vals || !p.count || p.n_valid > p.M) return hipErrorInvalidValue;
-    if (dtype == CE_DT_F16) return launch_t<_Float16, EPI_THRESH>(p, stream);
+    if (dtype == CE_DT_F16) return ce_gemm_tri_persist(p, stream);             // persistent pipeline (gemm_tri.hip)
     if (dtype == CE_DT_BF16) return launch_t<__bf16, EPI_THRESH>(p, stream);
   }
   return hipErrorInvalidValue;

@@ -69,6 +69,21 @@ __device__ __forceinline__ void glds16_at(const char* base, unsigned off, unsign
 
 struct TileId { int m0, n0, tn; };
 
+// operand type per epilogue: the near-duplicate search (EPI_THRESH, gemm_tri.hip) runs on f16 operands, everything else on bf16
+template <int EPI> struct OperandOf { typedef bf16x8_t frag; };
+template <> struct OperandOf<EPI_THRESH> { typedef f16x8_t frag; };
+__device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4_t mfma16(f16x8_t a, f16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+// upper-triangular tile list of a TT x TT tile grid, row-major: row tm holds tiles tn = tm .. TT-1 (EPI_THRESH).  A workgroup
+// walks the list in steps of the grid size; the position (row tm, offset off in the row) is advanced with scalar integer
+// arithmetic only (a closed form needs a double-precision square root per tile: ~30 VALU instructions whose spilled constants
+// came back behind a vmcnt(0), i.e. a drain of the DMA pipeline at every tile boundary).
+__device__ __forceinline__ void tri_advance(int& tm, int& off, int step, int TT) {
+  off += step;
+  while (tm < TT && off >= TT - tm) { off -= TT - tm; ++tm; }
+}
+
 __device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n, bool deep_narrow) {
   const int nwg = tiles_m * tiles_n;
   const int q = nwg >> 3, r = nwg & 7, xcd = idx & 7, pos = idx >> 3;
@@ -84,7 +99,7 @@ __device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n,
 
 template <int EPI, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p) {
-  typedef bf16x8_t frag_t;
+  typedef typename OperandOf<EPI>::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -94,8 +109,10 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   const int frow = lane & 15;
 
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
-  const int nwg = tiles_m * tiles_n;
+  const int nwg = EPI == EPI_THRESH ? tiles_n * (tiles_n + 1) / 2 : tiles_m * tiles_n;
   const bool deep_narrow = tiles_n <= 4 && p.K >= 2048;
+  int tri_m = 0, tri_off = 0;                 // EPI_THRESH: position of the NEXT tile to decode in the triangular list
+#define DECODE_TILE(i_) (EPI == EPI_THRESH ? TileId{tri_m * BM, (tri_m + tri_off) * BN, tri_m + tri_off} : decode_tile((i_), tiles_m, tiles_n, deep_narrow))
   const int G = gridDim.x;
   const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
   const int kend = p.K * 2;                  // bytes along K; one stage = 128 B; K % 128 == 0 (stages come in pairs)
@@ -118,7 +135,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 #define TW_ADDR(nt) (tr + tw_base + ((((nt) * 2 + (qd >> 1)) ^ tw_sw) << 4))
 
   int idx = blockIdx.x;
-  TileId cur = decode_tile(idx, tiles_m, tiles_n, deep_narrow);
+  if (EPI == EPI_THRESH) tri_advance(tri_m, tri_off, idx, tiles_n);
+  TileId cur = DECODE_TILE(idx);
   const char* Ablk = (const char*)p.A + (size_t)cur.m0 * lda_b;
   const char* Wblk = (const char*)p.W + (size_t)cur.n0 * ldw_b;
 #define AOFF(m0v, r) ((unsigned)((min((m0v) + (r), p.M - 1) - (m0v)) * lda_b) + dchunk16)
@@ -169,8 +187,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
     _Pragma("unroll") for (int j = 0; j < 4; ++j)                                           \
-      acc[(half) * 4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kh * 4 + j], fa[kh * 4 + i],               \
-                                   ((ZC) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(half) * 4 + i][j], 0, 0, 0); \
+      acc[(half) * 4 + i][j] = mfma16(fb[kh * 4 + j], fa[kh * 4 + i],                                               \
+                                   ((ZC) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(half) * 4 + i][j]);          \
   } while (0)
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
 #define WAIT_LDS()                                                                          \
@@ -258,7 +276,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
     if (has_next) {
-      nxt = decode_tile(nidx, tiles_m, tiles_n, deep_narrow);
+      if (EPI == EPI_THRESH) tri_advance(tri_m, tri_off, G, tiles_n);
+      nxt = DECODE_TILE(nidx);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
     }
@@ -289,6 +308,48 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 #endif
 
     // ------------------------------- epilogue of tile `cur` -------------------------------
+    if constexpr (EPI == EPI_THRESH) {
+      // /root/reference/_2_remove_duplicates.py:74: where(triu(S, 1) > threshold) -> (i, j, S[i][j]), appended through one
+      // atomic counter; lane (row = lane & 15, quad = lane >> 4) holds columns 4 quad + 0..3 of each 16 x 16 block
+      const float thr = p.fp16_compare ? (float)(_Float16)p.thr : p.thr;
+      const int frow_t = lane & 15, q4t = (lane >> 4) * 4;
+      // Screen first: almost every tile holds no value anywhere near the threshold (random unit vectors have cosines of a
+      // few hundredths), and the exact test below costs ~7 VALU instructions per value (fp16 rounding, index tests): one
+      // running maximum per lane and a wave vote skip it.  The margin covers the fp16 rounding of the value (half an ulp of
+      // fp16 at 1.0 = 4.9e-4), so no qualifying pair can hide behind the screen.
+      float vmax = -1e30f;
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+        {   // two v_max3_f32 per accumulator (fmaxf puts a canonicalising v_max in front of every MFMA output: 3x the instructions)
+          asm("v_max3_f32 %0, %0, %1, %2" : "+v"(vmax) : "v"(acc[mt][nt][0]), "v"(acc[mt][nt][1]));
+          asm("v_max3_f32 %0, %0, %1, %2" : "+v"(vmax) : "v"(acc[mt][nt][2]), "v"(acc[mt][nt][3]));
+        }
+      if (__builtin_amdgcn_ballot_w64(vmax > thr - 2.0e-3f * fmaxf(1.0f, fabsf(thr))) != 0ull) {
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) {
+        const int i = cur.m0 + wr * 128 + mt * 16 + frow_t;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = cur.n0 + wc * 64 + nt * 16 + q4t + e;
+            float v = acc[mt][nt][e];
+            if (p.fp16_compare) v = (float)(_Float16)v;
+            if (j > i && j < p.n_valid && v > thr) {
+              const unsigned long long slot = atomicAdd(p.count, 1ull);
+              if (slot < p.cap) {
+                p.pairs[slot * 2 + 0] = i;
+                p.pairs[slot * 2 + 1] = j;
+                p.vals[slot] = v;
+              }
+            }
+          }
+        }
+      }
+      }
+    } else {
     // epilogue lane mapping: 16-row x 128-B image per wave, 16-B chunk index XOR row&7 -- derived here from an opaque copy
     // of the lane id, so that hipcc does not carry these constants through the main loop
     int lane_e = lane;
@@ -438,6 +499,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       __syncthreads();                       // AUX is rewritten by the next tile's epilogue
     }
 
+    }
+
 #ifdef CLIPENC_DIAG
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 3] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 0] = blockIdx.x; }
 #endif
@@ -447,9 +510,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     }
     // all 256 rows valid: every guarded store above was issued (the waves of EPI_RESID that store statistics issued 17)
 #ifdef CLIPENC_DIAG
-    relax = (cur.m0 + BM <= p.M && p.dbg == nullptr) ? 2 : 0;   // (the stamps add stores: no relaxed waits then)
+    relax = (EPI != EPI_THRESH && cur.m0 + BM <= p.M && p.dbg == nullptr) ? 2 : 0;   // (the stamps add stores: no relaxed waits then)
 #else
-    relax = (cur.m0 + BM <= p.M) ? 2 : 0;      // the first two waits of the coming tile
+    relax = (EPI != EPI_THRESH && cur.m0 + BM <= p.M) ? 2 : 0;      // the first two waits of the coming tile (EPI_THRESH issues a data-dependent number of stores: never relaxed)
 #endif
     idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
     ++tile_iter;
@@ -461,7 +524,8 @@ hipError_t launch_persist(const GemmParams& p, hipStream_t stream) {
   static DeviceKernelSetup setup;             // per device: LDS opt-in + CU count (common.h)
   int n_cu = 0;
   if (hipError_t e = setup.ensure((const void*)gemm_persist_kernel<EPI, ACT>, LDS_BYTES, &n_cu); e != hipSuccess) return e;
-  const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
+  if (EPI == EPI_THRESH) { const int tt = p.N / BN; tiles = tt * (tt + 1) / 2; }
   int grid = n_cu > 0 ? n_cu : 256;
   grid -= grid % 8;                           // keep tile index mod 8 == workgroup index mod 8 (XCD affinity)
   if (grid < 8) grid = 8;
@@ -472,6 +536,12 @@ hipError_t launch_persist(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef GEMM_PERSIST_TRI_TU
+// gemm_tri.hip: the same kernel template instantiated in a translation unit of its own for the near-duplicate search (f16
+// operands, upper-triangular tile list, threshold + append epilogue), so that it cannot perturb the code generation of the
+// encoder's instantiations (guide rule 19).
+hipError_t ce_gemm_tri_persist(const GemmParams& p, hipStream_t stream) { return launch_persist<EPI_THRESH, -1>(p, stream); }
+#else
 hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream) {
   switch (epi) {
     case EPI_STORE_BF16: return launch_persist<EPI_STORE_BF16, -1>(p, stream);
@@ -483,3 +553,4 @@ hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream) 
     default: return hipErrorInvalidValue;
   }
 }
+#endif
