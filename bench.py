@@ -217,7 +217,7 @@ def dedup_100k(dev):
     tf = flop / (ms * 1e-3) / 1e12
     return {"workload": "BASELINE.json configs[4]: 100000 x 768 fp16, 1000 planted pairs, thr 0.96 (normalise + triangular GEMM + compaction)",
             "ms": round(ms, 3), "pairs_found": int(count.item()), "algorithmic_tflop": round(flop / 1e12, 3),
-            "tflops": round(tf, 1), "frac_of_f16_peak": round(tf / PEAK_BF16_TFLOPS, 4), "kernel": "gemm_nt_kernel<_Float16, 4>"}
+            "tflops": round(tf, 1), "frac_of_f16_peak": round(tf / PEAK_BF16_TFLOPS, 4), "kernel": "gemm_persist_kernel<4, -1> (gemm_tri.hip: f16 operands, triangular tile list)"}
 
 
 def cpu_baseline(cfg, sd, Ws, bs):
