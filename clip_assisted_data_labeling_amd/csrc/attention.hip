@@ -353,30 +353,35 @@ hipError_t launch_attn_long(const bf16_t* qkv, bf16_t* out, int n_crops, int n_t
 // (crop, head) tasks.  K and V of two tasks live in LDS (2 x 72 KiB).  The loader wave fills the buffer of
 // task k by LDS-DMA as soon as all 32-query blocks of task k-2 are done, so the HBM stream keeps
 // running while the compute waves work on the resident tasks.  The blocks of consecutive tasks form ONE
-// stream dealt round-robin to the compute waves (no 4+4+1 tail per task).  There is no s_barrier in the
+// stream handed out in order from an LDS counter (no 4+4+1 tail per task; of the 7 compute waves on 4 SIMDs
+// the one that shares its SIMD only with the loader takes ~50 % more blocks).  There is no s_barrier in the
 // steady state: the loader publishes `landed` (tasks whose K/V are readable) in LDS and the compute
 // waves count finished blocks per task in LDS; both sides poll with s_sleep and every spin is bounded.
 // Compute waves issue no LDS-DMA, so hipcc keeps counted waits for their Q loads and O stores.
 // O goes through a wave-private 2 KiB LDS image and leaves as whole 128-B rows.
 // ---------------------------------------------------------------------------------------------
 constexpr unsigned SPIN_LIMIT = 1u << 24;
+#ifdef ATTN_STAMPS               // timing experiment (results invalid): per-wave s_memtime ticks per section, written over `out`
+#define STAMP(i_) do { __builtin_amdgcn_sched_barrier(0); stamp[i_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(i_) do { } while (0)
+#endif
 
 __device__ __forceinline__ unsigned lds_load_u32(const char* p) {
   return __atomic_load_n((const unsigned*)p, __ATOMIC_RELAXED);
 }
 
-template <int NKT, int CT, int NCW>
+template <int NKT, int NCW>
 __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n_tok, int width, int heads, float scale_log2e,
     int n_tasks, int dbg_mode, const float* __restrict__ out_inv, int q_blocks) {
-  // NCW compute waves + 1 loader; keys walked in chunks of CT tiles (CT == NKT: one exact pass; CT < NKT:
-  // online softmax, fewer live score registers -> 3 waves per SIMD).
+  // NCW compute waves + 1 loader; all NKT key tiles of a block's scores live in registers (one exact pass)
   // dbg_mode (timing experiments only, results invalid): 1 = loader alone, 2 = compute alone
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWS = NKT * 32, MAT = ROWS * 128, BUF = 2 * MAT;
   constexpr int TRB = NCW <= 7 ? 2048 : 1024;                   // wave-private O image: 16 or 8 rows x 128 B
   constexpr int TR_ROWS = TRB / 128;
-  constexpr int CTRL = 2 * BUF + NCW * TRB;                     // [0]: landed, [16..]: done[k] per task (<= 496 tasks)
+  constexpr int CTRL = 2 * BUF + NCW * TRB;                     // [0]: landed, [4]: next block, [16..]: done[k] per task (<= 496 tasks)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int G = gridDim.x, wg = blockIdx.x;
@@ -445,14 +450,27 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
     const int cc = tt / heads, hh = tt - cc * heads;
     return qkv + (size_t)cc * n_tok * ld + hh * 64 + (size_t)min(qq * 32 + r, n_tok - 1) * ld + h * 8;
   };
+  // blocks are handed out in order from an LDS counter: a wave that has its SIMD to itself takes more of them
+  auto grab = [&]() -> int {
+    unsigned v = 0;
+    if (lane == 0) v = __atomic_fetch_add((unsigned*)(ctrl + 4), 1u, __ATOMIC_RELAXED);
+    return (int)__builtin_amdgcn_readfirstlane(v);
+  };
+  const int g_first = grab();
   bf16x8_t qf[4];
   {
-    const bf16_t* qp = q_ptr(min(wave, total_blocks - 1));
+    const bf16_t* qp = q_ptr(min(g_first, total_blocks - 1));
 #pragma unroll
     for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qp + st * 16);
   }
 
-  for (int g = wave; g < total_blocks; g += NCW) {
+#ifdef ATTN_STAMPS
+  unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0}, sect[5] = {0, 0, 0, 0, 0}, nblk = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+#endif
+  for (int g = g_first, g_next = 0; g < total_blocks; g = g_next) {
+    STAMP(0);
+    g_next = grab();                                            // the block after this one: its Q is prefetched below
     const int k = g / n_qb, qb = g - k * n_qb;
     const int t = t0 + k;
     const int crop = t / heads, head = t - crop * heads;
@@ -464,117 +482,148 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
       while (lds_load_u32(ctrl) <= (unsigned)k && ++spins < SPIN_LIMIT) __builtin_amdgcn_s_sleep(1);
       asm volatile("" ::: "memory");
     }
+    STAMP(1);
 
-    f32x16_t o[2];
+    f32x16_t o[2], lacc;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
-    float m_run = -INFINITY;
-    f32x16_t lacc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
+    for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; lacc[e] = 0.f; }
     const u32x4_t ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // eight bf16 1.0
     const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_w);
 
+    // ---- S^T tiles: s[c][reg] = <K[32 c + krow(reg,h)], Q[q]>.  K fragments of tile c + 1 are read before the MFMAs of tile c are
+    // issued (register double buffer; hipcc otherwise reads each fragment right in front of its MFMA and waits), and the row max of
+    // the finished tile c - 1 runs in the shadow of tile c's MFMAs, as four independent v_max3 chains (one chain of 72 dependent
+    // v_max3 after the last tile took twice as long by the section stamps) ----
+    f32x16_t s[NKT];
+    bf16x8_t kfa[4], kfb[4];
+    float mx4[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
-    for (int kt0 = 0; kt0 < NKT; kt0 += CT) {
-      constexpr int dummy = 0; (void)dummy;
-      f32x16_t s[CT];
-      // ---- S^T tiles of this chunk: s[c][reg] = <K[32(kt0+c) + krow(reg,h)], Q[q]> ----
-      // K fragments of tile c + 1 are read before the MFMAs of tile c are issued (register double buffer; hipcc otherwise reads
-      // each fragment right in front of its MFMA and waits: 29.6 -> 28.8 ms per step; the same for the V reads spills)
-      bf16x8_t kfa[4], kfb[4];
+    for (int st = 0; st < 4; ++st) kfa[st] = *(const bf16x8_t*)(Ks + k_swz(r, st * 2 + h));
 #pragma unroll
-      for (int st = 0; st < 4; ++st) kfa[st] = *(const bf16x8_t*)(Ks + k_swz(kt0 * 32 + r, st * 2 + h));
+    for (int c = 0; c < NKT; ++c) {
+      if (c + 1 < NKT) {
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        if (kt0 + c < NKT) {
-          if (c + 1 < CT && kt0 + c + 1 < NKT) {
-#pragma unroll
-            for (int st = 0; st < 4; ++st) kfb[st] = *(const bf16x8_t*)(Ks + k_swz((kt0 + c + 1) * 32 + r, st * 2 + h));
-          }
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int e = 0; e < 16; ++e) s[c][e] = 0.f;
-#pragma unroll
-          for (int st = 0; st < 4; ++st) s[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[st], qf[st], s[c], 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int st = 0; st < 4; ++st) kfa[st] = kfb[st];
-        }
+        for (int st = 0; st < 4; ++st) kfb[st] = *(const bf16x8_t*)(Ks + k_swz((c + 1) * 32 + r, st * 2 + h));
       }
-      if (kt0 + CT >= NKT) {                                    // last chunk: next block's Q can start flying
-        const bf16_t* qp = q_ptr(min(g + NCW, total_blocks - 1));
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qp + st * 16);
+      for (int e = 0; e < 16; ++e) s[c][e] = 0.f;
+#pragma unroll
+      for (int st = 0; st < 4; ++st) s[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfa[st], qf[st], s[c], 0, 0, 0);
+      if (c >= 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) mx4[e & 3] = fmaxf(mx4[e & 3], s[c - 1][e]);
       }
-      // ---- mask padded keys (last tile only), chunk max ----
-      float mx = m_run;
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        if (kt0 + c < NKT) {
+      for (int st = 0; st < 4; ++st) kfa[st] = kfb[st];
+    }
+    STAMP(2);
+    // ---- the last tile: mask its padded keys, finish the max (exact two-pass softmax: the true row max) ----
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            if (kt0 + c == NKT - 1) {
-              const int key = (kt0 + c) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-              if (key >= n_tok) s[c][e] = -INFINITY;
-            }
-            mx = fmaxf(mx, s[c][e]);
-          }
-        }
-      }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float moff = mx * scale_log2e;
-      if (CT < NKT) {                                           // online softmax: bring O and l to the new max
-        const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);    // 0 on the first chunk
-        m_run = mx;
-        lacc[0] *= alpha;
+    for (int e = 0; e < 16; ++e) {
+      const int key = (NKT - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (key >= n_tok) s[NKT - 1][e] = -INFINITY;
+      mx4[e & 3] = fmaxf(mx4[e & 3], s[NKT - 1][e]);
+    }
+    float mx = fmaxf(fmaxf(mx4[0], mx4[1]), fmaxf(mx4[2], mx4[3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float moff = mx * scale_log2e;
+    STAMP(3);
+
+    // ---- P = exp2(s*c - m*c), row sum, O^T += V^T . P^T as a software pipeline over 16-key steps with the program order pinned:
+    // the three MFMAs of step j (ones . P^T for the row sums of the ROUNDED weights, V^T . P^T for the two 32-wide halves of d) with
+    // the 20 VALU instructions of step j + 1 between them -- an MFMA holds the matrix pipe for 32 cycles, v_fma_f32 takes 5.2 and
+    // v_exp_f32 ~11 cycles of VALU issue in its shadow (tools/probes/issue_overlap_probe.hip) -- and each V fragment is read again
+    // for step j + 1 right behind the MFMA that consumed it, a whole step ahead of its use.  Left to itself hipcc computes a step's
+    // weights, reads its V fragments and waits for them in front of the MFMAs (section stamps: a quarter less time in this phase).
+    // No v_pk_fma_f32 for the scaling: packed fp32 runs on the matrix pipe (8.5 cycles each, serialised with the MFMAs). ----
+    {
+      constexpr int J = 2 * NKT - 1;                            // steps that always hold a real key; step J only if n_tok > 16 J
+      constexpr int QPF = 5;                                    // step at which the next block's Q loads are issued (s[0], s[1] are dead)
+      const int vi = lane & 15, vq = vi >> 2, vp = vi & 3, vg1 = (lane >> 4) & 1;
+      // V^T fragment of step j, half dt: rows 16 j + 4 h + q and + 8, 16-B chunk (32 dt + 16 g1 + 4 p) / 8; the swizzle term of
+      // those rows is ((q >> 1) & 1) for every j, so a step is a constant offset from a per-lane base
+      const char* vbase0 = Vs + v_swz(4 * h + vq, (vg1 * 16 + vp * 4) >> 3) + ((vg1 * 16 + vp * 4) & 7) * 2;
+      const char* vbase1 = Vs + v_swz(4 * h + vq, (32 + vg1 * 16 + vp * 4) >> 3) + ((vg1 * 16 + vp * 4) & 7) * 2;
+      auto p_scale = [&](int j, float (&t)[8]) {
+        const int c = j >> 1, s2 = j & 1;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
+        for (int i = 0; i < 8; ++i) t[i] = fmaf(s[c][s2 * 8 + i], scale_log2e, -moff);
+      };
+      auto v_frag = [&](int j, const char* vb) -> bf16x8_t {
+        typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+        s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + j * 2048));
+        s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + j * 2048 + 1024));
+        s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8_t, vv);
+      };
+      auto p_frag = [&](int j) -> bf16x8_t {
+        float t[8];
+        p_scale(j, t);
+        u32x4_t pw;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
-      }
-      // ---- P = exp2(s*c - m*c), row sum, O^T += V^T . P^T ----
+        for (int i = 0; i < 4; ++i) pw[i] = cvt_pk_bf16(__builtin_amdgcn_exp2f(t[2 * i]), __builtin_amdgcn_exp2f(t[2 * i + 1]));
+        return __builtin_bit_cast(bf16x8_t, pw);
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      bf16x8_t va = v_frag(0, vbase0), vb = v_frag(0, vbase1);
+      bf16x8_t pf = p_frag(0);
 #pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        if (kt0 + c < NKT) {
-          const int kt = kt0 + c;
+      for (int j = 0; j < J; ++j) {
+        float t[8];
+        u32x4_t pw = __builtin_bit_cast(u32x4_t, pf);
+        const bool nx = j + 1 < J;
+        __builtin_amdgcn_sched_barrier(0);
+        if (j == QPF) {                                         // next block's Q: in flight for the rest of this block
+          const bf16_t* qp = q_ptr(min(g_next, total_blocks - 1));
 #pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            if (kt < NKT - 1 || s2 == 0 || kt * 32 + 16 < n_tok) {   // wave-uniform; skips an all-padding k-step
-              typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-              const int key0 = kt * 32 + s2 * 16 + 4 * h;
-              float pv[8];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(fmaf(s[c][s2 * 8 + j], scale_log2e, -moff));
-              const u32x4_t pw = {cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]),
-                                  cvt_pk_bf16(pv[6], pv[7])};
-              const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
-              // row sums of the ROUNDED weights on the matrix pipe: ones^T . P^T (every output row = the sum); as VALU adds
-              // (18 fewer MFMAs, 144 more adds per block) it measured equal-to-slower and spilled in one instantiation
-              lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
-#pragma unroll
-              for (int dt = 0; dt < 2; ++dt) {
-                const int i = lane & 15, qq = i >> 2, pp = i & 3, g1 = (lane >> 4) & 1;
-                const int dcol = dt * 32 + g1 * 16 + pp * 4;
-                const int ra = key0 + qq, rb = key0 + 8 + qq;
-                s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(ra, dcol >> 3) + (dcol & 7) * 2));
-                s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(rb, dcol >> 3) + (dcol & 7) * 2));
-                s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, o[dt], 0, 0, 0);
-              }
-            }
-          }
+          for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qp + st * 16);
           __builtin_amdgcn_sched_barrier(0);
         }
+        lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nx) {
+          p_scale(j + 1, t);
+          // the empty asm makes the values exist HERE: instruction selection otherwise sinks them to their use behind the barriers
+          asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf, o[0], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nx) {
+          va = v_frag(j + 1, vbase0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t[i] = __builtin_amdgcn_exp2f(t[i]);
+          asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf, o[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nx) {
+          vb = v_frag(j + 1, vbase1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 4; i < 8; ++i) t[i] = __builtin_amdgcn_exp2f(t[i]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pw[i] = cvt_pk_bf16(t[2 * i], t[2 * i + 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        pf = __builtin_bit_cast(bf16x8_t, pw);
+      }
+      if (n_tok > J * 16) {                                     // wave-uniform: the last 16-key step holds real keys
+        const bf16x8_t vl0 = v_frag(J, vbase0), vl1 = v_frag(J, vbase1);
+        const bf16x8_t pl = p_frag(J);
+        lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pl, lacc, 0, 0, 0);
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl0, pl, o[0], 0, 0, 0);
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl1, pl, o[1], 0, 0, 0);
       }
     }
     // every K/V read of this block has returned (the MFMAs consumed them): release the buffer share
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __atomic_fetch_add((unsigned*)(ctrl + 16 + k * 4), 1u, __ATOMIC_RELAXED);
+    STAMP(4);
 
     const float inv = 1.0f / lacc[0];                           // the MFMA already summed both lane halves
 
@@ -634,22 +683,35 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
+#ifdef ATTN_STAMPS
+    STAMP(5);
+    for (int i = 0; i < 5; ++i) sect[i] += stamp[i + 1] - stamp[i];
+    ++nblk;
+#endif
   }
+#ifdef ATTN_STAMPS
+  {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    unsigned long long* so = (unsigned long long*)out + ((size_t)wg * NCW + wave) * 8;
+    if (lane == 0) { for (int i = 0; i < 5; ++i) so[i] = sect[i]; so[5] = nblk; so[6] = t_end - t_begin; so[7] = 0x5741505354414d50ull; }
+  }
+#endif
 }
 
-template <int NKT, int CT, int NCW>
+template <int NKT, int NCW>
 hipError_t launch_attn_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
                               const float* out_inv, int q_blocks, hipStream_t stream) {
   const int lds = 2 * 2 * NKT * 32 * 128 + NCW * (NCW <= 7 ? 2048 : 1024) + 2048;
   static DeviceKernelSetup setup;             // per device: LDS opt-in + CU count (common.h)
   int n_cu = 256;
-  if (hipError_t e = setup.ensure((const void*)attn_stream_kernel<NKT, CT, NCW>, lds, &n_cu); e != hipSuccess) return e;
+  if (hipError_t e = setup.ensure((const void*)attn_stream_kernel<NKT, NCW>, lds, &n_cu); e != hipSuccess) return e;
   const int n_tasks = n_crops * heads;
   int grid = n_tasks < n_cu ? n_tasks : n_cu;
   while ((n_tasks + grid - 1) / grid > 496) grid *= 2;      // per-workgroup task counters live in 2 KiB of LDS
   const float scale_log2e = 0.125f * 1.44269504088896340736f;
   static const int dbg = [] { const char* e = getenv("CLIPENC_ATTN_DBG"); return e ? atoi(e) : 0; }();
-  hipLaunchKernelGGL((attn_stream_kernel<NKT, CT, NCW>), dim3(grid), dim3((NCW + 1) * 64), lds, stream, qkv, out, n_tok, width, heads,
+  hipLaunchKernelGGL((attn_stream_kernel<NKT, NCW>), dim3(grid), dim3((NCW + 1) * 64), lds, stream, qkv, out, n_tok, width, heads,
                      scale_log2e, n_tasks, dbg, out_inv, q_blocks);
   return hipGetLastError();
 }
@@ -678,8 +740,8 @@ hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int 
   const bf16_t* q = (const bf16_t*)qkv;
   bf16_t* o = (bf16_t*)out;
   static const int impl = [] { const char* e = getenv("CLIPENC_ATTN_IMPL"); return e ? atoi(e) : 2; }();
-  if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8, 8, 7>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
-  if (impl == 2 && nkt == 9 && n_crops * heads >= 64) return launch_attn_stream<9, 9, 7>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+  if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8, 7>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+  if (impl == 2 && nkt == 9 && n_crops * heads >= 64) return launch_attn_stream<9, 7>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
   switch (nkt) {                 // NKT must equal ceil(n_tok/32): only the last key tile is masked
     case 1: return launch_attn<1>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
     case 2: return launch_attn<2>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);

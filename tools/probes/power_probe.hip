@@ -1,0 +1,107 @@
+// Probe: board power and sustained clock while all 256 CUs run one instruction type (two waves per SIMD), to price the
+// instruction types in joules: the board sits at its 1400 W cap under the encoder, so time follows energy.
+// Built as a small shared library driven by tools/probes/power_probe.py (which samples the hwmon power file):
+//   hipcc -O3 --offload-arch=gfx950 -shared -fPIC -o tools/probes/libpower_probe.so tools/probes/power_probe.hip
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+
+enum Role { SLEEP = 0, M32 = 1, M16 = 2, EXP = 3, FMA = 4, LDS128 = 5, LDSTR = 6, M32_EXP = 7, MAX3 = 8, M32Z = 9, M16Z = 10, DOT2 = 11, M32_LDS = 12 };
+
+#define MFMA32(acc, a_, b_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_))
+#define MFMA16(acc, a_, b_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_))
+
+template <int ROLE>
+__global__ __launch_bounds__(512, 2) void power_kernel(const uint32_t* __restrict__ rnd, unsigned long long* out, int iters) {
+  __shared__ __attribute__((aligned(16))) char lds[65536];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 65536 / 4; i += 512) ((uint32_t*)lds)[i] = rnd[i & 4095];
+  __syncthreads();
+  f32x16_t acc[4]; f32x4_t acc4[4];
+  for (int i = 0; i < 4; ++i) { for (int e = 0; e < 16; ++e) acc[i][e] = 0.f; for (int e = 0; e < 4; ++e) acc4[i][e] = 0.f; }
+  u32x4_t aw[4], bw[4];
+  for (int i = 0; i < 4; ++i)
+    for (int e = 0; e < 4; ++e) {
+      const bool z = (ROLE == M32Z || ROLE == M16Z);
+      aw[i][e] = z ? 0u : rnd[(lane * 16 + i * 4 + e) & 4095];
+      bw[i][e] = z ? 0u : rnd[(lane * 16 + i * 4 + e + 2048) & 4095];
+    }
+  float x[16]; for (int i = 0; i < 16; ++i) x[i] = -0.01f * (lane + i) - 0.5f;
+  const char* lp = lds + (((lane * 16) + wave * 1024) & 65535);
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+    if constexpr (ROLE == SLEEP) {
+      __builtin_amdgcn_s_sleep(64);
+    } else if constexpr (ROLE == M32 || ROLE == M32Z) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) MFMA32(acc[i & 3], __builtin_bit_cast(bf16x8_t, aw[i & 3]), __builtin_bit_cast(bf16x8_t, bw[(i + 1) & 3]));
+    } else if constexpr (ROLE == M16 || ROLE == M16Z) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) MFMA16(acc4[i & 3], __builtin_bit_cast(bf16x8_t, aw[i & 3]), __builtin_bit_cast(bf16x8_t, bw[(i + 1) & 3]));
+    } else if constexpr (ROLE == EXP) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32 %0, %1" : "=v"(x[i]) : "v"(x[i]));
+    } else if constexpr (ROLE == FMA) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(x[i & 15]) : "v"(x[(i + 1) & 15]), "v"(x[(i + 2) & 15]), "v"(x[(i + 3) & 15]));
+    } else if constexpr (ROLE == MAX3) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(x[i & 15]) : "v"(x[(i + 1) & 15]), "v"(x[(i + 2) & 15]), "v"(x[(i + 3) & 15]));
+    } else if constexpr (ROLE == DOT2) {
+#pragma unroll
+      for (int i = 0; i < 64; ++i) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(x[i & 15]) : "v"(aw[i & 3][0]), "v"(bw[i & 3][1]));
+    } else if constexpr (ROLE == LDS128) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        u32x4_t v;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(size_t)lp), "n"(i * 2048));
+        asm volatile("" :: "v"(v));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if constexpr (ROLE == LDSTR) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        uint2 v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(size_t)lp), "n"(i * 2048));
+        asm volatile("" :: "v"(v));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if constexpr (ROLE == M32_EXP) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        MFMA32(acc[i & 3], __builtin_bit_cast(bf16x8_t, aw[i & 3]), __builtin_bit_cast(bf16x8_t, bw[(i + 1) & 3]));
+        asm volatile("v_exp_f32 %0, %1" : "=v"(x[2 * i]) : "v"(x[2 * i]));
+        asm volatile("v_exp_f32 %0, %1" : "=v"(x[2 * i + 1]) : "v"(x[2 * i + 1]));
+      }
+    } else if constexpr (ROLE == M32_LDS) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        MFMA32(acc[i & 3], __builtin_bit_cast(bf16x8_t, aw[i & 3]), __builtin_bit_cast(bf16x8_t, bw[(i + 1) & 3]));
+        u32x4_t v;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"((unsigned)(size_t)lp), "n"(i * 2048));
+        asm volatile("" :: "v"(v));
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float sink = 0.f;
+  for (int i = 0; i < 16; ++i) sink += x[i];
+  for (int i = 0; i < 4; ++i) sink += acc[i][0] + acc4[i][0];
+  if (lane == 0) out[(size_t)blockIdx.x * 8 + wave] = t1 - t0;
+  if (sink == 12345.678f) out[0] = 0;
+}
+
+#define LAUNCH(R) case R: hipLaunchKernelGGL((power_kernel<R>), dim3(256), dim3(512), 0, (hipStream_t)stream, (const uint32_t*)rnd, (unsigned long long*)out, iters); break;
+extern "C" int power_probe_run(int role, const void* rnd, void* out, int iters, void* stream) {
+  switch (role) {
+    LAUNCH(SLEEP) LAUNCH(M32) LAUNCH(M16) LAUNCH(EXP) LAUNCH(FMA) LAUNCH(LDS128) LAUNCH(LDSTR) LAUNCH(M32_EXP) LAUNCH(MAX3) LAUNCH(M32Z) LAUNCH(M16Z)
+    LAUNCH(DOT2) LAUNCH(M32_LDS)
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Developer: board power, sustained shader clock and joules per instruction for single instruction types on all 256 CUs
+(tools/probes/power_probe.hip).  The encoder runs at the 1400 W cap, so a kernel's time follows its energy."""
+import ctypes, os, sys, time
+import numpy as np
+import torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from bench import EnvSampler  # noqa: E402
+
+ROLES = [("sleep", 0, 0, ""), ("mfma 32x32x16 bf16", 1, 8, "mfma"), ("mfma 32x32x16 zeros", 9, 8, "mfma"), ("mfma 16x16x32 bf16", 2, 16, "mfma"),
+         ("mfma 16x16x32 zeros", 10, 16, "mfma"), ("v_exp_f32", 3, 16, "instr"), ("v_fma_f32", 4, 64, "instr"), ("v_max3_f32", 8, 64, "instr"),
+         ("v_dot2c_f32_bf16", 11, 64, "instr"), ("ds_read_b128", 5, 16, "instr"), ("ds_read_b64_tr_b16", 6, 16, "instr"),
+         ("mfma32 + 2 exp", 7, 8, "mfma"), ("mfma32 + ds_read_b128", 12, 8, "mfma")]
+
+
+def main():
+    lib = ctypes.CDLL(os.path.join(HERE, "libpower_probe.so"))
+    f = lib.power_probe_run
+    f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    rnd = torch.randn(8192, device=dev, generator=g).to(torch.bfloat16).view(torch.int32).contiguous()     # 4096 dwords of bf16 pairs
+    out = torch.zeros(256 * 8, device=dev, dtype=torch.int64)
+    st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    secs = float(os.environ.get("PROBE_SECONDS", "1.5"))
+    base_w = None
+    print(f"{'role':28s} {'GHz':>6s} {'W':>7s} {'cyc/instr':>9s} {'G instr/s':>10s} {'nJ/instr (above sleep)':>22s}")
+    for name, role, per_body, kind in ROLES:
+        f(role, rnd.data_ptr(), out.data_ptr(), 2000, st); torch.cuda.synchronize()
+        t0 = time.perf_counter(); f(role, rnd.data_ptr(), out.data_ptr(), 20000, st); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        iters = int(min(2e9, max(1000, 20000 * secs / dt)))
+        with EnvSampler(0) as es:
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); f(role, rnd.data_ptr(), out.data_ptr(), iters, st); e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        cyc = out.double().mean().item()
+        ghz = cyc / ms / 1e6
+        pw = es.samples["power_w"]
+        w = float(np.median(pw[len(pw) // 3:])) if pw else float("nan")
+        if role == 0:
+            base_w = w
+            print(f"{name:28s} {ghz:6.3f} {w:7.0f}")
+            continue
+        n_instr = per_body * iters * 256.0 * 8
+        rate = n_instr / (ms * 1e-3)
+        nj = (w - base_w) / rate * 1e9
+        print(f"{name:28s} {ghz:6.3f} {w:7.0f} {cyc / (per_body * iters):9.2f} {rate / 1e9:10.1f} {nj:22.2f}")
+
+
+if __name__ == "__main__":
+    main()
