@@ -180,6 +180,46 @@ def probe_clock_during(fn, dev, n_probes=48, spacing_s=0.004):
     return (round(float(np.median(mhz)), 1) if ok.any() else None), int(ok.sum()), out
 
 
+def mfma_stream_ceiling(dev, fp8, seconds=0.4):
+    """What the board's power management grants the matrix pipes alone on this box: every SIMD issues nothing but the GEMM's
+    MFMA instruction on operand registers holding normal-variate bit patterns (no LDS, no memory traffic), for `seconds`;
+    timed with HIP events on the launch stream, power / clock from the hwmon files meanwhile.  The nominal peak assumes 2.4 GHz;
+    under such a stream the board settles at ~1.3 kW and ~2.0 GHz, and a GEMM -- which also pays for LDS, L2 and HBM traffic out
+    of the same budget -- sits below this rate."""
+    import ctypes
+    from clip_assisted_data_labeling_amd import _lib
+    lib = _lib.load()
+    st = _lib.current_stream_ptr(dev)
+    g = torch.Generator(device=dev).manual_seed(11)
+    if fp8:
+        ops = (torch.randn(32768, device=dev, generator=g) * 2).to(torch.float8_e4m3fn).view(torch.uint8)
+    else:
+        ops = torch.randn(16384, device=dev, generator=g).to(torch.bfloat16).view(torch.uint8)
+    sink = torch.zeros(1, device=dev)
+    flop = ctypes.c_double(0.0)
+
+    def run(iters):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(lib.clipenc_mfma_stream_probe(dev.index, int(fp8), ops.data_ptr(), sink.data_ptr(), iters, ctypes.byref(flop), st),
+                   "mfma_stream_probe")
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3
+    run(1000)
+    t = run(50_000)
+    iters = int(max(1000, min(2 ** 31 - 1, 50_000 * seconds / t)))
+    with EnvSampler(dev.index) as es:
+        t = run(iters)
+    pw, fq = es.samples["power_w"], es.samples["sclk_mhz"]
+    return {"value": round(flop.value / t / 1e12, 1), "unit": "TFLOP/s", "seconds": round(t, 3),
+            "instruction": "v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales" if fp8 else "v_mfma_f32_16x16x32_bf16",
+            "power_w": round(float(np.median(pw[len(pw) // 3:])), 1) if pw else None,
+            "sclk_mhz": round(float(np.median(fq[len(fq) // 3:])), 1) if fq else None,
+            "what": "all CUs x 8 waves issue only this MFMA on registers of normal-variate operands (no LDS / memory traffic): "
+                    "the rate the board's power management grants the matrix pipes alone on this box"}
+
+
 def dedup_100k(dev):
     """BASELINE.json configs[4]: cosine all-pairs on 100 000 x 768 fp16 embeddings with 1 000 planted pairs, threshold 0.96
     (/root/reference/_2_remove_duplicates.py:63-80), timed with HIP events on the launch stream."""
@@ -537,6 +577,10 @@ def main():
             "kernels_tflops": {k.replace("shape:", ""): round(v[2] / (v[0] * 1e-3) / 1e12, 1) for k, v in prof.items()
                                if v[0] > 0 and v[2] > 1e12},
         }
+        if world == 1 and not args.no_secondary:
+            ceil = mfma_stream_ceiling(dev, "fp8" in DOMINANT)
+            ceil["frac"] = round(achieved / ceil["value"], 4) if ceil["value"] else None     # dominant kernel / that ceiling
+            line["roofline"]["power_capped_mfma_stream"] = ceil
         if world == 1 and not args.no_secondary and not fp8:
             del crops
             torch.cuda.empty_cache()

@@ -64,6 +64,7 @@ SIGNATURES = {
     "clipenc_profile_enable": (c_int, [c_void_p, c_int]),
     "clipenc_profile_kinds": (c_int, []),
     "clipenc_clock_probe": (c_int, [c_int, c_void_p, c_int, c_void_p]),
+    "clipenc_mfma_stream_probe": (c_int, [c_int, c_int, c_void_p, c_void_p, ctypes.c_longlong, ctypes.POINTER(ctypes.c_double), c_void_p]),
     "clipenc_profile_read": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(ctypes.c_double), POINTER(c_longlong),
                                      POINTER(ctypes.c_double), c_int]),
     "clipenc_op_gemm_nt": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

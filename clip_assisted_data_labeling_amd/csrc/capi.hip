@@ -78,7 +78,7 @@ enum { PK_PATCHIFY = 0, PK_GEMM_PATCH, PK_EMBED_LN_PRE, PK_GEMM_QKV, PK_ATTENTIO
        PK_QUANT_LN, PK_QUANT, PK_GEMM8_QKV, PK_GEMM8_FC1, PK_GEMM8_RESID, PK_SUB8_OUT, PK_SUB8_FC2, PK_COUNT };
 static const char* const kProfileNames[PK_COUNT] = {
     "patchify_kernel<float>", "gemm_persist_kernel<1, -1>", "embed_ln_pre_kernel", "gemm_persist_kernel<2, -1>",
-    "attn_stream_kernel<9, 9, 7>", "gemm_persist_kernel<3, -1>", "gemm_persist_kernel<2, 0>", "head_kernel", "fcreg_kernel",
+    "attn_stream_kernel<9, 7>", "gemm_persist_kernel<3, -1>", "gemm_persist_kernel<2, 0>", "head_kernel", "fcreg_kernel",
     "shape:out_proj(gemm_persist_kernel<3, -1>)", "shape:fc2(gemm_persist_kernel<3, -1>)",
     "quant_rows_kernel<unsigned short, true, 2, 4>", "quant_rows_kernel<unsigned short, false, 2, 4>", "gemm_fp8_kernel<0, -1>",
     "gemm_fp8_kernel<2, 0>", "gemm_fp8_kernel<1, -1>", "shape:out_proj(gemm_fp8_kernel<1, -1>)",
@@ -660,6 +660,18 @@ int clipenc_clock_probe(int device, unsigned long long* out2_dev, int spin_us, v
   if (spin_us < 1 || spin_us > 10000) return fail("clock_probe: spin_us %d outside 1..10000", spin_us);
   HIP_TRY(hipSetDevice(device));
   HIP_TRY(ce_clock_probe(out2_dev, spin_us * 100, (hipStream_t)stream));
+  return 0;
+}
+
+int clipenc_mfma_stream_probe(int device, int fp8, const void* operands_dev, float* sink_dev, long long iters, double* flop_out, void* stream) {
+  if (!operands_dev || !sink_dev) return fail("mfma_stream_probe: NULL device pointer");
+  if (iters < 1 || iters > (1ll << 31)) return fail("mfma_stream_probe: iters %lld outside 1..2^31", iters);
+  HIP_TRY(hipSetDevice(device));
+  int n_cu = 0;
+  HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
+  HIP_TRY(ce_mfma_stream(operands_dev, fp8 != 0, sink_dev, iters, n_cu, (hipStream_t)stream));
+  // per wave and iteration: 16 x 16x16x32 (16 384 flop) = 8 x 32x32x64 (131 072 flop) ... both 2 x M x N x K per instruction
+  if (flop_out) *flop_out = (double)n_cu * 8.0 * (double)iters * (fp8 ? 8.0 * 131072.0 : 16.0 * 16384.0);
   return 0;
 }
 

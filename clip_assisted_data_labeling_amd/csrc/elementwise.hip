@@ -279,6 +279,61 @@ hipError_t ce_clock_probe(unsigned long long* out2, int spin_ticks, hipStream_t 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Matrix-pipe stream probe for bench.py: every SIMD of the chip (one workgroup of 8 waves per CU, two per SIMD) issues nothing
+// but the GEMMs' MFMA -- v_mfma_f32_16x16x32_bf16, or v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales -- on operand
+// registers loaded once from the caller's buffer (so the bit patterns, which set the switching power, are the caller's choice).
+// No LDS, no memory traffic: the rate this reaches is what the board's power management grants the matrix pipes alone, the
+// ceiling any GEMM on this box sits under ("power"); bench.py reports it beside roofline.peak.
+template <bool FP8>
+__global__ __launch_bounds__(512, 2) void mfma_stream_kernel(const uint32_t* __restrict__ operands, float* __restrict__ sink, long long iters) {
+  typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint32_t* src = operands + ((size_t)(wave & 3) * 64 + lane) * 32;       // 128 B per lane, 4 wave patterns: 32 KiB
+  float total = 0.f;
+  if constexpr (FP8) {
+    f32x16_t acc[4];
+    i32x8_t a[2], b[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { a[i][e] = (int)src[i * 8 + e]; b[i][e] = (int)src[16 + i * 8 + e]; }
+    for (long long it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        acc[i & 3] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[i & 1], b[(i >> 1) & 1], acc[i & 3], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) total += acc[i][0];
+  } else {
+    f32x4_t acc[8];
+    bf16x8_t a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[i][e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a[i] = *(const bf16x8_t*)(src + i * 4); b[i] = *(const bf16x8_t*)(src + 16 + i * 4); }
+    for (long long it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[(i >> 2) & 3], acc[i & 7], 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) total += acc[i][0];
+  }
+  if (total == 12345.678f) sink[0] = total;                    // keeps the accumulators alive; never true for finite operands of this size
+}
+
+hipError_t ce_mfma_stream(const void* operands_32k, int fp8, float* sink, long long iters, int n_cu, hipStream_t stream) {
+  if (fp8) hipLaunchKernelGGL(mfma_stream_kernel<true>, dim3(n_cu), dim3(512), 0, stream, (const uint32_t*)operands_32k, sink, iters);
+  else hipLaunchKernelGGL(mfma_stream_kernel<false>, dim3(n_cu), dim3(512), 0, stream, (const uint32_t*)operands_32k, sink, iters);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Row statistics of the CLS rows only: out[part][i] = in[part][i * row_stride] (float2 = sum, sum of squares).  Feeds the
 // LayerNorm-folded GEMMs of the LAST transformer block, which run on the class-token rows alone (capi.hip, run_tower).
 __global__ void gather_row_stats_kernel(const float2* __restrict__ in, int in_ld, float2* __restrict__ out, int out_ld, int n,

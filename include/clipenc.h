@@ -224,6 +224,15 @@ int clipenc_profile_read(clipenc_t enc, int kind, const char** name, double* tot
  * (roofline.frac_at_sustained_clock); touches no handle and no product buffer. */
 int clipenc_clock_probe(int device, unsigned long long* out2_dev, int spin_us, void* stream);
 
+/* Matrix-pipe stream for bench.py's power ceiling: all CUs (8 waves each) issue `iters` x 16 v_mfma_f32_16x16x32_bf16
+ * (fp8 = 0) or `iters` x 8 v_mfma_scale_f32_32x32x64_f8f6f4 (fp8 = 1) per wave on operand registers read once from
+ * operands_dev (32 KiB of bf16 / e4m3 bit patterns of the caller's choice); no LDS or memory traffic.  *flop_out = the
+ * floating-point operations the launch performs.  Timed by the caller with events on `stream`: the rate is what the
+ * board's power management grants the matrix pipes alone on this box.  sink_dev: one float, never written for finite
+ * operands.  Touches no handle and no product buffer. */
+int clipenc_mfma_stream_probe(int device, int fp8, const void* operands_dev, float* sink_dev, long long iters,
+                              double* flop_out, void* stream);
+
 /* Operator-level entry points (used by the parity tests to pin each kernel on its own). */
 #define CLIPENC_DT_BF16 0
 #define CLIPENC_DT_F16 1

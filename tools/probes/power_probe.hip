@@ -9,8 +9,9 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
-enum Role { SLEEP = 0, M32 = 1, M16 = 2, EXP = 3, FMA = 4, LDS128 = 5, LDSTR = 6, M32_EXP = 7, MAX3 = 8, M32Z = 9, M16Z = 10, DOT2 = 11, M32_LDS = 12 };
+enum Role { SLEEP = 0, M32 = 1, M16 = 2, EXP = 3, FMA = 4, LDS128 = 5, LDSTR = 6, M32_EXP = 7, MAX3 = 8, M32Z = 9, M16Z = 10, DOT2 = 11, M32_LDS = 12, F8_32 = 13, F8_16 = 14, F8_32Z = 15 };
 
 #define MFMA32(acc, a_, b_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_))
 #define MFMA16(acc, a_, b_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_))
@@ -29,6 +30,12 @@ __global__ __launch_bounds__(512, 2) void power_kernel(const uint32_t* __restric
       const bool z = (ROLE == M32Z || ROLE == M16Z);
       aw[i][e] = z ? 0u : rnd[(lane * 16 + i * 4 + e) & 4095];
       bw[i][e] = z ? 0u : rnd[(lane * 16 + i * 4 + e + 2048) & 4095];
+    }
+  i32x8_t a8[2], b8[2];                      // fp8 operands: rnd[4096 ..] holds e4m3 bytes of normal variates
+  for (int i = 0; i < 2; ++i)
+    for (int e = 0; e < 8; ++e) {
+      a8[i][e] = (ROLE == F8_32Z) ? 0 : (int)rnd[4096 + ((lane * 16 + i * 8 + e) & 4095)];
+      b8[i][e] = (ROLE == F8_32Z) ? 0 : (int)rnd[4096 + ((lane * 16 + i * 8 + e + 1024) & 4095)];
     }
   float x[16]; for (int i = 0; i < 16; ++i) x[i] = -0.01f * (lane + i) - 0.5f;
   const char* lp = lds + (((lane * 16) + wave * 1024) & 65535);
@@ -77,6 +84,14 @@ __global__ __launch_bounds__(512, 2) void power_kernel(const uint32_t* __restric
         asm volatile("v_exp_f32 %0, %1" : "=v"(x[2 * i]) : "v"(x[2 * i]));
         asm volatile("v_exp_f32 %0, %1" : "=v"(x[2 * i + 1]) : "v"(x[2 * i + 1]));
       }
+    } else if constexpr (ROLE == F8_32 || ROLE == F8_32Z) {   // 4 x 32x32x64 (64 cycles each)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        acc[i] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[i & 1], b8[(i >> 1) & 1], acc[i], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+    } else if constexpr (ROLE == F8_16) {                     // 8 x 16x16x128 (32 cycles each)
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        acc4[i & 3] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a8[i & 1], b8[(i >> 1) & 1], acc4[i & 3], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
     } else if constexpr (ROLE == M32_LDS) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(512, 2) void power_kernel(const uint32_t* __restric
 extern "C" int power_probe_run(int role, const void* rnd, void* out, int iters, void* stream) {
   switch (role) {
     LAUNCH(SLEEP) LAUNCH(M32) LAUNCH(M16) LAUNCH(EXP) LAUNCH(FMA) LAUNCH(LDS128) LAUNCH(LDSTR) LAUNCH(M32_EXP) LAUNCH(MAX3) LAUNCH(M32Z) LAUNCH(M16Z)
-    LAUNCH(DOT2) LAUNCH(M32_LDS)
+    LAUNCH(DOT2) LAUNCH(M32_LDS) LAUNCH(F8_32) LAUNCH(F8_16) LAUNCH(F8_32Z)
     default: return -1;
   }
   return (int)hipGetLastError();

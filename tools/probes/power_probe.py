@@ -11,7 +11,8 @@ from bench import EnvSampler  # noqa: E402
 ROLES = [("sleep", 0, 0, ""), ("mfma 32x32x16 bf16", 1, 8, "mfma"), ("mfma 32x32x16 zeros", 9, 8, "mfma"), ("mfma 16x16x32 bf16", 2, 16, "mfma"),
          ("mfma 16x16x32 zeros", 10, 16, "mfma"), ("v_exp_f32", 3, 16, "instr"), ("v_fma_f32", 4, 64, "instr"), ("v_max3_f32", 8, 64, "instr"),
          ("v_dot2c_f32_bf16", 11, 64, "instr"), ("ds_read_b128", 5, 16, "instr"), ("ds_read_b64_tr_b16", 6, 16, "instr"),
-         ("mfma32 + 2 exp", 7, 8, "mfma"), ("mfma32 + ds_read_b128", 12, 8, "mfma")]
+         ("mfma32 + 2 exp", 7, 8, "mfma"), ("mfma32 + ds_read_b128", 12, 8, "mfma"),
+         ("mfma_scale 32x32x64 fp8", 13, 4, "mfma"), ("mfma_scale 32x32x64 zeros", 15, 4, "mfma"), ("mfma_scale 16x16x128 fp8", 14, 8, "mfma")]
 
 
 def main():
@@ -20,12 +21,13 @@ def main():
     f.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev); g.manual_seed(3)
-    rnd = torch.randn(8192, device=dev, generator=g).to(torch.bfloat16).view(torch.int32).contiguous()     # 4096 dwords of bf16 pairs
+    rnd = torch.cat([torch.randn(8192, device=dev, generator=g).to(torch.bfloat16).view(torch.int32),       # 4096 dwords of bf16 pairs
+                     (torch.randn(16384, device=dev, generator=g) * 2).to(torch.float8_e4m3fn).view(torch.int32)]).contiguous()   # + 4096 of e4m3
     out = torch.zeros(256 * 8, device=dev, dtype=torch.int64)
     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     secs = float(os.environ.get("PROBE_SECONDS", "1.5"))
     base_w = None
-    print(f"{'role':28s} {'GHz':>6s} {'W':>7s} {'cyc/instr':>9s} {'G instr/s':>10s} {'nJ/instr (above sleep)':>22s}")
+    print(f"{'role':28s} {'memtime GHz':>11s} {'hwmon MHz':>9s} {'W':>7s} {'cyc/instr':>9s} {'G instr/s':>10s} {'nJ/instr (above sleep)':>22s}")
     for name, role, per_body, kind in ROLES:
         f(role, rnd.data_ptr(), out.data_ptr(), 2000, st); torch.cuda.synchronize()
         t0 = time.perf_counter(); f(role, rnd.data_ptr(), out.data_ptr(), 20000, st); torch.cuda.synchronize()
@@ -39,14 +41,16 @@ def main():
         ghz = cyc / ms / 1e6
         pw = es.samples["power_w"]
         w = float(np.median(pw[len(pw) // 3:])) if pw else float("nan")
+        fq = es.samples["sclk_mhz"]
+        mhz = float(np.median(fq[len(fq) // 3:])) if fq else float("nan")
         if role == 0:
             base_w = w
-            print(f"{name:28s} {ghz:6.3f} {w:7.0f}")
+            print(f"{name:28s} {ghz:11.3f} {mhz:9.0f} {w:7.0f}")
             continue
         n_instr = per_body * iters * 256.0 * 8
         rate = n_instr / (ms * 1e-3)
         nj = (w - base_w) / rate * 1e9
-        print(f"{name:28s} {ghz:6.3f} {w:7.0f} {cyc / (per_body * iters):9.2f} {rate / 1e9:10.1f} {nj:22.2f}")
+        print(f"{name:28s} {ghz:11.3f} {mhz:9.0f} {w:7.0f} {cyc / (per_body * iters):9.2f} {rate / 1e9:10.1f} {nj:22.2f}")
 
 
 if __name__ == "__main__":
