@@ -113,6 +113,80 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const TIN* __restrict__
   }
 }
 
+// The LayerNorm-quantise pass of the fp8 tower (bf16 residual rows of 768 / 1024 / 1280 columns, twice per block: 18 of a 200 ms
+// step with the kernel above, whose three 64-lane reductions per row are six dependent ds_bpermute steps each and whose VALU work
+// per row, ~175 instructions, already costs what the HBM transfer does).  Here a row lives in SIXTEEN lanes (lane i of the
+// group holds the 16-B pieces i, i + 16, ... of the row: every load and store instruction of the wave still covers whole 128-B
+// lines, four rows at a time), so each reduction is four DPP adds inside a DPP row and serves four rows at once: ~100
+// instructions per row, no LDS crossbar.  Same arithmetic as above (two-pass variance, y = (x - mean) * rstd, scale = max|y| /
+// 448); no clamp: |y * (448 / max|y|)| <= 448 (1 + 2^-22), which v_cvt_pk_fp8_f32 rounds to 448.
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {          // all 16 lanes of a DPP row end with the row's sum
+  v += dpp_row<0xB1>(v);                                        // quad_perm [1,0,3,2]
+  v += dpp_row<0x4E>(v);                                        // quad_perm [2,3,0,1]
+  v += dpp_row<0x141>(v);                                       // row_half_mirror
+  v += dpp_row<0x140>(v);                                       // row_mirror
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, dpp_row<0xB1>(v));
+  v = fmaxf(v, dpp_row<0x4E>(v));
+  v = fmaxf(v, dpp_row<0x141>(v));
+  v = fmaxf(v, dpp_row<0x140>(v));
+  return v;
+}
+
+template <int NCH>                                              // K = 128 * NCH
+__global__ __launch_bounds__(256) void quant_ln16_kernel(const bf16_t* __restrict__ in, size_t ld_in, uint8_t* __restrict__ out,
+                                                         size_t ld_out, float* __restrict__ scale, int n_rows, float eps) {
+  constexpr int K = NCH * 128;
+  const int lane = threadIdx.x & 63, sub = lane & 15, rr = lane >> 4;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+  for (int row0 = wave * 4; row0 < n_rows; row0 += n_waves * 4) {
+    const int row = min(row0 + rr, n_rows - 1);
+    const bf16_t* src = in + (size_t)row * ld_in + sub * 8;
+    float v[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) load8<bf16_t>(src + c * 128, v[c]);
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[c][j];
+    const float mean = row16_sum(s) * (1.0f / (float)K);
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[c][j] -= mean; ss += v[c][j] * v[c][j]; }
+    const float rstd = rsqrtf(row16_sum(ss) * (1.0f / (float)K) + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[c][j] *= rstd; amax = fmaxf(amax, fabsf(v[c][j])); }
+    amax = row16_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = amax > 0.f ? 448.0f / amax : 0.f;
+    if (row0 + rr < n_rows) {
+      uint8_t* dst = out + (size_t)row * ld_out + sub * 8;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][0] * inv, v[c][1] * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][2] * inv, v[c][3] * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][4] * inv, v[c][5] * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][6] * inv, v[c][7] * inv, w1, true);
+        *(uint2*)(dst + c * 128) = uint2{(uint32_t)w0, (uint32_t)w1};
+      }
+      if (sub == 0) scale[row] = sc;
+    }
+  }
+}
+
 // Static (data-free) output scale of a LayerNorm-fed linear layer, from the Cauchy-Schwarz bound
 //   |LN(x) . w'_n + b'_n| <= sqrt(K) * ||w'_n||_2 + |b'_n|      (||LN(x) without affine||_2 <= sqrt(K))
 // widened by 1.07 for the e4m3 rounding of both operands and by a 1.2 margin:  s[n] = bound / 448 * 1.2, inv_s = 1/s.
@@ -172,6 +246,17 @@ hipError_t ce_scale_cols(const void* W_bf16, const float* s, float* out_f32, int
 hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out8, size_t ld_out, float* scale, int n_rows,
                              int K, int ln, float eps, hipStream_t stream) {
   if (n_rows < 1 || K < 8 || K % 8 != 0 || K > QMAXC * 512 || ld_in < (size_t)K || ld_out < (size_t)K) return hipErrorInvalidValue;
+  if (!in_f32 && ln && K % 128 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in | (uintptr_t)out8) % 16 == 0) {
+    // the tower's LayerNorm-quantise pass: 16 lanes per row (quant_ln16_kernel)
+    const int waves = (n_rows + 3) / 4;
+    dim3 grid((unsigned)std::min((waves + 3) / 4, 16384)), block(256);
+#define Q16(NCH_)                                                                                                                  \
+    case NCH_: hipLaunchKernelGGL((quant_ln16_kernel<NCH_>), grid, block, 0, stream, (const bf16_t*)in, ld_in, (uint8_t*)out8,     \
+                                  ld_out, scale, n_rows, eps);                                                                     \
+      return hipGetLastError();
+    switch (K / 128) { Q16(6) Q16(8) Q16(10) default: break; }
+#undef Q16
+  }
   const int chunks = (K + 511) / 512;
   // rows per wave step: as many as keep the row registers (CH * 8 * NR floats) around 64
 #define QLAUNCH(T, LNV, CH, NR)                                                             \
