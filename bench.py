@@ -425,6 +425,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="crops per pass through the layer chain (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[4] dedup timing appended to the line")
+    ap.add_argument("--no-power-ceiling", action="store_true",
+                    help="skip roofline.power_capped_mfma_stream (0.35 s of pure MFMA; tools/profile_round.sh leaves it out of the rocprofv3 passes)")
     ap.add_argument("--job-images", type=int, default=0,
                     help="BASELINE.json configs[3]: run a whole N-image job (sharded over the ranks, crops generated on the device "
                          "per batch, one gather at the end) instead of the resident-batch step loop; use with --dtype fp8")
@@ -577,7 +579,7 @@ def main():
             "kernels_tflops": {k.replace("shape:", ""): round(v[2] / (v[0] * 1e-3) / 1e12, 1) for k, v in prof.items()
                                if v[0] > 0 and v[2] > 1e12},
         }
-        if world == 1 and not args.no_secondary:
+        if world == 1 and not args.no_secondary and not args.no_power_ceiling:
             ceil = mfma_stream_ceiling(dev, "fp8" in DOMINANT)
             ceil["frac"] = round(achieved / ceil["value"], 4) if ceil["value"] else None     # dominant kernel / that ceiling
             line["roofline"]["power_capped_mfma_stream"] = ceil
