@@ -80,11 +80,11 @@ static const char* const kProfileNames[PK_COUNT] = {
     "patchify_kernel<float>", "gemm_persist_kernel<1, -1>", "embed_ln_pre_kernel", "gemm_persist_kernel<2, -1>",
     "attn_stream_kernel<9, 7>", "gemm_persist_kernel<3, -1>", "gemm_persist_kernel<2, 0>", "head_kernel", "fcreg_kernel",
     "shape:out_proj(gemm_persist_kernel<3, -1>)", "shape:fc2(gemm_persist_kernel<3, -1>)",
-    "quant_rows_kernel<unsigned short, true, 2, 4>", "quant_rows_kernel<unsigned short, false, 2, 4>", "gemm_fp8_kernel<0, -1>",
+    "quant_ln16_kernel<8>", "quant_rows_kernel<unsigned short, false, 2, 4>", "gemm_fp8_kernel<0, -1>",
     "gemm_fp8_kernel<2, 0>", "gemm_fp8_kernel<1, -1>", "shape:out_proj(gemm_fp8_kernel<1, -1>)",
     "shape:fc2(gemm_fp8_kernel<1, -1>)"};
 // (template arguments: <EPI, ACT>; FC1 is <2, 0> with QuickGELU and <2, 1> with erf-GELU; the attention name is the
-//  ViT-L/14 instantiation, other token counts use attn_kernel<NKT> / attn_long_kernel<7>)
+//  ViT-L/14 instantiation, other token counts use attn_kernel<NKT> / attn_long_kernel<7>; quant_ln16_kernel<width / 128>)
 
 struct ProfRec { int kind, sub; hipEvent_t a, b; double flops; };
 
