@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("CLIPENC_LIB_PATH", os.path.join(ROOT, "clip_assisted_data_labeling_amd", "libclipenc_hip_diag.so"))
 from clip_assisted_data_labeling_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda", 0); st = _lib.current_stream_ptr(dev)
-M = 131584
+M = int(os.environ.get("GEMM_M", "526336"))
 for (N, K, kind) in ((1024, 1024, "random"), (1024, 4096, "random"), (4096, 1024, "random"), (1024, 4096, "zeros")):
     if kind == "random":
         a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = torch.randn(N, K, device=dev).to(torch.bfloat16)
