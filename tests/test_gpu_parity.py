@@ -414,3 +414,32 @@ def test_dedup_larger_set_vs_oracle(gpu):
     assert c == len(got) and 20 < len(gold) < planted
     for (i, j) in gold ^ got:                                  # only fp16-ulp ties at the threshold may differ
         assert abs(s32[i, j] - thr) < 1e-3, (i, j, s32[i, j])
+
+
+# ------------------------------------------------------------------------------------- measurement support of bench.py
+def test_measurement_probes_contract(gpu):
+    """clipenc_clock_probe / clipenc_mfma_stream_probe: the two handle-free entries bench.py uses for `env.inkernel_clock_mhz`
+    and `roofline.power_capped_mfma_stream` -- argument checks, the flop count they report, and a plausible clock."""
+    import ctypes
+    lib = _lib.load()
+    st = _stream(gpu)
+    out2 = torch.zeros(2, dtype=torch.int64, device=gpu)
+    _lib.check(lib.clipenc_clock_probe(gpu.index or 0, out2.data_ptr(), 50, st), "clock_probe")
+    torch.cuda.synchronize()
+    cyc, ticks = (int(v) for v in out2.cpu())
+    assert ticks >= 5000 and 500.0 < 100.0 * cyc / ticks < 3000.0          # >= 50 us of 100 MHz ticks; a shader clock in MHz
+    assert lib.clipenc_clock_probe(gpu.index or 0, None, 50, st) != 0
+    assert lib.clipenc_clock_probe(gpu.index or 0, out2.data_ptr(), 0, st) != 0
+    ops = torch.randn(16384, device=gpu).to(torch.bfloat16)                 # 32 KiB of operand bit patterns
+    sink = torch.zeros(1, device=gpu)
+    flop = ctypes.c_double(0.0)
+    n_cu = torch.cuda.get_device_properties(gpu).multi_processor_count
+    for fp8, per_wave in ((0, 16 * 2 * 16 * 16 * 32), (1, 8 * 2 * 32 * 32 * 64)):
+        _lib.check(lib.clipenc_mfma_stream_probe(gpu.index or 0, fp8, ops.data_ptr(), sink.data_ptr(), 100, ctypes.byref(flop), st),
+                   "mfma_stream_probe")
+        torch.cuda.synchronize()
+        assert flop.value == float(n_cu) * 8 * 100 * per_wave
+    assert sink.item() == 0.0                                               # never written for finite operands
+    assert lib.clipenc_mfma_stream_probe(gpu.index or 0, 0, None, sink.data_ptr(), 100, ctypes.byref(flop), st) != 0
+    assert lib.clipenc_mfma_stream_probe(gpu.index or 0, 0, ops.data_ptr(), sink.data_ptr(), 0, ctypes.byref(flop), st) != 0
+    assert b"mfma_stream_probe" in lib.clipenc_last_error()
