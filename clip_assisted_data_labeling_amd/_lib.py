@@ -57,6 +57,7 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p]),
     "dedup_find_pairs": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                  c_ulonglong, c_void_p, c_void_p]),
+    "dedup_tile_order": (c_int, [c_int, c_int, POINTER(ctypes.c_uint), c_long]),
     "preproc_create": (c_int, [c_int, POINTER(c_void_p)]),
     "preproc_destroy": (c_int, [c_void_p]),
     "preproc_crops_u8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, POINTER(c_int), c_int, c_void_p, c_void_p]),

@@ -710,7 +710,11 @@ hipError_t launch_attn_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n
   int grid = n_tasks < n_cu ? n_tasks : n_cu;
   while ((n_tasks + grid - 1) / grid > 496) grid *= 2;      // per-workgroup task counters live in 2 KiB of LDS
   const float scale_log2e = 0.125f * 1.44269504088896340736f;
+#ifdef CLIPENC_DIAG                         // timing experiments of tools/attn_ab.py (results invalid): 1 = loader alone, 2 = compute alone
   static const int dbg = [] { const char* e = getenv("CLIPENC_ATTN_DBG"); return e ? atoi(e) : 0; }();
+#else
+  constexpr int dbg = 0;
+#endif
   hipLaunchKernelGGL((attn_stream_kernel<NKT, NCW>), dim3(grid), dim3((NCW + 1) * 64), lds, stream, qkv, out, n_tok, width, heads,
                      scale_log2e, n_tasks, dbg, out_inv, q_blocks);
   return hipGetLastError();
@@ -739,7 +743,11 @@ hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int 
   const int nkt = (n_tok + 31) / 32;
   const bf16_t* q = (const bf16_t*)qkv;
   bf16_t* o = (bf16_t*)out;
+#ifdef CLIPENC_DIAG                         // developer A/B: 0 = one workgroup per (crop, head) for every shape
   static const int impl = [] { const char* e = getenv("CLIPENC_ATTN_IMPL"); return e ? atoi(e) : 2; }();
+#else
+  constexpr int impl = 2;
+#endif
   if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8, 7>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
   if (impl == 2 && nkt == 9 && n_crops * heads >= 64) return launch_attn_stream<9, 7>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
   switch (nkt) {                 // NKT must equal ceil(n_tok/32): only the last key tile is masked

@@ -142,7 +142,7 @@ struct clipenc_s {
   float *ln_post_w = nullptr, *ln_post_b = nullptr, *proj = nullptr;
   std::vector<LayerDev> layers;
   int precision = CLIPENC_PREC_BF16;
-  bool cls_only_last = true;                             // last block on the class-token rows only (bf16 path; CLIPENC_FULL_LAST_BLOCK=1 disables)
+  bool cls_only_last = true;                             // last block on the class-token rows only (the diagnostic build reads CLIPENC_FULL_LAST_BLOCK=1 to disable it)
   DevBuf weights8;                                       // fp8 copies of the block weights (made by clipenc_set_precision)
   std::vector<LayerDev8> layers8;
   uint8_t* a8 = nullptr;                                 // workspace: quantised GEMM operand [T][width] (the e4m3 MLP hidden
@@ -200,7 +200,13 @@ int ensure_workspace(clipenc_s* e) {
   const bool f8 = e->precision == CLIPENC_PREC_FP8;
   const size_t o_a8 = f8 ? take(T * (size_t)g.width) : 0, o_sa8 = f8 ? take(T * 4) : 0;
   HIP_TRY(hipSetDevice(e->device));
-  HIP_TRY(e->ws.alloc(off));
+  // allocate the new slab FIRST and swap it in on success: on failure the handle keeps its old, still valid workspace
+  // (and the chunk / precision it was sized for), so no pointer ever refers to freed memory
+  DevBuf fresh;
+  if (hipError_t err = fresh.alloc(off); err != hipSuccess)
+    return fail("workspace of %zu bytes for a chunk of %d crops: %s", off, c, hipGetErrorString(err));
+  e->ws.release();
+  e->ws = fresh;
   char* b = (char*)e->ws.p;
   e->a_patch = (bf16_t*)(b + o_ap); e->pe = (bf16_t*)(b + o_pe); e->x = (bf16_t*)(b + o_x);
   e->qkv = (bf16_t*)(b + o_qkv); e->attn = (bf16_t*)(b + o_at); e->hid = (bf16_t*)(b + o_h);
@@ -444,7 +450,9 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
 
   clipenc_s* e = new clipenc_s();
   e->cfg = g; e->device = device; e->tokens = tokens;
-  e->cls_only_last = getenv("CLIPENC_FULL_LAST_BLOCK") == nullptr;      // developer A/B switch
+#ifdef CLIPENC_DIAG                         // diagnostic library only: run the last block on every token (tests/test_gpu_cls_only.py)
+  e->cls_only_last = getenv("CLIPENC_FULL_LAST_BLOCK") == nullptr;
+#endif
   const int kreal = 3 * g.patch * g.patch;
   e->kpad = (int)align_up(kreal, 128);
   const int D = g.width, M = g.mlp_dim, L = g.layers, E = g.embed_dim;
@@ -600,8 +608,10 @@ int clipenc_set_precision(clipenc_t e, int precision) {
     HIP_TRY(hipStreamSynchronize(nullptr));
     e->layers8.swap(l8);
   }
-  e->precision = precision;
-  return ensure_workspace(e);                              // the fp8 operand buffers belong to the workspace
+  const int old_precision = e->precision;
+  e->precision = precision;                                // (ensure_workspace sizes for e->precision)
+  if (int rc = ensure_workspace(e)) { e->precision = old_precision; return rc; }   // the fp8 operand buffers belong to the workspace
+  return 0;
 }
 
 int clipenc_set_chunk(clipenc_t e, int chunk_crops) {
@@ -821,6 +831,14 @@ int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int
   const int ld = (d + 127) / 128 * 128;
   HIP_TRY(ce_dedup_normalize_f16(emb_f16_dev, ehat_ws_dev, n, d, ld, st));
   HIP_TRY(ce_dedup_pairs(ehat_ws_dev, n, d, ld, threshold, fp16_compare, pairs_dev, vals_dev, capacity, count_dev, st));
+  return 0;
+}
+
+int dedup_tile_order(int tiles_per_side, int grid, unsigned* order_out, long capacity) {
+  if (tiles_per_side < 1 || tiles_per_side > 0xffff || grid < 1 || !order_out) return fail("dedup_tile_order: bad argument");
+  const std::vector<unsigned> order = tri_tile_order(tiles_per_side, grid);
+  if ((long)order.size() > capacity) return fail("dedup_tile_order: capacity %ld < %zu tiles", capacity, order.size());
+  memcpy(order_out, order.data(), order.size() * sizeof(unsigned));
   return 0;
 }
 

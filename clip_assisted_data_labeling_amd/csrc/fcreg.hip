@@ -200,6 +200,9 @@ __global__ __launch_bounds__(256) void fcreg_mfma_kernel(const FcRegParams p) {
       // follows -- i.e. BEFORE the stage's MFMAs instead of behind them, which serialised load and compute (MFMA-busy 0.60).
       // The wait is hand-placed in front of the stage-end barrier below.
       const unsigned lds_dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * stage_bytes + q * 1024));   // wave-uniform, provably
+      // (M0: the AMDGPU backend keeps m0 RESERVED -- it never holds a value of the register allocator's, and a "m0" clobber is
+      //  rejected with -Winline-asm "reserved register"; the compiler's own M0 users (LDS-DMA builtins, movrel) re-initialise it
+      //  in front of each use, and this translation unit has none: `tools/kernel_resources.sh fcreg.hip` counts the M0 writes in the ISA)
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(lds_dst) : "memory");
     }
   };

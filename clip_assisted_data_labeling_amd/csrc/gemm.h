@@ -27,6 +27,7 @@ struct GemmParams {
   float* vals;                   // [cap]
   unsigned long long cap;
   unsigned long long* count;
+  const unsigned* tile_list;     // [tt (tt + 1) / 2] tm | tn << 16: execution order of the upper-triangular tiles (set by ce_gemm_tri_persist)
   // fp8 path (gemm_fp8.hip): out = acc * scale_a[m] * scale_w[n] + bias[n]
   const float* scale_a;          // [M] per-token activation scale (NULL: 1)
   const float* scale_w;          // [N] per-output-channel weight scale
@@ -40,3 +41,5 @@ hipError_t ce_gemm_nt(const GemmParams& p, int dtype, int epi, hipStream_t strea
 hipError_t ce_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);           // fp8 e4m3 operands; EPI_STORE_BF16 / EPI_RESID / EPI_STORE_FP8
 hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream);   // bf16; EPI_STORE_BF16 / LNFOLD / RESID
 hipError_t ce_gemm_tri_persist(const GemmParams& p, hipStream_t stream);            // f16 E.E^T, upper triangle, EPI_THRESH (gemm_tri.hip)
+#include <vector>
+std::vector<unsigned> tri_tile_order(int tt, int grid);                            // gemm_tri.hip: execution order of the triangular tile list

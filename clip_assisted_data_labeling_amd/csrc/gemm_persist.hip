@@ -75,13 +75,14 @@ template <> struct OperandOf<EPI_THRESH> { typedef f16x8_t frag; };
 __device__ __forceinline__ f32x4_t mfma16(bf16x8_t a, bf16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4_t mfma16(f16x8_t a, f16x8_t b, f32x4_t c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
-// upper-triangular tile list of a TT x TT tile grid, row-major: row tm holds tiles tn = tm .. TT-1 (EPI_THRESH).  A workgroup
-// walks the list in steps of the grid size; the position (row tm, offset off in the row) is advanced with scalar integer
-// arithmetic only (a closed form needs a double-precision square root per tile: ~30 VALU instructions whose spilled constants
-// came back behind a vmcnt(0), i.e. a drain of the DMA pipeline at every tile boundary).
-__device__ __forceinline__ void tri_advance(int& tm, int& off, int step, int TT) {
-  off += step;
-  while (tm < TT && off >= TT - tm) { off -= TT - tm; ++tm; }
+// Upper-triangular tile list of a TT x TT tile grid (EPI_THRESH): the ORDER is made on the host (tri_tile_order below) and read
+// here with one scalar load per tile -- entry i = tm | tn << 16 is the tile that workgroup i % G runs in its round i / G.
+// (Scalar memory counts in lgkmcnt, not in the vmcnt that the DMA pipeline's counted waits rely on.)
+__device__ __forceinline__ TileId tri_tile(const unsigned* list, int i) {
+  unsigned v;
+  asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(list), "s"(i * 4) : "memory");
+  const int tm = (int)(v & 0xffffu), tn = (int)(v >> 16);
+  return TileId{tm * BM, tn * BN, tn};
 }
 
 __device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n, bool deep_narrow) {
@@ -111,8 +112,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
   const int nwg = EPI == EPI_THRESH ? tiles_n * (tiles_n + 1) / 2 : tiles_m * tiles_n;
   const bool deep_narrow = tiles_n <= 4 && p.K >= 2048;
-  int tri_m = 0, tri_off = 0;                 // EPI_THRESH: position of the NEXT tile to decode in the triangular list
-#define DECODE_TILE(i_) (EPI == EPI_THRESH ? TileId{tri_m * BM, (tri_m + tri_off) * BN, tri_m + tri_off} : decode_tile((i_), tiles_m, tiles_n, deep_narrow))
+#define DECODE_TILE(i_) (EPI == EPI_THRESH ? tri_tile(p.tile_list, (i_)) : decode_tile((i_), tiles_m, tiles_n, deep_narrow))
   const int G = gridDim.x;
   const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
   const int kend = p.K * 2;                  // bytes along K; one stage = 128 B; K % 128 == 0 (stages come in pairs)
@@ -135,7 +135,6 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 #define TW_ADDR(nt) (tr + tw_base + ((((nt) * 2 + (qd >> 1)) ^ tw_sw) << 4))
 
   int idx = blockIdx.x;
-  if (EPI == EPI_THRESH) tri_advance(tri_m, tri_off, idx, tiles_n);
   TileId cur = DECODE_TILE(idx);
   const char* Ablk = (const char*)p.A + (size_t)cur.m0 * lda_b;
   const char* Wblk = (const char*)p.W + (size_t)cur.n0 * ldw_b;
@@ -276,7 +275,6 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
     if (has_next) {
-      if (EPI == EPI_THRESH) tri_advance(tri_m, tri_off, G, tiles_n);
       nxt = DECODE_TILE(nidx);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
@@ -519,6 +517,16 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   }
 }
 
+// grid of the persistent launch: one workgroup per CU, a multiple of 8 so that tile index mod 8 == workgroup index mod 8
+// (workgroups b and b + 8 share an XCD under the round-robin dispatch: speed only, never correctness)
+int persist_grid(int n_cu, int tiles) {
+  int grid = n_cu > 0 ? n_cu : 256;
+  grid -= grid % 8;
+  if (grid < 8) grid = 8;
+  if (tiles < grid) grid = tiles;
+  return grid;
+}
+
 template <int EPI, int ACT>
 hipError_t launch_persist(const GemmParams& p, hipStream_t stream) {
   static DeviceKernelSetup setup;             // per device: LDS opt-in + CU count (common.h)
@@ -526,10 +534,7 @@ hipError_t launch_persist(const GemmParams& p, hipStream_t stream) {
   if (hipError_t e = setup.ensure((const void*)gemm_persist_kernel<EPI, ACT>, LDS_BYTES, &n_cu); e != hipSuccess) return e;
   int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
   if (EPI == EPI_THRESH) { const int tt = p.N / BN; tiles = tt * (tt + 1) / 2; }
-  int grid = n_cu > 0 ? n_cu : 256;
-  grid -= grid % 8;                           // keep tile index mod 8 == workgroup index mod 8 (XCD affinity)
-  if (grid < 8) grid = 8;
-  if (tiles < grid) grid = tiles;
+  const int grid = persist_grid(n_cu, tiles);
   hipLaunchKernelGGL((gemm_persist_kernel<EPI, ACT>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
   return hipGetLastError();
 }
@@ -540,7 +545,89 @@ hipError_t launch_persist(const GemmParams& p, hipStream_t stream) {
 // gemm_tri.hip: the same kernel template instantiated in a translation unit of its own for the near-duplicate search (f16
 // operands, upper-triangular tile list, threshold + append epilogue), so that it cannot perturb the code generation of the
 // encoder's instantiations (guide rule 19).
-hipError_t ce_gemm_tri_persist(const GemmParams& p, hipStream_t stream) { return launch_persist<EPI_THRESH, -1>(p, stream); }
+#include <mutex>
+#include <vector>
+
+// Order of the upper-triangular tile list (TT x TT tiles, tn >= tm) for a grid of G workgroups, G / 8 per XCD.
+// Entry i = the tile of workgroup i % G in its round i / G.  What the order is for: the G / 8 tiles that are resident on ONE
+// XCD at a time should touch as few 256-row operand panels as possible, because every panel a tile needs and its neighbours
+// do not is a read that misses the XCD's 4 MiB L2.  A row-major walk (round 2) gave an XCD 32 tiles of one tile row:
+// 1 shared A panel + 32 different W panels = 33 panels per 32 tiles (rocprofv3: 35 GB of L2-miss reads per launch for a
+// 0.15 GB operand).  Here the grid is cut into super-blocks of 8 (tm) x 4 (tn) tiles = 12 panels per 32 tiles; the FULL
+// super-blocks come first, super-row-major, one super-block per XCD and round, so the 8 XCDs of a round hold 8 neighbouring
+// super-blocks of one super-row (the same 8 A panels, hot in the Infinity Cache) and an XCD's consecutive rounds stay in that
+// super-row (its A panels may still be in its L2); the tiles of the partial super-blocks along the diagonal and the grid
+// edge follow, compacted.  Every valid tile appears exactly once; the rounds are full except the last.
+std::vector<unsigned> tri_tile_order(int TT, int G) {
+  const long long total = (long long)TT * (TT + 1) / 2;
+  std::vector<unsigned> seq;
+  seq.reserve((size_t)total);
+  constexpr int SBM = 8, SBN = 4;
+  const int SR = (TT + SBM - 1) / SBM, SC = (TT + SBN - 1) / SBN;
+  auto valid = [&](int tm, int tn) { return tm < TT && tn < TT && tn >= tm; };
+  for (int pass = 0; pass < 2; ++pass)          // pass 0: full super-blocks, pass 1: the tiles of the partial ones
+    for (int R = 0; R < SR; ++R)
+      for (int C = 0; C < SC; ++C) {
+        if (C * SBN + SBN - 1 < R * SBM) continue;                           // wholly below the diagonal
+        const bool full = valid(R * SBM + SBM - 1, C * SBN) && C * SBN + SBN - 1 < TT;
+        if (full != (pass == 0)) continue;
+        for (int j = 0; j < SBN; ++j)
+          for (int i = 0; i < SBM; ++i)
+            if (valid(R * SBM + i, C * SBN + j)) seq.push_back((unsigned)(R * SBM + i) | ((unsigned)(C * SBN + j) << 16));
+      }
+  std::vector<unsigned> order(seq.size());
+  const int lpx = G / 8;                          // workgroups per XCD
+  const size_t grouped = (G >= 8 && G % 8 == 0) ? seq.size() / (size_t)G * (size_t)G : 0;   // whole rounds
+  for (size_t e = 0; e < seq.size(); ++e) {
+    size_t idx = e;
+    if (e < grouped) {                            // element e of a round: XCD slot q takes lpx consecutive tiles
+      const size_t round = e / (size_t)G, w = e % (size_t)G, q = w / (size_t)lpx, l = w % (size_t)lpx;
+      idx = round * (size_t)G + l * 8 + q;
+    }
+    order[idx] = seq[e];
+  }
+  return order;
+}
+
+namespace {
+struct TriOrderEntry { int device, tt, grid; unsigned* dev_list; };
+std::mutex g_tri_mu;
+std::vector<TriOrderEntry> g_tri_cache;         // a handful of (device, problem size) pairs per process; oldest evicted
+}  // namespace
+
+hipError_t ce_gemm_tri_persist(const GemmParams& p_in, hipStream_t stream) {
+  GemmParams p = p_in;
+  const int tt = p.N / BN;
+  if (tt > 0xffff) return hipErrorInvalidValue;                              // tile coordinates are packed 16 + 16 bits
+  static DeviceKernelSetup setup;
+  int n_cu = 0, device = 0;
+  if (hipError_t e = setup.ensure((const void*)gemm_persist_kernel<EPI_THRESH, -1>, LDS_BYTES, &n_cu); e != hipSuccess) return e;
+  if (hipError_t e = hipGetDevice(&device); e != hipSuccess) return e;
+  const int grid = persist_grid(n_cu, tt * (tt + 1) / 2);
+  {
+    std::lock_guard<std::mutex> lock(g_tri_mu);
+    for (const auto& c : g_tri_cache)
+      if (c.device == device && c.tt == tt && c.grid == grid) p.tile_list = c.dev_list;
+    if (!p.tile_list) {
+      const std::vector<unsigned> order = tri_tile_order(tt, grid);
+      unsigned* d = nullptr;
+      if (hipError_t e = hipMalloc((void**)&d, order.size() * sizeof(unsigned)); e != hipSuccess) return e;
+      // (first use of a problem size only; a blocking copy, so the list is complete before any launch can read it)
+      if (hipError_t e = hipMemcpy(d, order.data(), order.size() * sizeof(unsigned), hipMemcpyHostToDevice); e != hipSuccess) {
+        (void)hipFree(d);
+        return e;
+      }
+      if (g_tri_cache.size() >= 8) {              // the evicted list may still be read by a launch in flight: wait for the device
+        (void)hipDeviceSynchronize();
+        (void)hipFree(g_tri_cache.front().dev_list);
+        g_tri_cache.erase(g_tri_cache.begin());
+      }
+      g_tri_cache.push_back(TriOrderEntry{device, tt, grid, d});
+      p.tile_list = d;
+    }
+  }
+  return launch_persist<EPI_THRESH, -1>(p, stream);
+}
 #else
 hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream) {
   switch (epi) {

@@ -10,6 +10,7 @@ from __future__ import annotations
 import dataclasses
 import math
 import os
+import re
 from typing import Dict, Optional
 
 import torch
@@ -220,23 +221,46 @@ def _read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
     return {k: v for k, v in raw.items() if isinstance(v, torch.Tensor)}
 
 
+# pretrained tag -> what the hub repository of that tag is called (lower case, '_' -> '-').  open_clip resolves a tag to
+# exactly one repository [upstream: open_clip pretrained.py]; a snapshot is accepted only when its repository name carries
+# BOTH the architecture and one of the tag's names, so that e.g. a LAION ViT-L-14 snapshot is never loaded for 'openai'.
+_TAG_ALIASES = {"openai": ("openai",), "laion2b_s32b_b82k": ("laion2b-s32b-b82k", "laion2b"),
+                "laion2b_s34b_b79k": ("laion2b-s34b-b79k", "laion2b"), "laion400m_e31": ("laion400m-e31", "laion400m"),
+                "laion400m_e32": ("laion400m-e32", "laion400m"), "datacomp_xl_s13b_b90k": ("datacomp-xl-s13b-b90k", "datacomp"),
+                "dfn2b": ("dfn2b",)}
+
+
+def _has_component(name: str, part: str) -> bool:
+    """`part` occurs in `name` as a whole component: not glued to more letters/digits on either side and not followed by
+    '-<digit>' ('vit-l-14' must not accept a 'vit-l-14-336' repository)."""
+    for m in re.finditer(re.escape(part), name):
+        before = name[m.start() - 1] if m.start() > 0 else "-"
+        if not before.isalnum() and not re.match(r"[a-z0-9]|-\d", name[m.end():]):
+            return True
+    return False
+
+
 def _hub_snapshots(cache_dir: str, arch: str, pretrained: str):
     """Checkpoint files inside a Hugging Face hub cache tree (`models--<org>--<repo>/snapshots/<rev>/<file>`), which is
-    what open_clip leaves in `cache_dir` for hf-hub hosted tags; best name match first."""
+    what open_clip leaves in `cache_dir` for hf-hub hosted tags.  Only repositories whose name holds the architecture
+    AND the pretrained tag qualify; the longest tag match comes first."""
     import glob
     found = []
-    arch_l, tag_l = arch.lower(), pretrained.lower().replace("_", "-")
+    arch_names = [arch.lower()]
+    if arch in _TIMM_ARCH:
+        arch_names.append(_TIMM_ARCH[arch].replace("_", "-"))
+    tag_l = pretrained.lower().replace("_", "-")
+    tag_names = tuple(dict.fromkeys((tag_l,) + _TAG_ALIASES.get(pretrained.lower(), ())))
     for repo in sorted(glob.glob(os.path.join(cache_dir, "models--*"))):
         name = os.path.basename(repo).lower().replace("_", "-")
-        score = 0
-        if arch_l in name or _TIMM_ARCH.get(arch, "~").replace("_", "-") in name:
-            score += 2
-        if tag_l and (tag_l in name or name.endswith("." + tag_l)):
-            score += 1
+        arch_hit = any(_has_component(name, a) for a in arch_names)
+        tag_hit = max((len(t) for t in tag_names if t and t in name), default=0)
+        if not (arch_hit and tag_hit):
+            continue
         for fname in _HUB_FILES:
             hits = sorted(glob.glob(os.path.join(repo, "snapshots", "*", fname)))
             if hits:
-                found.append((-score, hits[-1]))
+                found.append((-tag_hit, hits[-1]))
                 break
     return [p for _, p in sorted(found)]
 
@@ -248,11 +272,12 @@ def load_weights(model_name: str, model_path: Optional[str]) -> Dict[str, torch.
     * pretrained tag 'seed<N>'  -> seeded synthetic weights (bench / parity);
     * `model_path` is a file     -> that file;
     * `model_path` is a directory, searched in this order:
-        1. what open_clip's own download leaves there for the `openai` tag: `ViT-L-14.pt`, `ViT-L-14-336px.pt`,
+        1. `<arch>-<pretrained>.{pt,pth,bin,safetensors}` / `<arch>_<pretrained>.*` (a hand-placed file: the exact name);
+        2. what open_clip's own download leaves there for the `openai` tag: `ViT-L-14.pt`, `ViT-L-14-336px.pt`,
            `ViT-B-32.pt`, `ViT-B-16.pt` (TorchScript archives, fp16);
-        2. a Hugging Face hub cache tree `models--*/snapshots/*/open_clip_model.safetensors|open_clip_pytorch_model.bin`
-           (hf-hub hosted tags, and `openai` in newer open_clip releases);
-        3. `<arch>-<pretrained>.{pt,pth,bin,safetensors}` / `<arch>_<pretrained>.*` (a hand-placed file).
+        3. a Hugging Face hub cache tree `models--*/snapshots/*/open_clip_model.safetensors|open_clip_pytorch_model.bin`
+           (hf-hub hosted tags, and `openai` in newer open_clip releases) -- only repositories whose name carries both
+           the architecture and the pretrained tag: open_clip resolves exactly the named tag, and so does this.
       Files may hold an OpenAI / open_clip state dict (with or without the `visual.` prefix), a `transformers`
       CLIPVisionModelWithProjection dict, in any float dtype (fp16 archives are up-cast).
     No download is attempted: a missing file raises FileNotFoundError.
@@ -265,12 +290,12 @@ def load_weights(model_name: str, model_path: Optional[str]) -> Dict[str, torch.
     if model_path and os.path.isfile(model_path):
         candidates.append(model_path)
     elif model_path:
+        for ext in ("pt", "pth", "bin", "safetensors"):       # the exact, hand-placed name wins over every search
+            candidates.append(os.path.join(model_path, f"{arch}-{pretrained}.{ext}"))
+            candidates.append(os.path.join(model_path, f"{arch}_{pretrained}.{ext}"))
         if pretrained == "openai" and arch in _OPENAI_JIT_NAMES:
             candidates.append(os.path.join(model_path, _OPENAI_JIT_NAMES[arch]))
         candidates += _hub_snapshots(model_path, arch, pretrained)
-        for ext in ("pt", "pth", "bin", "safetensors"):
-            candidates.append(os.path.join(model_path, f"{arch}-{pretrained}.{ext}"))
-            candidates.append(os.path.join(model_path, f"{arch}_{pretrained}.{ext}"))
     errors = []
     for path in candidates:
         if not os.path.isfile(path):

@@ -150,6 +150,13 @@ int fctrain_get_params(fctrain_t t, int layer, float* W_host, float* b_host);
 int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int fp16_compare,
                      void* ehat_ws_dev, long long* pairs_dev, float* vals_dev, unsigned long long capacity,
                      unsigned long long* count_dev, void* stream);
+/* Host-only view of HOW dedup_find_pairs walks the similarity matrix (no device work; the CPU tests check it): the
+ * execution order of the 256 x 256 tiles of the upper triangle (tn >= tm) of a tiles_per_side x tiles_per_side tile grid for a
+ * launch of `grid` persistent workgroups.  order_out[i] = tm | tn << 16 is the tile that workgroup i % grid runs in its round
+ * i / grid; `capacity` must be >= tiles_per_side (tiles_per_side + 1) / 2 entries, tiles_per_side <= 65535.  The tiles that are
+ * resident on one XCD at a time (workgroups b, b + 8, ... of a round) form 8 x 4 blocks of the grid: 12 operand panels per
+ * 32 tiles instead of the 33 of a row-major walk. */
+int dedup_tile_order(int tiles_per_side, int grid, unsigned* order_out, long capacity);
 
 /* Replaces the per-file loop of find_similar_imgs (/root/reference/tools/find_similar_imgs.py:96-137): the distance of
  * every stored embedding row to one query (the mean context embedding, :62) and the top_n closest.

@@ -55,24 +55,30 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, n_total, batch, q):
+def _worker(rank, world, port, n_total, batch, gather_dst, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        res = run_embed_job(n_total, batch, CROPS, E, 1, _source, _encode_score, "cpu", rank, world, gather=True)
+        res = run_embed_job(n_total, batch, CROPS, E, 1, _source, _encode_score, "cpu", rank, world, gather=True,
+                            gather_dst=gather_dst)
         e, s = _expected(n_total)
-        ok = torch.equal(res["emb"], e) and torch.equal(res["score"], s)
+        if gather_dst is None or rank == gather_dst:
+            ok = torch.equal(res["emb"], e) and torch.equal(res["score"], s)
+        else:
+            ok = res["emb"] is None and res["score"] is None           # a true gather: only the destination holds the job
         q.put((rank, bool(ok), res["n_local"], res["batches"]))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total,batch,expect", [(11, 3, [(0, True, 6, 2), (1, True, 5, 2)]), (1, 4, [(0, True, 1, 1), (1, True, 0, 0)])])
-def test_job_world2_gloo(n_total, batch, expect):
+@pytest.mark.parametrize("gather_dst", [None, 0])
+@pytest.mark.parametrize("n_total,batch,expect", [(11, 3, [(0, True, 6, 2), (1, True, 5, 2)]), (1, 4, [(0, True, 1, 1), (1, True, 0, 0)]),
+                                                  (12, 4, [(0, True, 6, 2), (1, True, 6, 2)])])
+def test_job_world2_gloo(n_total, batch, expect, gather_dst):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, batch, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, batch, gather_dst, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in procs)

@@ -212,10 +212,29 @@ def test_load_weights_from_what_open_clip_leaves_in_cache_dir(tmp_path):
     assert all(torch.equal(back[k], sd[k]) for k in sd)
     back2 = vit_config.load_weights("ViT-small-test/laion2b_s32b_b82k", str(hub))
     assert back2["conv1.weight"].shape[0] == other_cfg.width
-    with pytest.raises(ValueError):                                           # files exist, none fits
+    with pytest.raises(FileNotFoundError):                                    # no repository of that architecture
         vit_config.load_weights("ViT-long-test/laion2b_s32b_b82k", str(hub))
     with pytest.raises(FileNotFoundError):
         vit_config.load_weights("ViT-tiny-test/openai", str(tmp_path / "empty"))
+    # open_clip resolves exactly the named tag (/root/reference/utils/embedder.py:66-73): a snapshot of the right
+    # architecture but ANOTHER pretrained tag must not be loaded silently
+    with pytest.raises(FileNotFoundError):
+        vit_config.load_weights("ViT-tiny-test/openai", str(hub))
+    with pytest.raises(FileNotFoundError):
+        vit_config.load_weights("ViT-tiny-test/laion400m_e32", str(hub))
+    # ... and a repository of a LONGER architecture name does not answer for the shorter one (ViT-L-14 vs ViT-L-14-336)
+    assert vit_config._has_component("models--laion--clip-vit-l-14-laion2b-s32b-b82k", "vit-l-14")
+    assert not vit_config._has_component("models--laion--clip-vit-l-14-336-laion2b", "vit-l-14")
+    assert not vit_config._has_component("models--x--clip-convit-l-14-laion2b", "vit-l-14")
+    # the exact hand-placed file wins over a hub snapshot of the same name pair
+    exact = {k: v + 1.0 for k, v in sd.items()}
+    torch.save(exact, str(hub / "ViT-tiny-test-laion2b_s32b_b82k.pt"))
+    back3 = vit_config.load_weights("ViT-tiny-test/laion2b_s32b_b82k", str(hub))
+    assert torch.equal(back3["conv1.weight"], exact["conv1.weight"])
+    # a file that is there but holds another architecture still reports ValueError, not "not found"
+    torch.save({k: v for k, v in vit_config.seeded_state_dict(other_cfg, 1).items()}, str(hub / "ViT-long-test-openai.pt"))
+    with pytest.raises(ValueError):
+        vit_config.load_weights("ViT-long-test/openai", str(hub))
 
 
 class _TraceWrap(torch.nn.Module):

@@ -35,10 +35,18 @@ def _worker(rank, world, port, n_total, q):
         # stand-in for the per-rank encode+score result: row i of the job is filled with i
         emb = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1).expand(hi - lo, 4, 6).contiguous()
         score = torch.arange(lo, hi, dtype=torch.float32).view(-1, 1) * 0.5
-        full_e = gather_rows(emb, n_total)
+        want_e, want_s = torch.arange(n_total, dtype=torch.float32), torch.arange(n_total, dtype=torch.float32) * 0.5
+        full_e = gather_rows(emb, n_total)                      # every rank receives (all-gather / ragged: broadcasts)
         full_s = gather_rows(score, n_total)
-        ok = (full_e.shape == (n_total, 4, 6) and torch.equal(full_e[:, 0, 0], torch.arange(n_total, dtype=torch.float32))
-              and torch.equal(full_s[:, 0], torch.arange(n_total, dtype=torch.float32) * 0.5))
+        ok = full_e.shape == (n_total, 4, 6) and torch.equal(full_e[:, 0, 0], want_e) and torch.equal(full_s[:, 0], want_s)
+        ok = ok and torch.equal(full_e[:, 3, 5], want_e)
+        for dst in range(world):                                # true gather: only `dst` receives, the others get None
+            g_e = gather_rows(emb, n_total, dst=dst)
+            g_s = gather_rows(score, n_total, dst=dst)
+            if rank == dst:
+                ok = ok and g_e.shape == (n_total, 4, 6) and torch.equal(g_e[:, 1, 2], want_e) and torch.equal(g_s[:, 0], want_s)
+            else:
+                ok = ok and g_e is None and g_s is None
         # max-over-ranks timing reduction used by bench.py
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -47,19 +55,64 @@ def _worker(rank, world, port, n_total, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_total", [10, 7, 1])
-def test_gather_rows_world2_gloo(n_total):
+def _run_world(target, world, *args):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res == [(0, True, 2.0), (1, True, 2.0)]
+    return res
+
+
+@pytest.mark.parametrize("world,n_total", [(2, 10), (2, 7), (2, 1), (3, 8), (3, 9)])
+def test_gather_rows_gloo(world, n_total):
+    res = _run_world(_worker, world, n_total)
+    assert res == [(r, True, float(world)) for r in range(world)]
+
+
+def _peak_worker(rank, world, port, n_total, dst, q):
+    """Peak resident memory of one gather: the result is the ONLY allocation (no padded copy, no concatenation)."""
+    import resource
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_bounds(n_total, rank, world)
+        width = 4 * 768                                          # [n, 4, 768] fp32 rows of the embed job: 12 KiB per image
+        local = torch.full((hi - lo, width), float(rank + 1))
+        warm = gather_rows(torch.ones(hi - lo, 8), n_total, dst=dst)          # transport set-up outside the measurement
+        del warm
+        result_bytes = n_total * width * 4
+        before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024
+        out = gather_rows(local, n_total, dst=dst)
+        after = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024
+        receives = dst is None or rank == dst
+        ok = (out is not None) == receives
+        if receives:
+            for r in range(world):
+                rlo, rhi = shard_bounds(n_total, r, world)
+                ok = ok and bool((out[rlo:rhi] == float(r + 1)).all())
+        q.put((rank, bool(ok), (after - before) / result_bytes, receives))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total,dst", [(16384, None), (16383, None), (16383, 0)])
+def test_gather_rows_peak_memory_is_one_result(n_total, dst):
+    """192 MB result (16 384 images x 12 KiB): the old padded + gathered + concatenated path peaked at > 2.5 x the result."""
+    res = _run_world(_peak_worker, 2, n_total, dst)
+    # gather_rows allocates the result and nothing else.  One backend-side exception on CPU: gloo implements
+    # all_gather_into_tensor (the equal-shard path) through a flattened staging buffer of its own, + 1 x the result inside the
+    # backend; ncclAllGather (RCCL) receives in place.  The ragged and the dst paths are staging-free on gloo too.
+    staged_by_gloo = dst is None and n_total % 2 == 0
+    for rank, ok, growth, receives in res:
+        assert ok
+        bound = (2.25 if staged_by_gloo else 1.25) if receives else 0.25
+        assert growth <= bound, f"rank {rank}: peak memory grew by {growth:.2f} x the result"
 
 
 def test_gather_rows_single_process_passthrough():

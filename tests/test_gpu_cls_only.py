@@ -1,0 +1,56 @@
+"""The last transformer block runs on the class-token rows only: the embedding is ln_post + proj of
+token 0 (/root/reference/utils/embedder.py:98 takes the pooled output), so the rows left out are dead.  Proven here bit for
+bit: the diagnostic library (same sources, -DCLIPENC_DIAG) reads CLIPENC_FULL_LAST_BLOCK=1 at clipenc_create and then runs the
+last block on every token; ViT-L/14, 64 crops, bf16 and fp8, each configuration in a child process of its own."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DIAG_LIB = os.path.join(ROOT, "clip_assisted_data_labeling_amd", "libclipenc_hip_diag.so")
+
+pytestmark = pytest.mark.gpu
+
+_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+from clip_assisted_data_labeling_amd import vit_config
+from clip_assisted_data_labeling_amd.embedder import HipViT
+dev = torch.device("cuda", 0)
+cfg = vit_config.ARCHS["ViT-L-14"]
+vit = HipViT(cfg, vit_config.seeded_state_dict(cfg, 0), dev)
+g = torch.Generator(device=dev).manual_seed(3)
+crops = torch.randn(64, 3, 224, 224, device=dev, generator=g)
+out = {"bf16": vit.encode(crops).cpu()}
+vit.set_precision("fp8")
+out["fp8"] = vit.encode(crops).cpu()
+torch.save(out, sys.argv[1])
+"""
+
+
+def _run(path, env_extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("CLIPENC_FULL_LAST_BLOCK", "CLIPENC_LIB_PATH")}
+    env.update(env_extra)
+    subprocess.run([sys.executable, "-c", _CHILD, path, ROOT], env=env, check=True, timeout=600)
+    return torch.load(path)
+
+
+def test_cls_only_last_block_equals_full_last_block_bitwise(gpu, tmp_path):
+    assert os.path.exists(DIAG_LIB), f"{DIAG_LIB} missing: __graft_entry__.build() makes it (make -C .../csrc diag)"
+    product = _run(str(tmp_path / "product.pt"), {})                                          # the shipped library, default path
+    cls_only = _run(str(tmp_path / "cls.pt"), {"CLIPENC_LIB_PATH": DIAG_LIB})                 # diagnostic build, same path
+    full = _run(str(tmp_path / "full.pt"), {"CLIPENC_LIB_PATH": DIAG_LIB, "CLIPENC_FULL_LAST_BLOCK": "1"})
+    for prec in ("bf16", "fp8"):
+        assert torch.isfinite(product[prec]).all()
+        assert torch.equal(product[prec], cls_only[prec]), f"{prec}: diagnostic build differs from the product library"
+        assert torch.equal(cls_only[prec], full[prec]), \
+            f"{prec}: class-token-only last block differs from the full last block, max abs {(cls_only[prec] - full[prec]).abs().max():.3e}"
+    # the switch must not be live in the PRODUCT library: with the variable set it still takes the class-token-only path
+    # (same bits either way, so this is checked through the library's symbol table instead)
+    strings = subprocess.run(["strings", os.path.join(ROOT, "clip_assisted_data_labeling_amd", "libclipenc_hip.so")],
+                             capture_output=True, text=True).stdout
+    for name in ("CLIPENC_FULL_LAST_BLOCK", "CLIPENC_ATTN_IMPL", "CLIPENC_ATTN_DBG"):
+        assert name not in strings, f"developer switch {name} is compiled into the product library"
