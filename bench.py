@@ -327,22 +327,154 @@ def cpu_baseline(cfg, sd, Ws, bs):
     return out
 
 
+KERNEL_SOURCES = (("gemm_fp8", ("gemm_fp8.hip",)), ("gemm_persist", ("gemm_persist.hip", "gemm_tri.hip")), ("attn_", ("attention.hip",)),
+                  ("quant_", ("quant_fp8.hip",)), ("fcreg", ("fcreg.hip",)), ("", ("elementwise.hip",)))
+
+
+def kernel_source_sha(kernel_name):
+    """sha256 (16 hex digits) of the HIP sources a kernel is compiled from (+ the shared headers): what a committed PMC
+    summary must have been taken with for its numbers to describe the kernel that runs today."""
+    import hashlib
+    csrc = os.path.join(ROOT, "clip_assisted_data_labeling_amd", "csrc")
+    files = next(f for key, f in KERNEL_SOURCES if key in kernel_name) + ("common.h", "gemm.h")
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel_name):
-    """HBM-side bytes per launch of `kernel_name` from the latest committed rocprofv3 PMC passes
-    (profiles/*/pmc_hbm_traffic_per_kernel.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read
-    correction, written by tools/summarize_profiles.py); None when no profile has been committed."""
+    """L2-miss (HBM-side) bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC passes that contain it
+    (profiles/*/pmc_hbm_traffic_per_kernel.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction, written by
+    tools/summarize_profiles.py together with the sha of the kernel's sources).  None when no profile has been committed,
+    or when the profile PREDATES the kernel (its recorded source sha differs from today's sources): a stale number is not
+    quoted."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_traffic_per_kernel.json")))
-    if not files:
-        return None
     for path in reversed(files):                      # newest round first; bf16 and fp8 runs are summarised separately
         try:
-            for k, v in json.load(open(path)).items():
-                if kernel_name in k:
-                    return round(float(v.get("bytes_per_launch", v.get("hbm_bytes", 0.0))), 1)
+            doc = json.load(open(path))
         except Exception:
             continue
+        for k, v in doc.items():
+            if k != "_meta" and kernel_name in k:
+                recorded = doc.get("_meta", {}).get("source_sha", {}).get(kernel_name)
+                if recorded != kernel_source_sha(kernel_name):
+                    return None                       # taken with other sources (or before shas were recorded)
+                return round(float(v.get("bytes_per_launch", v.get("hbm_bytes", 0.0))), 1)
     return None
+
+
+def timed_steps(fn, steps, warmup=1):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def fp8_step(vit, reg, crops, cfg, n_img):
+    """BASELINE.json configs[3] arithmetic on the headline batch: the same 512 images x 4 crops through the e4m3 MFMA block
+    GEMMs (clipenc_set_precision), timed over 3 un-profiled steps, then 1 profiled step for the dominant kernel."""
+    sel = list(range(CROPS_PER_IMAGE))
+    vit.set_precision("fp8")
+    try:
+        dt = timed_steps(lambda: vit.encode_score(crops, reg, CROPS_PER_IMAGE, sel), 3)
+        vit.profile_enable(True)
+        vit.encode_score(crops, reg, CROPS_PER_IMAGE, sel)
+        torch.cuda.synchronize()
+        prof = vit.profile_read()
+        vit.profile_enable(False)
+    finally:
+        vit.set_precision("bf16")
+    dom = max((k for k in prof if not k.startswith("shape:")), key=lambda k: prof[k][0])
+    d_ms, d_n, d_fl = prof[dom]
+    tf = d_fl / (d_ms * 1e-3) / 1e12 if d_ms > 0 else 0.0
+    value = n_img / dt
+    flop = 2.0 * cfg.macs_per_crop() * CROPS_PER_IMAGE
+    peak = PEAK_FP8_TFLOPS if "fp8" in dom else PEAK_BF16_TFLOPS
+    return {"workload": f"the headline batch ({n_img} images x 4 crops, ViT-L/14) with e4m3 MFMA block GEMMs (BASELINE.json configs[3] arithmetic), 3 steps",
+            "value": round(value, 2), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "fp8",
+            "end_to_end_tflops": round(value * flop / 1e12, 1), "frac_of_fp8_peak": round(value * flop / 1e12 / PEAK_FP8_TFLOPS, 4),
+            "dominant_kernel": dom, "dominant_tflops": round(tf, 1), "dominant_frac": round(tf / peak, 4), "dominant_peak": peak,
+            "kernels_ms_per_step": {k: round(v[0], 3) for k, v in prof.items() if v[0] > 0 and not k.startswith("shape:")}}
+
+
+def vit_l14_336_step(dev, Ws, bs):
+    """The reference's DEFAULT model (/root/reference/_1_embed_with_CLIP.py:190: ViT-L-14-336, 577 tokens) at full size: 128 images
+    x 4 crops of 336 x 336 per step, bf16, fused regressor; images/s and the attention kernel's share of the step."""
+    from clip_assisted_data_labeling_amd import vit_config
+    from clip_assisted_data_labeling_amd.embedder import HipViT
+    from clip_assisted_data_labeling_amd.nn_model import HipRegressor
+    cfg = vit_config.ARCHS["ViT-L-14-336"]
+    n_img = 128
+    vit = HipViT(cfg, vit_config.seeded_state_dict(cfg, 0), dev, chunk_crops=n_img * CROPS_PER_IMAGE)
+    reg = HipRegressor([torch.from_numpy(w) for w in Ws], [torch.from_numpy(b) for b in bs], 0.01, dev)
+    try:
+        crops = synthetic_crops(n_img * CROPS_PER_IMAGE, cfg.image_size, 336, dev)
+        sel = list(range(CROPS_PER_IMAGE))
+        dt = timed_steps(lambda: vit.encode_score(crops, reg, CROPS_PER_IMAGE, sel), 3)
+        vit.profile_enable(True)
+        vit.encode_score(crops, reg, CROPS_PER_IMAGE, sel)
+        torch.cuda.synchronize()
+        prof = vit.profile_read()
+    finally:
+        vit.close()
+        reg.close()
+    total = sum(v[0] for k, v in prof.items() if not k.startswith("shape:"))
+    attn = sum(v[0] for k, v in prof.items() if k.startswith("attn_"))
+    attn_fl = sum(v[2] for k, v in prof.items() if k.startswith("attn_"))
+    value = n_img / dt
+    flop = 2.0 * cfg.macs_per_crop() * CROPS_PER_IMAGE
+    return {"workload": f"ViT-L-14-336 (the reference's default model, 577 tokens) bf16 encode + score of {n_img} images x 4 crops of 336 x 336, 3 steps",
+            "value": round(value, 2), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3),
+            "end_to_end_tflops": round(value * flop / 1e12, 1), "frac_of_bf16_peak": round(value * flop / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "attention_share_of_step": round(attn / total, 4) if total > 0 else None,
+            "attention_tflops": round(attn_fl / (attn * 1e-3) / 1e12, 1) if attn > 0 else None,
+            "kernels_ms_per_step": {k: round(v[0], 3) for k, v in prof.items() if v[0] > 0 and not k.startswith("shape:")}}
+
+
+def embed_e2e(dev, n=2048, size=512, workers=16, batch=256):
+    """The real-data rate of the embed driver (/root/reference/_1_embed_with_CLIP.py:95-184 -> embed_driver.Feature_Dataset):
+    `n` generated JPEG files -> DataLoader workers decode -> GPU crop/resize front end -> ViT-L/14 encoder -> one .pt per image;
+    DataLoader start-up included.  JPEG decode runs on the host cores, so this is a property of the box's CPU share too."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from clip_assisted_data_labeling_amd import embed_driver
+    from clip_assisted_data_labeling_amd.embedder import CLIP_Encoder
+    tmp = tempfile.mkdtemp(prefix="bench_e2e_")
+    try:
+        base = np.random.RandomState(0).randint(0, 256, (size, size, 3), dtype=np.uint8)
+
+        def write(i):
+            Image.fromarray(np.roll(base, i * 7, axis=1)).save(os.path.join(tmp, f"{i:06d}.jpg"), quality=90)
+        with ThreadPoolExecutor(8) as ex:
+            list(ex.map(write, range(n)))
+        workers = max(1, min(workers, len(os.sched_getaffinity(0))))
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            enc = CLIP_Encoder(f"{MODEL}/seed0", None, device=f"cuda:{dev.index}")
+            ds = embed_driver.Feature_Dataset(tmp, f"{MODEL}/seed0", batch, shuffle_filenames=False, num_workers=workers, encoder=enc,
+                                              device=f"cuda:{dev.index}", gpu_preprocess=True, force_reencode=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            n_emb = ds.process()[0]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        n_pt = sum(f.endswith(".pt") for f in os.listdir(tmp))
+        enc.model.close()
+        return {"workload": f"embed_driver on {n} generated {size}x{size} JPEG files: host decode ({workers} DataLoader workers) -> GPU front end "
+                            f"-> ViT-L/14 bf16 -> one .pt per image, loader start-up included",
+                "value": round(n_emb / dt, 1), "unit": "images/s", "seconds": round(dt, 2), "images": int(n_emb), "pt_files_written": n_pt,
+                "workers": workers, "batch": batch}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def run_job(args, cfg, vit, reg, dev, rank, world, backend):
@@ -376,24 +508,30 @@ def run_job(args, cfg, vit, reg, dev, rank, world, backend):
     t0 = time.perf_counter()
     res = run_embed_job(N, B, CROPS_PER_IMAGE, cfg.embed_dim, reg.sizes[-1], source,
                         lambda c: vit.encode_score(c, reg, CROPS_PER_IMAGE, sel), dev, rank, world, gather=True,
-                        sync=torch.cuda.synchronize, progress=progress)
+                        sync=torch.cuda.synchronize, progress=progress, gather_dst=0)   # a true gather: rank 0 collects
     fence()
     elapsed = time.perf_counter() - t0
     times = torch.tensor([elapsed, res["t_encode"], res["t_gather"]], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     elapsed, t_enc, t_gat = (float(x) for x in times.tolist())
-    emb, score = res["emb"], res["score"]
-    assert emb.shape == (N, CROPS_PER_IMAGE, cfg.embed_dim) and score.shape[0] == N
-    assert torch.isfinite(emb).all() and torch.isfinite(score).all()
-    norm_err = float((emb.norm(dim=-1) - 1.0).abs().max().item())
+    emb, score = res["emb"], res["score"]                 # the whole job on rank 0, None elsewhere
+    loc_e, loc_s = res["emb_local"], res["score_local"]
+    norm_err = 0.0
+    if rank == 0:
+        assert emb.shape == (N, CROPS_PER_IMAGE, cfg.embed_dim) and score.shape[0] == N
+        assert torch.isfinite(emb).all() and torch.isfinite(score).all()
+        assert torch.equal(emb[res["lo"]:res["hi"]], loc_e) and torch.equal(score[res["lo"]:res["hi"]], loc_s)
+        norm_err = float((emb.norm(dim=-1) - 1.0).abs().max().item())
+    else:
+        assert emb is None and score is None
     # reproducibility: the first batch of this rank's shard again, from a fresh generator with the same seed, must give the
     # stored rows bit for bit (counter-based source + deterministic encoder)
     again = synthetic_u8_source(cfg.image_size, CROPS_PER_IMAGE, args.job_seed, rank, dev)
     nb = min(B, res["n_local"])
     e2, s2 = vit.encode_score(again(res["lo"], nb), reg, CROPS_PER_IMAGE, sel)
     torch.cuda.synchronize()
-    same = bool(torch.equal(e2, emb[res["lo"]:res["lo"] + nb]) and torch.equal(s2, score[res["lo"]:res["lo"] + nb]))
+    same = bool(torch.equal(e2, loc_e[:nb]) and torch.equal(s2, loc_s[:nb]))
     if rank == 0:
         flop_per_image = 2.0 * cfg.macs_per_crop() * CROPS_PER_IMAGE
         value = N / elapsed
@@ -403,7 +541,7 @@ def run_job(args, cfg, vit, reg, dev, rank, world, backend):
             "n_gpus": world, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"BASELINE.json configs[3]: {N} synthetic images x 4 crops sharded over {world} rank(s), uint8 crops "
                                    f"generated on the device per {B}-image batch (Philox counter generator, seed {args.job_seed} + rank), "
-                                   f"{args.dtype} block GEMMs, fused fp32 regressor, embeddings + scores kept in HBM, one all_gather at the end",
+                                   f"{args.dtype} block GEMMs, fused fp32 regressor, embeddings + scores kept in HBM, one gather onto rank 0 at the end",
                        "job_images": N, "batch_images": B, "images_per_rank": res["n_local"], "batches_per_rank": res["batches"],
                        "parallelism": f"image-sharded x{world}"},
             "seconds": {"job": round(elapsed, 3), "generate_encode_score": round(t_enc, 3), "gather": round(t_gat, 4)},
@@ -424,7 +562,8 @@ def main():
     ap.add_argument("--images", type=int, default=IMAGES_PER_GPU, help="images per GPU per step (default 512)")
     ap.add_argument("--chunk", type=int, default=0, help="crops per pass through the layer chain (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[4] dedup timing appended to the line")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary block (fp8 step, configs[4] dedup, ViT-L-14-336 step, JPEG-to-embeddings driver rate)")
     ap.add_argument("--no-power-ceiling", action="store_true",
                     help="skip roofline.power_capped_mfma_stream (0.35 s of pure MFMA; tools/profile_round.sh leaves it out of the rocprofv3 passes)")
     ap.add_argument("--job-images", type=int, default=0,
@@ -559,6 +698,7 @@ def main():
                            # the LAST block's Q / attention / out-proj / MLP run on the class-token row only
                            # (dead rows are not computed); this is the rate of the arithmetic actually issued
                            "executed_tflops": round(value * flop_exec_per_image / 1e12, 1),
+                           "frac_executed": round(value * flop_exec_per_image / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
                            "flop_per_image": flop_per_image, "flop_per_image_executed": flop_exec_per_image},
             "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": d_peak,
                          "unit": "TFLOP/s", "frac": round(achieved / d_peak, 4), "traffic": pmc_traffic(DOMINANT),
@@ -584,9 +724,18 @@ def main():
             ceil["frac"] = round(achieved / ceil["value"], 4) if ceil["value"] else None     # dominant kernel / that ceiling
             line["roofline"]["power_capped_mfma_stream"] = ceil
         if world == 1 and not args.no_secondary and not fp8:
+            sec = {"fp8_step": fp8_step(vit, reg, crops, cfg, n_img)}
             del crops
+            vit.close()
             torch.cuda.empty_cache()
-            line["secondary"] = {"dedup_100k": dedup_100k(dev)}
+            sec["dedup_100k"] = dedup_100k(dev)
+            sec["vit_l14_336"] = vit_l14_336_step(dev, Ws, bs)
+            torch.cuda.empty_cache()
+            try:
+                sec["embed_e2e"] = embed_e2e(dev)
+            except Exception as exc:                                   # host-side (loader workers, /tmp): never lose the line to it
+                sec["embed_e2e"] = {"error": f"{type(exc).__name__}: {exc}"}
+            line["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, Ws, bs)
         print(json.dumps(line), flush=True)

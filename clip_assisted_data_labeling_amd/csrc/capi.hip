@@ -697,6 +697,12 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
     *name = kProfileNames[kind];
     if (e->cfg.act == CLIPENC_ACT_GELU_ERF && kind == PK_GEMM_FC1) *name = "gemm_persist_kernel<2, 1>";
     if (e->cfg.act == CLIPENC_ACT_GELU_ERF && kind == PK_GEMM8_FC1) *name = "gemm_fp8_kernel<2, 1>";
+    if (kind == PK_ATTENTION) {                      // the instantiation ce_attention picks for this token count
+      const int nkt = (e->tokens + 31) / 32;
+      if (nkt > 9) *name = "attn_long_kernel<7>";
+      else if (nkt == 8) *name = "attn_stream_kernel<8, 7>";
+      else if (nkt < 8) { static thread_local char buf[32]; snprintf(buf, sizeof buf, "attn_kernel<%d>", nkt); *name = buf; }
+    }
   }
   if (total_ms) *total_ms = e->prof.ms[kind];
   if (launches) *launches = e->prof.launches[kind];

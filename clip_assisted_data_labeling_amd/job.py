@@ -44,7 +44,7 @@ def run_embed_job(n_images: int, batch_images: int, crops_per_image: int, embed_
                   device, rank: int = 0, world: int = 1, gather: bool = True, sync: Optional[Callable[[], None]] = None,
                   progress: Optional[Callable[[int, int], None]] = None, gather_dst: Optional[int] = None) -> Dict:
     """Runs this rank's shard of the job.  `encode_score(crops) -> (emb [b, crops, E], score [b, score_dim])` on `device`.
-    Returns {'emb', 'score'} (gather=True: the FULL job on every rank, or -- with gather_dst=r -- on rank r only and None
+    Returns {'emb_local', 'score_local'} (this rank's block) and {'emb', 'score'} (gather=True: the FULL job on every rank, or -- with gather_dst=r -- on rank r only and None
     elsewhere; gather=False: the local block), 'n_local', 'lo', 'hi', 'batches' and wall-clock seconds of the encode phase
     and of the gather ('t_encode', 't_gather'; `sync` is called before each clock is read -- torch.cuda.synchronize on a
     GPU).  The gather allocates nothing but the result (sharding.gather_rows)."""
@@ -69,7 +69,8 @@ def run_embed_job(n_images: int, batch_images: int, crops_per_image: int, embed_
             progress(b0 + nb, n_local)
     sync()
     t1 = time.perf_counter()
-    out = {"n_local": n_local, "lo": lo, "hi": hi, "batches": batches, "t_encode": t1 - t0, "t_gather": 0.0}
+    out = {"n_local": n_local, "lo": lo, "hi": hi, "batches": batches, "t_encode": t1 - t0, "t_gather": 0.0,
+           "emb_local": emb, "score_local": score}            # this rank's own rows, whatever the gather does
     if gather and world > 1:
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("world > 1 needs an initialised torch.distributed process group")

@@ -11,7 +11,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
-enum Role { SLEEP = 0, M32 = 1, M16 = 2, EXP = 3, FMA = 4, LDS128 = 5, LDSTR = 6, M32_EXP = 7, MAX3 = 8, M32Z = 9, M16Z = 10, DOT2 = 11, M32_LDS = 12, F8_32 = 13, F8_16 = 14, F8_32Z = 15 };
+enum Role { SLEEP = 0, M32 = 1, M16 = 2, EXP = 3, FMA = 4, LDS128 = 5, LDSTR = 6, M32_EXP = 7, MAX3 = 8, M32Z = 9, M16Z = 10, DOT2 = 11, M32_LDS = 12, F8_32 = 13, F8_16 = 14, F8_32Z = 15,
+            // issue ORDER of a 4 x 4 block of 16x16x32 MFMAs (16 accumulators, 4 srcA and 4 srcB fragments), round 3:
+            ORD_ROW = 16, ORD_SERP = 17, ORD_DIAG = 18, ORD_COL = 19, ORD_SAME = 20, ORD_SERP_COL = 21 };
 
 #define MFMA32(acc, a_, b_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_))
 #define MFMA16(acc, a_, b_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_))
@@ -22,7 +24,8 @@ __global__ __launch_bounds__(512, 2) void power_kernel(const uint32_t* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 65536 / 4; i += 512) ((uint32_t*)lds)[i] = rnd[i & 4095];
   __syncthreads();
-  f32x16_t acc[4]; f32x4_t acc4[4];
+  f32x16_t acc[4]; f32x4_t acc4[4]; f32x4_t acc16[16];
+  for (int i = 0; i < 16; ++i) for (int e = 0; e < 4; ++e) acc16[i][e] = 0.f;
   for (int i = 0; i < 4; ++i) { for (int e = 0; e < 16; ++e) acc[i][e] = 0.f; for (int e = 0; e < 4; ++e) acc4[i][e] = 0.f; }
   u32x4_t aw[4], bw[4];
   for (int i = 0; i < 4; ++i)
@@ -49,6 +52,21 @@ __global__ __launch_bounds__(512, 2) void power_kernel(const uint32_t* __restric
     } else if constexpr (ROLE == M16 || ROLE == M16Z) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) MFMA16(acc4[i & 3], __builtin_bit_cast(bf16x8_t, aw[i & 3]), __builtin_bit_cast(bf16x8_t, bw[(i + 1) & 3]));
+    } else if constexpr (ROLE >= ORD_ROW && ROLE <= ORD_SERP_COL) {
+      // acc16[i][j] += srcA[j] . srcB[i]: the GEMM's MMA2 block.  What differs between the roles is only WHICH operand registers
+      // change between consecutive MFMAs: ROW (the shipped order: j inner -> srcA changes every MFMA, srcB every 4th), SERP (j runs
+      // 0..3, 3..0, ...: exactly one operand changes per MFMA), COL (i inner: srcB changes every MFMA, srcA every 4th), SERP_COL,
+      // DIAG (both change every MFMA), SAME (one operand pair for all 16: nothing but the accumulator changes).
+#pragma unroll
+      for (int n = 0; n < 16; ++n) {
+        int i = n >> 2, j = n & 3;
+        if constexpr (ROLE == ORD_SERP) j = (i & 1) ? 3 - j : j;
+        if constexpr (ROLE == ORD_COL) { const int t = i; i = j; j = t; }
+        if constexpr (ROLE == ORD_SERP_COL) { const int t = i; i = (t & 1) ? 3 - j : j; j = t; }
+        if constexpr (ROLE == ORD_DIAG) { i = n & 3; j = ((n & 3) + (n >> 2)) & 3; }
+        const int ia = ROLE == ORD_SAME ? 0 : j, ib = ROLE == ORD_SAME ? 0 : i;
+        MFMA16(acc16[i * 4 + j], __builtin_bit_cast(bf16x8_t, aw[ia]), __builtin_bit_cast(bf16x8_t, bw[ib]));
+      }
     } else if constexpr (ROLE == EXP) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) asm volatile("v_exp_f32 %0, %1" : "=v"(x[i]) : "v"(x[i]));
@@ -107,6 +125,7 @@ __global__ __launch_bounds__(512, 2) void power_kernel(const uint32_t* __restric
   float sink = 0.f;
   for (int i = 0; i < 16; ++i) sink += x[i];
   for (int i = 0; i < 4; ++i) sink += acc[i][0] + acc4[i][0];
+  for (int i = 0; i < 16; ++i) sink += acc16[i][0];
   if (lane == 0) out[(size_t)blockIdx.x * 8 + wave] = t1 - t0;
   if (sink == 12345.678f) out[0] = 0;
 }
@@ -116,6 +135,7 @@ extern "C" int power_probe_run(int role, const void* rnd, void* out, int iters, 
   switch (role) {
     LAUNCH(SLEEP) LAUNCH(M32) LAUNCH(M16) LAUNCH(EXP) LAUNCH(FMA) LAUNCH(LDS128) LAUNCH(LDSTR) LAUNCH(M32_EXP) LAUNCH(MAX3) LAUNCH(M32Z) LAUNCH(M16Z)
     LAUNCH(DOT2) LAUNCH(M32_LDS) LAUNCH(F8_32) LAUNCH(F8_16) LAUNCH(F8_32Z)
+    LAUNCH(ORD_ROW) LAUNCH(ORD_SERP) LAUNCH(ORD_DIAG) LAUNCH(ORD_COL) LAUNCH(ORD_SAME) LAUNCH(ORD_SERP_COL)
     default: return -1;
   }
   return (int)hipGetLastError();

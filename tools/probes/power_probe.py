@@ -12,7 +12,11 @@ ROLES = [("sleep", 0, 0, ""), ("mfma 32x32x16 bf16", 1, 8, "mfma"), ("mfma 32x32
          ("mfma 16x16x32 zeros", 10, 16, "mfma"), ("v_exp_f32", 3, 16, "instr"), ("v_fma_f32", 4, 64, "instr"), ("v_max3_f32", 8, 64, "instr"),
          ("v_dot2c_f32_bf16", 11, 64, "instr"), ("ds_read_b128", 5, 16, "instr"), ("ds_read_b64_tr_b16", 6, 16, "instr"),
          ("mfma32 + 2 exp", 7, 8, "mfma"), ("mfma32 + ds_read_b128", 12, 8, "mfma"),
-         ("mfma_scale 32x32x64 fp8", 13, 4, "mfma"), ("mfma_scale 32x32x64 zeros", 15, 4, "mfma"), ("mfma_scale 16x16x128 fp8", 14, 8, "mfma")]
+         ("mfma_scale 32x32x64 fp8", 13, 4, "mfma"), ("mfma_scale 32x32x64 zeros", 15, 4, "mfma"), ("mfma_scale 16x16x128 fp8", 14, 8, "mfma"),
+         # issue order of a 4 x 4 block of 16x16x32 MFMAs (PROBE_ONLY=order runs just these, three interleaved rounds)
+         ("4x4 block, shipped order (srcA every MFMA, srcB every 4th)", 16, 16, "order"), ("4x4 block, serpentine (one operand per MFMA)", 17, 16, "order"),
+         ("4x4 block, diagonal (both operands every MFMA)", 18, 16, "order"), ("4x4 block, transposed (srcB every MFMA, srcA every 4th)", 19, 16, "order"),
+         ("4x4 block, transposed serpentine", 21, 16, "order"), ("4x4 block, one operand pair for all 16", 20, 16, "order")]
 
 
 def main():
@@ -27,8 +31,12 @@ def main():
     st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     secs = float(os.environ.get("PROBE_SECONDS", "1.5"))
     base_w = None
-    print(f"{'role':28s} {'memtime GHz':>11s} {'hwmon MHz':>9s} {'W':>7s} {'cyc/instr':>9s} {'G instr/s':>10s} {'nJ/instr (above sleep)':>22s}")
-    for name, role, per_body, kind in ROLES:
+    print(f"{'role':60s} {'memtime GHz':>11s} {'hwmon MHz':>9s} {'W':>7s} {'cyc/instr':>9s} {'G instr/s':>10s} {'nJ/instr (above sleep)':>22s}")
+    only = os.environ.get("PROBE_ONLY", "")
+    roles = [r for r in ROLES if not only or r[3] == only or r[1] == 0]
+    if only:
+        roles = roles[:1] + roles[1:] * int(os.environ.get("PROBE_ROUNDS", "3"))      # interleaved rounds: same-box, same-minute A/B
+    for name, role, per_body, kind in roles:
         f(role, rnd.data_ptr(), out.data_ptr(), 2000, st); torch.cuda.synchronize()
         t0 = time.perf_counter(); f(role, rnd.data_ptr(), out.data_ptr(), 20000, st); torch.cuda.synchronize()
         dt = time.perf_counter() - t0
@@ -45,12 +53,12 @@ def main():
         mhz = float(np.median(fq[len(fq) // 3:])) if fq else float("nan")
         if role == 0:
             base_w = w
-            print(f"{name:28s} {ghz:11.3f} {mhz:9.0f} {w:7.0f}")
+            print(f"{name:60s} {ghz:11.3f} {mhz:9.0f} {w:7.0f}")
             continue
         n_instr = per_body * iters * 256.0 * 8
         rate = n_instr / (ms * 1e-3)
         nj = (w - base_w) / rate * 1e9
-        print(f"{name:28s} {ghz:11.3f} {mhz:9.0f} {w:7.0f} {cyc / (per_body * iters):9.2f} {rate / 1e9:10.1f} {nj:22.2f}")
+        print(f"{name:60s} {ghz:11.3f} {mhz:9.0f} {w:7.0f} {cyc / (per_body * iters):9.2f} {rate / 1e9:10.1f} {nj:22.2f}")
 
 
 if __name__ == "__main__":

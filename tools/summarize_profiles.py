@@ -21,7 +21,7 @@ def per_kernel(path, names):
     dur = collections.defaultdict(float)
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
-        if not any(s in k for s in ("gemm", "attn", "fcreg", "head_kernel", "patchify", "embed_ln", "quant_rows")):
+        if not any(s in k for s in ("gemm", "attn", "fcreg", "head_kernel", "patchify", "embed_ln", "quant_")):
             continue
         if r["Counter_Name"] in names:
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -40,7 +40,18 @@ for k in f:
     wr = w.get(k, {}).get("WRITE_SIZE", 0.0) * 1024 / max(nw.get(k, 1), 1)
     traffic[k] = {"launches": nf[k], "read_bytes_per_launch": rd, "write_bytes_per_launch": wr, "bytes_per_launch": rd + wr,
                   "note": "L2-miss traffic (Infinity-Cache hits are counted by the fabric counters); FETCH_SIZE x2 gfx950 correction"}
+# sha of the sources each profiled kernel was built from: bench.py quotes `roofline.traffic` only while they are unchanged
+sys.path.insert(0, root)
+import bench  # noqa: E402
+import re  # noqa: E402
+short = {}
+for k in traffic:
+    m = re.search(r"(\w+_kernel(<[^>]*>)?)", k)
+    if m:
+        short[m.group(1)] = bench.kernel_source_sha(m.group(1))
+traffic["_meta"] = {"source_sha": short, "note": "sha256[:16] of the kernel's .hip sources + common.h + gemm.h at profile time"}
 json.dump(traffic, open(os.path.join(dst, "pmc_hbm_traffic_per_kernel.json"), "w"), indent=1)
+del traffic["_meta"]
 sq_names = {"SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
             "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT"}
 s, ns, dur = per_kernel(newest(os.path.join(src, "pmc_sq", "*", "*counter_collection.csv")), sq_names)
