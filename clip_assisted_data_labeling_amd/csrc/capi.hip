@@ -77,7 +77,7 @@ enum { PK_PATCHIFY = 0, PK_GEMM_PATCH, PK_EMBED_LN_PRE, PK_GEMM_QKV, PK_ATTENTIO
        PK_SUB_OUT, PK_SUB_FC2,                // PK_SUB_*: the EPI_RESID launches split by shape
        PK_QUANT_LN, PK_QUANT, PK_GEMM8_QKV, PK_GEMM8_FC1, PK_GEMM8_RESID, PK_SUB8_OUT, PK_SUB8_FC2, PK_COUNT };
 static const char* const kProfileNames[PK_COUNT] = {
-    "patchify_kernel<float>", "gemm_persist_kernel<1, -1>", "embed_ln_pre_kernel", "gemm_persist_kernel<2, -1>",
+    "patchify_kernel<float, 14>", "gemm_persist_kernel<1, -1>", "embed_ln_pre_kernel<2>", "gemm_persist_kernel<2, -1>",
     "attn_stream_kernel<9, 7>", "gemm_persist_kernel<3, -1>", "gemm_persist_kernel<2, 0>", "head_kernel", "fcreg_kernel",
     "shape:out_proj(gemm_persist_kernel<3, -1>)", "shape:fc2(gemm_persist_kernel<3, -1>)",
     "quant_ln16_kernel<8>", "quant_rows_kernel<unsigned short, false, 2, 4>", "gemm_fp8_kernel<0, -1>",
@@ -697,6 +697,12 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
     *name = kProfileNames[kind];
     if (e->cfg.act == CLIPENC_ACT_GELU_ERF && kind == PK_GEMM_FC1) *name = "gemm_persist_kernel<2, 1>";
     if (e->cfg.act == CLIPENC_ACT_GELU_ERF && kind == PK_GEMM8_FC1) *name = "gemm_fp8_kernel<2, 1>";
+    if (kind == PK_PATCHIFY || kind == PK_EMBED_LN_PRE) {   // (patchify: fp32 crops; uint8 / f16 inputs run the <unsigned char, P> / <_Float16, P> twins)
+      static thread_local char nb[2][40];
+      snprintf(nb[0], sizeof nb[0], "patchify_kernel<float, %d>", e->cfg.patch);
+      snprintf(nb[1], sizeof nb[1], "embed_ln_pre_kernel<%d>", (e->cfg.width + 511) / 512);
+      *name = nb[kind == PK_EMBED_LN_PRE];
+    }
     if (kind == PK_ATTENTION) {                      // the instantiation ce_attention picks for this token count
       const int nkt = (e->tokens + 31) / 32;
       if (nkt > 9) *name = "attn_long_kernel<7>";

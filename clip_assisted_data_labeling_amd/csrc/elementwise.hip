@@ -22,9 +22,62 @@ __device__ __forceinline__ float load_pixel<uint8_t>(const uint8_t* p, int c, co
   return ((float)*p / 255.0f - nm.mean[c]) / nm.std[c];
 }
 
-template <typename TIN>
+// One workgroup per (crop, gy) = one row of g patches.  The 3 * patch image rows it needs are contiguous runs of `image`
+// elements: they are fetched with 16-B loads per lane (whole 128-B lines per 8 lanes; the first version read one element
+// per lane in runs of `patch` elements and wrote 2 B per lane: 2.8 TB/s), converted once and kept in LDS as bf16
+// [c][ky][x]; the g * kpad output elements of the patch row are one contiguous block of dst and leave as 16-B pieces of 8
+// consecutive k (gathered from the LDS image with 2-B reads: LDS bandwidth is not what this kernel is short of).
+// Same arithmetic per element as before (bitwise-equal operand, checked by tests/test_gpu_parity.py).
+template <typename TIN> struct Vec16 { static constexpr int N = 16 / sizeof(TIN); };
+
+// PATCH is a template constant: the index arithmetic of the gather divides by patch, patch^2 and kpad, which must be
+// multiplications (the run-time form costs more VALU than the block has memory time for).
+template <typename TIN, int PATCH>
 __global__ __launch_bounds__(256) void patchify_kernel(const TIN* __restrict__ in, bf16_t* __restrict__ out,
-                                                       int image, int patch, int kpad, PixelNorm nm) {
+                                                       int image, PixelNorm nm) {
+  constexpr int patch = PATCH, kpad = (3 * PATCH * PATCH + 127) / 128 * 128;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  bf16_t* img = (bf16_t*)smem;                       // [3 * patch][image]
+  constexpr int V = Vec16<TIN>::N;                   // elements per 16-B load: 4 fp32, 8 f16, 16 uint8
+  const int g = image / patch;
+  const int crop = blockIdx.x / g, gy = blockIdx.x % g;
+  const int k_real = 3 * patch * patch;
+  const TIN* src = in + (size_t)crop * 3 * image * image;
+  bf16_t* dst = out + ((size_t)crop * g + gy) * g * kpad;
+  const int rows = 3 * patch, per_row = image / V;   // host checks image % V == 0 for the vector path
+  for (int idx = threadIdx.x; idx < rows * per_row; idx += 256) {
+    const int r = idx / per_row, v = idx - r * per_row;
+    const int c = r / patch, ky = r - c * patch;
+    const TIN* p = src + ((size_t)c * image + gy * patch + ky) * image + v * V;
+    const uint4 raw = *(const uint4*)p;
+    const TIN* e = (const TIN*)&raw;
+    bf16_t* o = img + (size_t)r * image + v * V;
+#pragma unroll
+    for (int j = 0; j < V; ++j) o[j] = f32_to_bf16(load_pixel<TIN>(e + j, c, nm));
+  }
+  __syncthreads();
+  const int pp = patch * patch;
+  const int pieces = g * kpad / 8;                   // kpad % 128 == 0
+  for (int idx = threadIdx.x; idx < pieces; idx += 256) {
+    const int gx = (idx * 8) / kpad, k0 = idx * 8 - gx * kpad;
+    // (c, ky, kx) of the piece's first k, advanced element by element
+    int c = k0 / pp, rem = k0 - c * pp;
+    int ky = rem / patch, kx = rem - ky * patch;
+    const bf16_t* rowp = img + (c * patch + ky) * image + gx * patch;
+    bf16_t w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      w[j] = (k0 + j < k_real) ? rowp[kx] : (bf16_t)0;
+      if (++kx == patch) { kx = 0; rowp += image; }          // next ky (c * patch + ky is one running row index)
+    }
+    *(uint4*)(dst + (size_t)idx * 8) = *(const uint4*)w;
+  }
+}
+
+// element-per-lane fallback for image sizes whose rows are not a whole number of 16-B vectors
+template <typename TIN>
+__global__ __launch_bounds__(256) void patchify_scalar_kernel(const TIN* __restrict__ in, bf16_t* __restrict__ out,
+                                                              int image, int patch, int kpad, PixelNorm nm) {
   const int g = image / patch;
   const int crop = blockIdx.x / g, gy = blockIdx.x % g;
   const int k_real = 3 * patch * patch;
@@ -54,73 +107,124 @@ __device__ __forceinline__ float wave_sum(float v) {
 // written as bf16, plus the per-row (sum, sumsq) of the ROUNDED row for the LayerNorm folded into
 // the first QKV GEMM.  One wave per token row; lanes own 8-element (16 B) column chunks.
 // ---------------------------------------------------------------------------------------------
+// Token-major: a wave owns ONE token position and walks `cpw` crops of it, so pos[tok], gamma and beta (12 KB per row
+// from L2 against 2 KB of patch embedding and 2 KB of output from/to HBM in the row-major first version: 3.7 TB/s) are
+// read once per wave and live in registers; per row only the patch embedding is loaded, two rows in flight per wave.
+// Row arithmetic (per-lane accumulation order, wave reductions) is unchanged, so the output is bitwise the same.
 constexpr int LN_MAX_CHUNKS = 4;   // width <= 2048
 
+template <int NCH>
 __global__ __launch_bounds__(256) void embed_ln_pre_kernel(const bf16_t* __restrict__ pe, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, bf16_t* __restrict__ x,
-                                                           float* __restrict__ stats, int n_rows, int n_tok, int width,
-                                                           float eps) {
+                                                           float* __restrict__ stats, int n_crops, int n_tok, int width,
+                                                           float eps, int cpw, int waves_per_tok) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= n_rows) return;
-  const int crop = row / n_tok, tok = row - crop * n_tok;
-  float v[LN_MAX_CHUNKS][8];
-  float s = 0.f;
+  const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int tok = gw / waves_per_tok, slot = gw - tok * waves_per_tok;
+  if (tok >= n_tok) return;
+  const int crop0 = slot * cpw, crop1 = min(n_crops, crop0 + cpw);
+  float pz[NCH][8], gm[NCH][8], bt[NCH][8];
 #pragma unroll
-  for (int ci = 0; ci < LN_MAX_CHUNKS; ++ci) {
-    const int c = ci * 512 + lane * 8;
-    if (c < width) {
-      float4 p0 = *(const float4*)(pos + (size_t)tok * width + c);
-      float4 p1 = *(const float4*)(pos + (size_t)tok * width + c + 4);
-      float e[8];
-      if (tok == 0) {
-        float4 c0 = *(const float4*)(cls + c), c1 = *(const float4*)(cls + c + 4);
-        e[0] = c0.x; e[1] = c0.y; e[2] = c0.z; e[3] = c0.w; e[4] = c1.x; e[5] = c1.y; e[6] = c1.z; e[7] = c1.w;
-      } else {
-        uint4 raw = *(const uint4*)(pe + ((size_t)crop * (n_tok - 1) + tok - 1) * width + c);
-        e[0] = __uint_as_float(raw.x << 16); e[1] = __uint_as_float(raw.x & 0xffff0000u);
-        e[2] = __uint_as_float(raw.y << 16); e[3] = __uint_as_float(raw.y & 0xffff0000u);
-        e[4] = __uint_as_float(raw.z << 16); e[5] = __uint_as_float(raw.z & 0xffff0000u);
-        e[6] = __uint_as_float(raw.w << 16); e[7] = __uint_as_float(raw.w & 0xffff0000u);
-      }
-      v[ci][0] = e[0] + p0.x; v[ci][1] = e[1] + p0.y; v[ci][2] = e[2] + p0.z; v[ci][3] = e[3] + p0.w;
-      v[ci][4] = e[4] + p1.x; v[ci][5] = e[5] + p1.y; v[ci][6] = e[6] + p1.z; v[ci][7] = e[7] + p1.w;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) s += v[ci][j];
-    }
-  }
-  const float mean = wave_sum(s) / (float)width;
-  float ss = 0.f;
-#pragma unroll
-  for (int ci = 0; ci < LN_MAX_CHUNKS; ++ci) {
+  for (int ci = 0; ci < NCH; ++ci) {
     const int c = ci * 512 + lane * 8;
     if (c < width) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[ci][j] - mean; ss += d * d; }
-    }
-  }
-  const float rstd = rsqrtf(wave_sum(ss) / (float)width + eps);
-  float rs = 0.f, rss = 0.f;
-#pragma unroll
-  for (int ci = 0; ci < LN_MAX_CHUNKS; ++ci) {
-    const int c = ci * 512 + lane * 8;
-    if (c < width) {
-      float y[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) y[j] = (v[ci][j] - mean) * rstd * gamma[c + j] + beta[c + j];
-      uint4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
-      *(uint4*)(x + (size_t)row * width + c) = pk;
-      const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float a = __uint_as_float(w4[j] << 16), b = __uint_as_float(w4[j] & 0xffff0000u);
-        rs += a + b; rss += a * a + b * b;
+      for (int h = 0; h < 2; ++h) {
+        const float4 p = *(const float4*)(pos + (size_t)tok * width + c + 4 * h);
+        const float4 g = *(const float4*)(gamma + c + 4 * h), b = *(const float4*)(beta + c + 4 * h);
+        pz[ci][4 * h + 0] = p.x; pz[ci][4 * h + 1] = p.y; pz[ci][4 * h + 2] = p.z; pz[ci][4 * h + 3] = p.w;
+        gm[ci][4 * h + 0] = g.x; gm[ci][4 * h + 1] = g.y; gm[ci][4 * h + 2] = g.z; gm[ci][4 * h + 3] = g.w;
+        bt[ci][4 * h + 0] = b.x; bt[ci][4 * h + 1] = b.y; bt[ci][4 * h + 2] = b.z; bt[ci][4 * h + 3] = b.w;
       }
     }
   }
-  rs = wave_sum(rs); rss = wave_sum(rss);
-  if (lane == 0) *(float2*)(stats + (size_t)row * 2) = float2{rs, rss};
+  if (tok == 0) {                                    // class token: the same embedding for every crop
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) {
+      const int c = ci * 512 + lane * 8;
+      if (c < width) {
+        const float4 c0 = *(const float4*)(cls + c), c1 = *(const float4*)(cls + c + 4);
+        pz[ci][0] += c0.x; pz[ci][1] += c0.y; pz[ci][2] += c0.z; pz[ci][3] += c0.w;
+        pz[ci][4] += c1.x; pz[ci][5] += c1.y; pz[ci][6] += c1.z; pz[ci][7] += c1.w;
+      }
+    }
+  }
+  // one row: v = e + pos (e = 0 and pos already holds cls + pos for the class token), LayerNorm, store, statistics
+  auto row_out = [&](int crop, const uint4 (&raw)[NCH]) {
+    float v[NCH][8];
+    float s = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) {
+      const int c = ci * 512 + lane * 8;
+      if (c < width) {
+        if (tok == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[ci][j] = pz[ci][j];
+        } else {
+          const uint32_t w4[4] = {raw[ci].x, raw[ci].y, raw[ci].z, raw[ci].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            v[ci][2 * j] = __uint_as_float(w4[j] << 16) + pz[ci][2 * j];
+            v[ci][2 * j + 1] = __uint_as_float(w4[j] & 0xffff0000u) + pz[ci][2 * j + 1];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += v[ci][j];
+      }
+    }
+    const float mean = wave_sum(s) / (float)width;
+    float ss = 0.f;
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) {
+      const int c = ci * 512 + lane * 8;
+      if (c < width) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[ci][j] - mean; ss += d * d; }
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)width + eps);
+    float rs = 0.f, rss = 0.f;
+    const size_t row = (size_t)crop * n_tok + tok;
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) {
+      const int c = ci * 512 + lane * 8;
+      if (c < width) {
+        float y[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) y[j] = (v[ci][j] - mean) * rstd * gm[ci][j] + bt[ci][j];
+        uint4 pk = {pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]), pack_bf16x2(y[6], y[7])};
+        *(uint4*)(x + row * width + c) = pk;
+        const uint32_t w4[4] = {pk.x, pk.y, pk.z, pk.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = __uint_as_float(w4[j] << 16), b = __uint_as_float(w4[j] & 0xffff0000u);
+          rs += a + b; rss += a * a + b * b;
+        }
+      }
+    }
+    rs = wave_sum(rs); rss = wave_sum(rss);
+    if (lane == 0) *(float2*)(stats + row * 2) = float2{rs, rss};
+  };
+  auto load_row = [&](int crop, uint4 (&raw)[NCH]) {
+#pragma unroll
+    for (int ci = 0; ci < NCH; ++ci) {
+      const int c = ci * 512 + lane * 8;
+      raw[ci] = uint4{0, 0, 0, 0};
+      if (c < width && tok != 0) raw[ci] = *(const uint4*)(pe + ((size_t)crop * (n_tok - 1) + tok - 1) * width + c);
+    }
+  };
+  int crop = crop0;
+  for (; crop + 1 < crop1; crop += 2) {              // two rows in flight
+    uint4 ra[NCH], rb[NCH];
+    load_row(crop, ra); load_row(crop + 1, rb);
+    row_out(crop, ra); row_out(crop + 1, rb);
+  }
+  if (crop < crop1) {
+    uint4 ra[NCH];
+    load_row(crop, ra);
+    row_out(crop, ra);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -222,14 +326,23 @@ hipError_t ce_patchify(const void* crops, int in_dtype, void* a_patch, int n_cro
   const int g = image / patch;
   dim3 grid(n_crops * g), block(256);
   PixelNorm nm{{mean3[0], mean3[1], mean3[2]}, {std3[0], std3[1], std3[2]}};
-  if (in_dtype == 0)
-    hipLaunchKernelGGL(patchify_kernel<float>, grid, block, 0, stream, (const float*)crops, (bf16_t*)a_patch, image, patch, kpad, nm);
-  else if (in_dtype == 1)
-    hipLaunchKernelGGL(patchify_kernel<_Float16>, grid, block, 0, stream, (const _Float16*)crops, (bf16_t*)a_patch, image, patch, kpad, nm);
-  else if (in_dtype == 2)
-    hipLaunchKernelGGL(patchify_kernel<uint8_t>, grid, block, 0, stream, (const uint8_t*)crops, (bf16_t*)a_patch, image, patch, kpad, nm);
-  else
-    return hipErrorInvalidValue;
+  const size_t lds = (size_t)3 * patch * image * 2;                 // bf16 image rows of one patch row
+  const int esz = in_dtype == 0 ? 4 : (in_dtype == 1 ? 2 : 1);
+  // 16-B loads need every image row to start on a 16-B boundary: rows are `image` elements apart from an aligned base
+  const bool vec = (image * esz) % 16 == 0 && ((uintptr_t)crops & 15) == 0 && lds <= 64 * 1024;
+  const bool kp = kpad == (3 * patch * patch + 127) / 128 * 128;
+#define LAUNCH_PATCHIFY(T)                                                                                                     \
+  do {                                                                                                                         \
+    if (vec && kp && patch == 14) hipLaunchKernelGGL((patchify_kernel<T, 14>), grid, block, lds, stream, (const T*)crops, (bf16_t*)a_patch, image, nm); \
+    else if (vec && kp && patch == 16) hipLaunchKernelGGL((patchify_kernel<T, 16>), grid, block, lds, stream, (const T*)crops, (bf16_t*)a_patch, image, nm); \
+    else if (vec && kp && patch == 32) hipLaunchKernelGGL((patchify_kernel<T, 32>), grid, block, lds, stream, (const T*)crops, (bf16_t*)a_patch, image, nm); \
+    else hipLaunchKernelGGL(patchify_scalar_kernel<T>, grid, block, 0, stream, (const T*)crops, (bf16_t*)a_patch, image, patch, kpad, nm); \
+  } while (0)
+  if (in_dtype == 0) LAUNCH_PATCHIFY(float);
+  else if (in_dtype == 1) LAUNCH_PATCHIFY(_Float16);
+  else if (in_dtype == 2) LAUNCH_PATCHIFY(uint8_t);
+  else return hipErrorInvalidValue;
+#undef LAUNCH_PATCHIFY
   return hipGetLastError();
 }
 
@@ -237,9 +350,22 @@ hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float*
                            const float* beta, void* x, float* stats, int n_crops, int n_tok, int width, float eps,
                            hipStream_t stream) {
   if (width % 8 != 0 || width > LN_MAX_CHUNKS * 512) return hipErrorInvalidValue;
-  const int n_rows = n_crops * n_tok;
-  hipLaunchKernelGGL(embed_ln_pre_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, stream, (const bf16_t*)patch_emb, cls,
-                     pos, gamma, beta, (bf16_t*)x, stats, n_rows, n_tok, width, eps);
+  // crops per wave: enough rows to pay for the per-wave constants, enough waves to fill the chip
+  const int cpw = n_crops >= 2048 ? 16 : (n_crops >= 256 ? 8 : (n_crops >= 32 ? 2 : 1));
+  const int waves_per_tok = (n_crops + cpw - 1) / cpw;
+  const long long waves = (long long)n_tok * waves_per_tok;
+  const dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  const int nch = (width + 511) / 512;
+#define LAUNCH_LN_PRE(N)                                                                                                  \
+  hipLaunchKernelGGL(embed_ln_pre_kernel<N>, grid, block, 0, stream, (const bf16_t*)patch_emb, cls, pos, gamma, beta, (bf16_t*)x, \
+                     stats, n_crops, n_tok, width, eps, cpw, waves_per_tok)
+  switch (nch) {
+    case 1: LAUNCH_LN_PRE(1); break;
+    case 2: LAUNCH_LN_PRE(2); break;
+    case 3: LAUNCH_LN_PRE(3); break;
+    default: LAUNCH_LN_PRE(4); break;
+  }
+#undef LAUNCH_LN_PRE
   return hipGetLastError();
 }
 

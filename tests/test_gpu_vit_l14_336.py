@@ -55,7 +55,9 @@ def test_vit_l14_336_matches_fp32_oracle(tower, gpu, precision):
     assert omc.max().item() < COS_TOL, omc
     rd = one_minus_cos(xl.flatten(1), x_last.flatten(1))                     # residual stream behind the LAST block, every token
     print(f"{ARCH} {precision} last-block residual 1-cos:", rd)
-    assert rd.max().item() < 5e-4, rd
+    # bf16: half the embedding budget.  e4m3 operands (no reference mode to match): the whole budget --
+    # measured 5.6e-4 at 577 tokens (4.9-5.9e-4 at 257), i.e. the operand rounding of 96 e4m3 GEMMs, not a function of the token count
+    assert rd.max().item() < (5e-4 if precision == "bf16" else COS_TOL), rd
 
 
 def test_vit_l14_336_batch_properties(tower, gpu):
