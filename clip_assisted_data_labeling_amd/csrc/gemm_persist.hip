@@ -223,9 +223,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   do {                                                                                      \
     const int sel_ = __builtin_amdgcn_readfirstlane(relax > 0 ? relax_sel : 0);             \
     relax = relax > 0 ? relax - 1 : 0;                                                      \
-    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lvm8_%=\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Lvm24_%=\n\t"          \
-                 "s_waitcnt vmcnt(25)\n\ts_branch .Lvmend_%=\n.Lvm24_%=:\n\ts_waitcnt vmcnt(24)\n\ts_branch .Lvmend_%=\n"       \
-                 ".Lvm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lvmend_%=:" : : "s"(sel_) : "memory", "scc");                                  \
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lvm8_%=\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Lvma_%=\n\t"          \
+                 "s_waitcnt vmcnt(%2)\n\ts_branch .Lvmend_%=\n.Lvma_%=:\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lvmend_%=\n"       \
+                 ".Lvm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lvmend_%=:" : : "s"(sel_), "n"(RELAX_A), "n"(RELAX_B) : "memory", "scc");    \
   } while (0)
 #define ISSUE_WAH0(b, ablk, wblk, o00, o01, kbyte)                                          \
   do { ISSUE_W(b, wblk, kbyte); ISSUE_AH0(b, ablk, o00, o01, kbyte); } while (0)
@@ -253,6 +253,11 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   BARRIER();
   int relax = 0;                             // waits of the coming tile that may leave the previous tile's stores in flight
   const int relax_sel = (EPI == EPI_RESID && w < 4) ? 2 : 1;   // those waves also store the row statistics: 17 stores, not 16
+  // what may stay outstanding at the first two waits of a tile: the 8 newest pieces + the previous tile's 16 (17) row stores
+  // + the column-sum / bias pieces issued at the top of the tile (2 for EPI_LNFOLD, 1 for EPI_RESID; EPI_STORE_BF16 issues
+  // one only with a bias: counted as none, i.e. that wait is one piece stricter than it need be)
+  constexpr int CB_PIECES = EPI == EPI_LNFOLD ? 2 : (EPI == EPI_RESID ? 1 : 0);
+  constexpr int RELAX_A = 24 + CB_PIECES, RELAX_B = 25 + CB_PIECES;
 
   for (;;) {
     f32x4_t acc[8][4];
@@ -261,7 +266,36 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 #ifdef CLIPENC_DIAG
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 4] = __builtin_amdgcn_s_memtime(); }
 #endif
-    if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
+    // Column sums and biases of this tile's 64 columns per wave, staged into the wave's (idle until the epilogue) 2-KiB image
+    // by LDS-DMA: [0, 256) colsum, [1024, 1280) bias (lanes 16..63 fetch duplicates).  As global loads at the head of the
+    // epilogue they were the only VMEM loads there, and waiting for a load means waiting for every older DMA piece of the
+    // next tile as well (vmcnt retires in order): 0.5-0.6 us per tile with the pipeline drained (tools/gemm_tile_boundary.py).
+    // An extra piece only makes the counted waits below stricter (one more piece must have landed), never weaker; it has
+    // retired before the epilogue because every path issues >= 8 younger pieces and passes a vmcnt(8) behind them.
+    if (EPI == EPI_LNFOLD || (EPI == EPI_RESID) || p.bias) {
+      const unsigned coff = (unsigned)(cur.n0 + wc * 64) * 4u + (unsigned)(lane & 15) * 16u;
+      if (EPI == EPI_LNFOLD) glds16_at((const char*)p.colsum, coff, lds0 + (unsigned)(TR_OFF + w * 2048));
+      glds16_at((const char*)p.bias, coff, lds0 + (unsigned)(TR_OFF + w * 2048 + 1024));
+    }
+    if (wr == 1) {
+      if constexpr (EPI == EPI_LNFOLD) {
+        // (mean, rstd) of this tile's 256 rows from the raw partial sums that the DMA left in AUX[buf] a tile ago (retired and
+        // behind a barrier since) -- by the second wave row, which would otherwise only wait here for the first row's read
+        // section; at the head of the epilogue this cost a workgroup barrier and 0.4 us per tile.  The tile's barriers order
+        // these writes before the epilogue's reads.
+        char* raw = smem + AUX_OFF + (tile_iter & 1) * 8192;
+        const int row = tid - 256;
+        float s_ = 0.f, ss_ = 0.f;
+        for (int part = 0; part < p.stats_in_parts; ++part) {
+          const float2 t = *(const float2*)(raw + part * 2048 + row * 8);
+          s_ += t.x; ss_ += t.y;
+        }
+        const float mean = s_ * p.inv_width;
+        const float var = fmaxf(ss_ * p.inv_width - mean * mean, 0.f);
+        *(float2*)(raw + row * 8) = float2{mean, rsqrtf(var + p.eps)};
+      }
+      BARRIER();                             // second wave row runs half a phase behind
+    }
 
     if (kend > 256) {
       // first stage pair of the tile: every accumulator starts from the constant 0 in its first MFMA
@@ -366,8 +400,6 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     const int tw_sw = frow_e & 7;
     const int tr_base = (lane_e >> 3) * 128 + (((lane_e & 7) ^ (lane_e >> 3)) << 4);   // + 1024 for rows 8..15
     const int row_l = lane_e >> 3;
-    const int q4 = qd * 4;
-    const int ncol0 = cur.n0 + wc * 64 + q4;         // + nt*16
     const int mw0 = cur.m0 + wr * 128;               // first row of the wave tile
     // Row stores and residual loads go through buffer descriptors that cover exactly the tile's existing rows: the hardware
     // drops (stores) / zero-fills (loads) the rows of a ragged last tile, so the blocks below are straight-line code
@@ -378,34 +410,22 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     const __amdgpu_buffer_rsrc_t rrsrc = __builtin_amdgcn_make_buffer_rsrc((char*)p.resid + (size_t)cur.m0 * row_bytes, 0, (int)tile_bytes, 0x00020000);
     const unsigned lcol_b = (unsigned)(cur.n0 + wc * 64 + (lane_e & 7) * 8) * 2u;              // byte column of the lane's 16-B piece
 
-    if constexpr (EPI == EPI_LNFOLD) {
-      // (mean, rstd) of the tile's rows from the raw partial sums that the DMA left in AUX[buf]
-      char* raw = smem + AUX_OFF + (tile_iter & 1) * 8192;
-      if (tid < 256) {
-        float s = 0.f, ss = 0.f;
-        for (int part = 0; part < p.stats_in_parts; ++part) {
-          const float2 t = *(const float2*)(raw + part * 2048 + tid * 8);
-          s += t.x; ss += t.y;
-        }
-        const float mean = s * p.inv_width;
-        const float var = fmaxf(ss * p.inv_width - mean * mean, 0.f);
-        *(float2*)(raw + tid * 8) = float2{mean, rsqrtf(var + p.eps)};
-      }
-      __syncthreads();
-    }
-
+    // column sums / biases of the wave's columns: from the image the DMA filled at the top of the tile (no VMEM load here)
     f32x4_t cs[4], bs[4];
     if constexpr (EPI == EPI_LNFOLD) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) cs[nt] = *(const f32x4_t*)(p.colsum + ncol0 + nt * 16);
+      for (int nt = 0; nt < 4; ++nt) cs[nt] = *(const f32x4_t*)(tr + nt * 64 + qd * 16);
     }
     if (EPI != EPI_STORE_BF16 || p.bias) {
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(p.bias + ncol0 + nt * 16);
+      for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(tr + 1024 + nt * 64 + qd * 16);
     } else {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) bs[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     }
+#ifdef CLIPENC_DIAG
+    if (p.dbg && tid == 0) p.dbg[(size_t)idx * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     // residual rows, 8 x 16 B per lane in flight (four 16-row blocks ahead of their use)
     uint4 rres[8];
@@ -489,6 +509,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       const unsigned oa = (unsigned)(wr * 128 + mt * 16 + row_l) * row_bytes + lcol_b;
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v0), orsrc, oa, 0, 0);
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v1), orsrc, oa + 8 * row_bytes, 0, 0);
+#ifdef CLIPENC_DIAG
+      if (mt == 0 && p.dbg && tid == 0) p.dbg[(size_t)idx * 8 + 7] = __builtin_amdgcn_s_memrealtime();   // first 16-row block out: column sums / bias / residual have arrived
+#endif
     }
 
     if constexpr (EPI == EPI_RESID) {
