@@ -1051,6 +1051,16 @@ int clipenc_op_gemm_lnfold(const void* a_dev, const void* w_dev, int m, int n, i
   return 0;
 }
 
+int clipenc_op_gemm_resid(const void* a_dev, const void* w_dev, int m, int n, int k, const float* bias_dev, void* x_inout_dev,
+                          float* stats_out_dev, int stats_ld, unsigned long long* stamps_dev, void* stream) {
+  GemmParams p{};
+  p.A = a_dev; p.lda = k; p.W = w_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = x_inout_dev; p.ldo = n;
+  p.bias = bias_dev; p.resid = x_inout_dev; p.stats_out = stats_out_dev; p.stats_ld = stats_ld; p.dbg = stamps_dev;
+  hipError_t err = ce_gemm_nt(p, CE_DT_BF16, EPI_RESID, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("gemm_resid failed: %s", hipGetErrorString(err));
+  return 0;
+}
+
 int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n, int k, void* out_dev,
                               unsigned long long* stamps_dev, void* stream) {
   GemmParams p{};

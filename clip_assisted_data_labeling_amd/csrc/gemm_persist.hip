@@ -180,7 +180,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
                          _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[i] = *(const frag_t*)(smem + (b) * BUF + a_rd0 + ((half) * 8 + i * 2) * 1024);  \
                          _Pragma("unroll") for (int i = 0; i < 4; ++i) fa[4 + i] = *(const frag_t*)(smem + (b) * BUF + a_rd1_ + ((half) * 8 + i * 2) * 1024); }
   // ZC: the first MFMA of every accumulator of a tile takes the constant 0 as its C operand instead of a zeroed register
-  // (128 v_mov per wave and tile with the matrix pipe idle otherwise)
+  // (128 v_mov per wave and tile with the matrix pipe idle otherwise) -- or, for EPI_RESID, the BIAS of its four columns:
+  // the sum starts from the bias and the epilogue has no bias add
+#define CINIT(j) (EPI == EPI_RESID ? binit[(j)] : f32x4_t{0.f, 0.f, 0.f, 0.f})
 // Issue order: serpentine over the 4 x 4 block (j runs 0..3, 3..0, ...), so that exactly ONE operand register set changes
 // between consecutive MFMAs; with j restarting at 0 both srcA and srcB changed at every fourth.  A pure stream of this
 // block on all CUs (tools/probes/power_probe.py, PROBE_ONLY=order) runs 2.0 % faster at the same board power.
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                      \
       const int j = (GEMM_MMA_ORDER && (i & 1)) ? 3 - j_ : j_;                              \
       acc[(half) * 4 + i][j] = mfma16(fb[kh * 4 + j], fa[kh * 4 + i],                                               \
-                                   ((ZC) && kh == 0) ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[(half) * 4 + i][j]);          \
+                                   ((ZC) && kh == 0) ? CINIT(j) : acc[(half) * 4 + i][j]);                            \
     }                                                                                       \
   } while (0)
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
@@ -247,6 +249,12 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   // ---- cold prologue of the first tile ----
   int tile_iter = 0;
   STAGE_STATS(0, cur.m0);
+  // EPI_RESID: the bias of a tile's 256 columns is ONE piece (1 KiB), fetched by wave 0 into the free half of AUX a tile ahead
+#define STAGE_BIAS(n0v)                                                                     \
+  do {                                                                                      \
+    if (EPI == EPI_RESID && w == 0) glds16_at((const char*)p.bias, (unsigned)(n0v) * 4u + (unsigned)lane * 16u, lds0 + (unsigned)(AUX_OFF + 8192)); \
+  } while (0)
+  STAGE_BIAS(cur.n0);
   ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 0); ISSUE_AH1(0, Ablk, aoff10, aoff11, 0);
   ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 128);           // A(half 1) of stage 1 follows in PA of stage 0
   VM8;                                                      // W and A(half 0) of stage 0 have landed
@@ -254,9 +262,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   int relax = 0;                             // waits of the coming tile that may leave the previous tile's stores in flight
   const int relax_sel = (EPI == EPI_RESID && w < 4) ? 2 : 1;   // those waves also store the row statistics: 17 stores, not 16
   // what may stay outstanding at the first two waits of a tile: the 8 newest pieces + the previous tile's 16 (17) row stores
-  // + the column-sum / bias pieces issued at the top of the tile (2 for EPI_LNFOLD, 1 for EPI_RESID; EPI_STORE_BF16 issues
-  // one only with a bias: counted as none, i.e. that wait is one piece stricter than it need be)
-  constexpr int CB_PIECES = EPI == EPI_LNFOLD ? 2 : (EPI == EPI_RESID ? 1 : 0);
+  // + the column-sum / bias pieces issued at the top of the tile (2 for EPI_LNFOLD; EPI_STORE_BF16 issues one only with a
+  // bias: counted as none, i.e. that wait is one piece stricter than it need be; EPI_RESID stages its bias a tile ahead)
+  constexpr int CB_PIECES = EPI == EPI_LNFOLD ? 2 : 0;
   constexpr int RELAX_A = 24 + CB_PIECES, RELAX_B = 25 + CB_PIECES;
 
   for (;;) {
@@ -272,7 +280,11 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     // next tile as well (vmcnt retires in order): 0.5-0.6 us per tile with the pipeline drained (tools/gemm_tile_boundary.py).
     // An extra piece only makes the counted waits below stricter (one more piece must have landed), never weaker; it has
     // retired before the epilogue because every path issues >= 8 younger pieces and passes a vmcnt(8) behind them.
-    if (EPI == EPI_LNFOLD || (EPI == EPI_RESID) || p.bias) {
+    f32x4_t binit[4];                        // EPI_RESID: bias of the lane's columns = the first MFMAs' C operand
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) binit[nt] = *(const f32x4_t*)(smem + AUX_OFF + 8192 + (wc * 64 + nt * 16 + (lane >> 4) * 4) * 4);
+    } else if (EPI == EPI_LNFOLD || p.bias) {
       const unsigned coff = (unsigned)(cur.n0 + wc * 64) * 4u + (unsigned)(lane & 15) * 16u;
       if (EPI == EPI_LNFOLD) glds16_at((const char*)p.colsum, coff, lds0 + (unsigned)(TR_OFF + w * 2048));
       glds16_at((const char*)p.bias, coff, lds0 + (unsigned)(TR_OFF + w * 2048 + 1024));
@@ -309,7 +321,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 4; ++j) acc[i][j] = CINIT(j);
     }
     // ---- last two stages: the DMA crosses into the next tile ----
     const int nidx = idx + G;
@@ -336,13 +348,15 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       const int kb = kend - 256;
       // ONE code path: without a next tile the DMA harmlessly re-fetches this tile's first stages into dead
       // buffers (two variants of this block made hipcc spill ~270 VGPRs)
-      if (has_next) STAGE_STATS((tile_iter + 1) & 1, nxt.m0);
+      if (has_next) { STAGE_STATS((tile_iter + 1) & 1, nxt.m0); STAGE_BIAS(nxt.n0); }
       STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Anext, Wnext, aoff00, aoff01, 0));
       aoff10 = AOFF_B(arow_b + 64); aoff11 = AOFF_B(arow_b + 72);
       STAGE(1, VM8, ISSUE_AH1(0, Anext, aoff10, aoff11, 0), ISSUE_WAH0(1, Anext, Wnext, aoff00, aoff01, 128));
     }
 #undef AOFF_B
-    if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
+    // (EPI_THRESH re-aligns the two wave rows here; the other epilogues first issue their residual loads and read their
+    //  column constants -- wave-private work -- and re-align in front of the first 16-row block)
+    if (EPI == EPI_THRESH && wr == 0) BARRIER();
 #ifdef CLIPENC_DIAG
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 5] = __builtin_amdgcn_s_memtime(); }
 #endif
@@ -400,7 +414,6 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     const int tw_sw = frow_e & 7;
     const int tr_base = (lane_e >> 3) * 128 + (((lane_e & 7) ^ (lane_e >> 3)) << 4);   // + 1024 for rows 8..15
     const int row_l = lane_e >> 3;
-    const int mw0 = cur.m0 + wr * 128;               // first row of the wave tile
     // Row stores and residual loads go through buffer descriptors that cover exactly the tile's existing rows: the hardware
     // drops (stores) / zero-fills (loads) the rows of a ragged last tile, so the blocks below are straight-line code
     // without per-row exec-mask branches.  Descriptors are built from wave-uniform values only (SGPRs, no waterfall loop).
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) cs[nt] = *(const f32x4_t*)(tr + nt * 64 + qd * 16);
     }
-    if (EPI != EPI_STORE_BF16 || p.bias) {
+    if (EPI == EPI_LNFOLD || (EPI == EPI_STORE_BF16 && p.bias)) {
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt) bs[nt] = *(const f32x4_t*)(tr + 1024 + nt * 64 + qd * 16);
     } else {
@@ -427,17 +440,34 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     if (p.dbg && tid == 0) p.dbg[(size_t)idx * 8 + 6] = __builtin_amdgcn_s_memrealtime();
 #endif
 
-    // residual rows, 8 x 16 B per lane in flight (four 16-row blocks ahead of their use)
-    uint4 rres[8];
+    // residual rows: ALL 16 x 16 B per lane of the wave's 128 rows are requested at once, as soon as the last MFMA phase has
+    // released the fragment registers and before the wave rows re-align.  They come from HBM (the residual stream is 1 GB,
+    // written a whole block of kernels ago) and, behind the 8 DMA pieces of the next tile in the in-order vmcnt queue, take
+    // ~2 us; with 8 in flight and the rest requested four blocks ahead the epilogue paid that latency more than twice
+    // (tools/gemm_tile_boundary.py: 7.4 us per tile for out-proj / FC2 against 2.0 us for QKV).
+    uint4 rres[16];
 #define LOAD_RES(k)                                                                           \
   do {                                                                                        \
     const unsigned off_ = (unsigned)(wr * 128 + (k) * 8 + row_l) * row_bytes + lcol_b;        \
-    rres[(k) & 7] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off_, 0, 0)); \
+    rres[(k)] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rrsrc, off_, 0, 0)); \
   } while (0)
+    // EPI_RESID: the 0/1 column selectors of the residual MFMA as A operands -- lane (c = lane & 15, k group qd) holds
+    // k = 8 qd .. 8 qd + 7 of selector row c: e_lo[c][k] = (k == c), e_hi[c][k] = (k == 16 + c) -- and the all-ones operand
+    frag_t e_lo, e_hi, ones8;
     if constexpr (EPI == EPI_RESID) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) LOAD_RES(k);
+      for (int k = 0; k < 16; ++k) LOAD_RES(k);
+      u32x4_t lo, hi;
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        const int k0 = 8 * qd + 2 * pp;
+        lo[pp] = (k0 == frow_e ? 0x3f80u : 0u) | (k0 + 1 == frow_e ? 0x3f800000u : 0u);
+        hi[pp] = (k0 == 16 + frow_e ? 0x3f80u : 0u) | (k0 + 1 == 16 + frow_e ? 0x3f800000u : 0u);
+      }
+      e_lo = __builtin_bit_cast(frag_t, lo); e_hi = __builtin_bit_cast(frag_t, hi);
+      ones8 = __builtin_bit_cast(frag_t, u32x4_t{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u});
     }
+    if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
 
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
@@ -471,34 +501,36 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
           pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         }
       } else {
-        // residual rows of this 16-row block: row-major image -> fragment layout
-        *(uint4*)(tr + tr_base) = rres[(mt * 2) & 7];
-        *(uint4*)(tr + 1024 + tr_base) = rres[(mt * 2 + 1) & 7];
-        // (no wait: the LDS serves one wave's accesses in order, so the fragment-layout reads below see these writes)
-        if (mt + 4 < 8) { LOAD_RES(mt * 2 + 8); LOAD_RES(mt * 2 + 9); }
-        float s = 0.f, ss = 0.f;
+        // Residual add and row statistics on the MATRIX pipe, which idles in the epilogue (as VALU work -- unpack, add, two
+        // dot products per packed pair, cross-lane sums -- this block was 75 instructions per wave and the epilogue of
+        // out-proj / FC2 took 7.4 us per tile against 2.0 us for QKV: tools/gemm_tile_boundary.py).
+        // (1) the block's residual rows go through the row-major image as before, but are read back as an MFMA B operand:
+        //     lane (row frow, k group qd) takes the whole 16-B piece 4 h + qd of its row (8 consecutive columns), and
+        //     D[c][row] += sum_k E[c][k] R[row][32 h + k] with the 0/1 selector E (k == c, or k == 16 + c for the odd column
+        //     block) adds exactly R[row][col] to the accumulator that already holds bias + A.W^T.
+        *(uint4*)(tr + tr_base) = rres[mt * 2];
+        *(uint4*)(tr + 1024 + tr_base) = rres[mt * 2 + 1];
+        // (no wait: the LDS serves one wave's accesses in order)
+        const frag_t r0 = *(const frag_t*)(tr + frow_e * 128 + ((qd ^ tw_sw) << 4));
+        const frag_t r1 = *(const frag_t*)(tr + frow_e * 128 + (((4 + qd) ^ tw_sw) << 4));
+        acc[mt][0] = mfma16(e_lo, r0, acc[mt][0]); acc[mt][1] = mfma16(e_hi, r0, acc[mt][1]);
+        acc[mt][2] = mfma16(e_lo, r1, acc[mt][2]); acc[mt][3] = mfma16(e_hi, r1, acc[mt][3]);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-          const uint2 rr = *(const uint2*)TW_ADDR(nt);
-          f32x4_t v = acc[mt][nt] + bs[nt];
-          v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-          v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-          pk[nt] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-          // sum and sum of squares of the ROUNDED values, straight from the packed pairs: v_dot2c_f32_bf16 (products of
-          // bf16 are exact in fp32) instead of unpack + add + multiply-add, a third of the instructions
-          const bf16x2_t p0 = __builtin_bit_cast(bf16x2_t, pk[nt].x), p1 = __builtin_bit_cast(bf16x2_t, pk[nt].y);
-          const bf16x2_t one2 = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
-          s = __builtin_amdgcn_fdot2_f32_bf16(p0, one2, s, false);
-          s = __builtin_amdgcn_fdot2_f32_bf16(p1, one2, s, false);
-          ss = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, ss, false);
-          ss = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, ss, false);
-        }
-        if (mw0 + mt * 16 + frow_e >= p.M) { s = 0.f; ss = 0.f; }
-        s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
-        s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-        if (lane_e < 16)
-          *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + lane_e) * 8) = float2{s, ss};
-        // (in order again: the image may be rewritten right behind the fragment reads)
+        for (int nt = 0; nt < 4; ++nt) pk[nt] = uint2{pack_bf16x2(acc[mt][nt][0], acc[mt][nt][1]), pack_bf16x2(acc[mt][nt][2], acc[mt][nt][3])};
+        // (2) sum and sum of squares of the ROUNDED row: the packed pairs of two column blocks are 8 distinct columns per lane,
+        //     i.e. a valid operand (any column order sums the same): ones . P^T gives the row sum in every register of the
+        //     row's lanes, P . P^T has the row's sum of squares on its diagonal (products of bf16 are exact in fp32)
+        const frag_t p01 = __builtin_bit_cast(frag_t, u32x4_t{pk[0].x, pk[0].y, pk[1].x, pk[1].y});
+        const frag_t p23 = __builtin_bit_cast(frag_t, u32x4_t{pk[2].x, pk[2].y, pk[3].x, pk[3].y});
+        f32x4_t d1 = mfma16(ones8, p01, f32x4_t{0.f, 0.f, 0.f, 0.f});
+        d1 = mfma16(ones8, p23, d1);
+        f32x4_t d2 = mfma16(p01, p01, f32x4_t{0.f, 0.f, 0.f, 0.f});
+        d2 = mfma16(p23, p23, d2);
+        // D[m][row]: lane (row, qd) register i is m = 4 qd + i, so the diagonal sits in lane qd == row / 4, register row % 4
+        const int di = frow_e & 3;
+        const float ssq = di == 0 ? d2[0] : (di == 1 ? d2[1] : (di == 2 ? d2[2] : d2[3]));
+        if (qd == (frow_e >> 2))
+          *(float2*)(smem + AUX_OFF + ((size_t)wc * 256 + wr * 128 + mt * 16 + frow_e) * 8) = float2{d1[0], ssq};
       }
       // fragment layout -> row-major image -> two 16-B-per-lane stores of 8 full rows each
 #pragma unroll

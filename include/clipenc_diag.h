@@ -20,6 +20,10 @@ int clipenc_op_gemm_nt_stamps(const void* a_dev, const void* w_dev, int m, int n
 int clipenc_op_gemm_lnfold(const void* a_dev, const void* w_dev, int m, int n, int k, const float* colsum_dev,
                            const float* bias_dev, const float* stats_dev, int parts, int stats_ld, int act, void* out_dev,
                            unsigned long long* stamps_dev, void* stream);
+/* The residual GEMM on its own (out-projection / FC2 of a block): x += A.W^T + bias in place (bf16), row statistics of the
+ * rounded rows to stats_out_dev [n / 256][stats_ld][2]; stamps_dev may be NULL. */
+int clipenc_op_gemm_resid(const void* a_dev, const void* w_dev, int m, int n, int k, const float* bias_dev, void* x_inout_dev,
+                          float* stats_out_dev, int stats_ld, unsigned long long* stamps_dev, void* stream);
 #ifdef __cplusplus
 }
 #endif
