@@ -564,6 +564,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary block (fp8 step, configs[4] dedup, ViT-L-14-336 step, JPEG-to-embeddings driver rate)")
+    ap.add_argument("--secondary", default="fp8,dedup,l14_336,e2e",
+                    help="which secondary measurements to append (comma list of fp8, dedup, l14_336, e2e); the rocprofv3 passes of "
+                         "tools/profile_round.sh keep only dedup (no loader worker processes under the profiler)")
     ap.add_argument("--no-power-ceiling", action="store_true",
                     help="skip roofline.power_capped_mfma_stream (0.35 s of pure MFMA; tools/profile_round.sh leaves it out of the rocprofv3 passes)")
     ap.add_argument("--job-images", type=int, default=0,
@@ -724,17 +727,23 @@ def main():
             ceil["frac"] = round(achieved / ceil["value"], 4) if ceil["value"] else None     # dominant kernel / that ceiling
             line["roofline"]["power_capped_mfma_stream"] = ceil
         if world == 1 and not args.no_secondary and not fp8:
-            sec = {"fp8_step": fp8_step(vit, reg, crops, cfg, n_img)}
+            want = set(args.secondary.split(","))
+            sec = {}
+            if "fp8" in want:
+                sec["fp8_step"] = fp8_step(vit, reg, crops, cfg, n_img)
             del crops
             vit.close()
             torch.cuda.empty_cache()
-            sec["dedup_100k"] = dedup_100k(dev)
-            sec["vit_l14_336"] = vit_l14_336_step(dev, Ws, bs)
-            torch.cuda.empty_cache()
-            try:
-                sec["embed_e2e"] = embed_e2e(dev)
-            except Exception as exc:                                   # host-side (loader workers, /tmp): never lose the line to it
-                sec["embed_e2e"] = {"error": f"{type(exc).__name__}: {exc}"}
+            if "dedup" in want:
+                sec["dedup_100k"] = dedup_100k(dev)
+            if "l14_336" in want:
+                sec["vit_l14_336"] = vit_l14_336_step(dev, Ws, bs)
+                torch.cuda.empty_cache()
+            if "e2e" in want:
+                try:
+                    sec["embed_e2e"] = embed_e2e(dev)
+                except Exception as exc:                               # host-side (loader workers, /tmp): never lose the line to it
+                    sec["embed_e2e"] = {"error": f"{type(exc).__name__}: {exc}"}
             line["secondary"] = sec
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, Ws, bs)

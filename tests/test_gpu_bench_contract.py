@@ -35,6 +35,17 @@ def test_single_gpu_line_has_the_contract_keys(gpu):
     assert "traffic" in r and "kernel" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "images/s" and c["sample"]
+    # the executed-arithmetic fraction next to the reference-count fraction (the last block runs on the class-token rows only)
+    e = d["end_to_end"]
+    assert 0 < e["frac_executed"] < e["frac_of_bf16_peak"] < 1
+    # driver-visible secondary measurements: fp8 arithmetic on the same batch, configs[4], the reference's default model, real data
+    sec = d["secondary"]
+    assert sec["fp8_step"]["dtype"] == "fp8" and sec["fp8_step"]["value"] > 0 and "fp8" in sec["fp8_step"]["dominant_kernel"]
+    assert sec["fp8_step"]["dominant_peak"] == 5033.2 and 0 < sec["fp8_step"]["dominant_frac"] < 1
+    assert sec["dedup_100k"]["pairs_found"] == 1000 and sec["dedup_100k"]["ms"] > 0
+    l336 = sec["vit_l14_336"]
+    assert l336["value"] > 0 and 0 < l336["attention_share_of_step"] < 1 and any(k.startswith("attn_long") for k in l336["kernels_ms_per_step"])
+    assert sec["embed_e2e"].get("images") == 2048 and sec["embed_e2e"]["pt_files_written"] == 2048 and sec["embed_e2e"]["value"] > 0, sec["embed_e2e"]
 
 
 def test_two_ranks_report_the_whole_job(gpu):
