@@ -53,6 +53,11 @@ __device__ __forceinline__ void glds16_at(const char* base, unsigned off, unsign
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(off), "s"(base), "s"(lds_addr) : "memory");
 }
 
+// the 4-byte form: 64 lanes x 4 B -> 256 B of LDS at lds_addr (per-row scales, every lane its own clamped row)
+__device__ __forceinline__ void glds4_at(const char* base, unsigned off, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(off), "s"(base), "s"(lds_addr) : "memory");
+}
+
 struct TileId { int m0, n0; };
 
 __device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n) {
@@ -192,13 +197,13 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   do {                                                                                      \
     const int sel_ = __builtin_amdgcn_readfirstlane(relax > 0 ? 1 : 0);                     \
     relax = relax > 0 ? relax - 1 : 0;                                                      \
-    if constexpr (NST == 16)                                                                \
-      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm8_%=\n\ts_waitcnt vmcnt(24)\n\ts_branch .Lf8end_%=\n"               \
-                   ".Lf8vm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lf8end_%=:" : : "s"(sel_) : "memory", "scc");                            \
-    else                                                                                    \
-      asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm8_%=\n\ts_waitcnt vmcnt(16)\n\ts_branch .Lf8end_%=\n"               \
-                   ".Lf8vm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lf8end_%=:" : : "s"(sel_) : "memory", "scc");                            \
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm8_%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lf8end_%=\n"               \
+                 ".Lf8vm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lf8end_%=:" : : "s"(sel_), "n"(8 + NST + CB_PIECES) : "memory", "scc");    \
   } while (0)
+  // the column constants (weight scales, biases, EPI 2: inverse output scales) of the tile are staged into the wave's image at
+  // the top of the tile (below): those pieces sit between the previous tile's stores and the first waits (the per-row
+  // scale pieces, issued only with per-token scales, are not counted: the wait is then two pieces stricter than need be)
+  constexpr int CB_PIECES = EPI == 2 ? 3 : 2;
 
   // ---- cold prologue of the first tile ----
   ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 0); ISSUE_AH1(0, Ablk, aoff10, aoff11, 0);
@@ -212,6 +217,25 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     i32x8_t fa[4], fb[4];
 
+    // Column constants of this tile's 64 columns per wave and the per-token scales of its 128 rows, by LDS-DMA into the wave's
+    // (idle until the epilogue) 4-KiB image: [0, 256) weight scales, [1024, 1280) biases, [2560, 2816) inverse output scales
+    // (EPI 2), [3584, 4096) per-row scales.  As global loads at the head of the epilogue they made the first block wait for
+    // every older DMA piece of the next tile (vmcnt retires in order) -- see gemm_persist.hip, same change, same argument:
+    // extra pieces only make the counted waits stricter, and they have retired before the epilogue.
+    {
+      int lane_t;                                              // the lane id from the hardware (not kept across the main loop)
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
+      const unsigned coff = (unsigned)(cur.n0 + wc * 64) * 4u + (unsigned)(lane_t & 15) * 16u;
+      const unsigned ti = lds0 + (unsigned)(TR_OFF + w * 4096);
+      glds16_at((const char*)p.scale_w, coff, ti);
+      glds16_at((const char*)p.bias, coff, ti + 1024);
+      if constexpr (EPI == 2) glds16_at((const char*)p.out_inv_scale, coff, ti + 2560);
+      if (p.scale_a) {
+        const int r0 = cur.m0 + wr * 128 + lane_t;
+        glds4_at((const char*)p.scale_a, (unsigned)min(r0, p.M - 1) * 4u, ti + 3584);
+        glds4_at((const char*)p.scale_a, (unsigned)min(r0 + 64, p.M - 1) * 4u, ti + 3840);
+      }
+    }
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
     constexpr bool ZERO_C = ZERO_C_OK;
@@ -279,12 +303,12 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     // pass 1 (keeps registers low): acc <- acc * sw[n] + bias[n] / sa[m], so that pass 2 only multiplies by sa[m]
     float sa[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) sa[mt] = p.scale_a ? p.scale_a[min(mw0 + mt * 32 + r32, p.M - 1)] : 1.0f;
+    for (int mt = 0; mt < 4; ++mt) sa[mt] = p.scale_a ? *(const float*)(tr + 3584 + (mt * 32 + r32) * 4) : 1.0f;
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const int n = nb + (c >> 2) * 32 + (c & 3) * 8 + h * 4;
-      const f32x4_t sw = *(const f32x4_t*)(p.scale_w + n);
-      const f32x4_t bs = *(const f32x4_t*)(p.bias + n);
+      const int nl = (c >> 2) * 32 + (c & 3) * 8 + h * 4;          // column within the wave's 64
+      const f32x4_t sw = *(const f32x4_t*)(tr + nl * 4);
+      const f32x4_t bs = *(const f32x4_t*)(tr + 1024 + nl * 4);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const float rsa = __builtin_amdgcn_rcpf(sa[mt]);
@@ -308,9 +332,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     if constexpr (EPI == 2) {
       // fp8 image: [32 rows][80 B pitch] per wave (64 data bytes; the pitch keeps the dword writes 2-way conflicted at most),
       // the wave's 64 inverse output scales behind it
-      float* isc = (float*)(tr + 2560);
-      isc[lane] = p.out_inv_scale[nb + lane];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      const float* isc = (const float*)(tr + 2560);             // (landed by the DMA of the tile's top)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // pass 1's reads of the image are done before it is rewritten
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll

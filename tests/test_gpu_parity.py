@@ -416,6 +416,38 @@ def test_dedup_larger_set_vs_oracle(gpu):
         assert abs(s32[i, j] - thr) < 1e-3, (i, j, s32[i, j])
 
 
+def test_dedup_mid_size_all_tile_classes(gpu):
+    """20 000 x 256 = 79 x 79 tiles = 3 160 upper-triangular tiles on 256 workgroups: 12 XCD-grouped rounds of the host-built
+    tile order plus a tail, full 8 x 4 super-blocks, diagonal and edge ones (dedup_tile_order).  1 500 planted pairs at uniformly
+    random positions (i, j) hit every class of tile; the pair set must equal a brute-force fp32 search on the device outside
+    the fp16-ulp band at the threshold."""
+    g = torch.Generator(device=gpu).manual_seed(11)
+    n, d, planted, thr = 20_000, 256, 1500, 0.9
+    e = torch.randn(n, d, device=gpu, generator=g)
+    idx = torch.randperm(n, device=gpu, generator=g)[:2 * planted]
+    a, b = idx[:planted], idx[planted:]
+    e[b] = e[a] + 0.2 * torch.randn(planted, d, device=gpu, generator=g)       # cos ~ 0.98
+    e16 = e.half()
+    c, p, v = _run_dedup(gpu, e16, thr, capacity=8192)
+    # brute force: the oracle's half normalisation, fp32 products, row blocks of 2 000
+    x = e16.float()
+    nrm = x.pow(2).sum(-1).sqrt().half().float()
+    xh = (x / nrm[:, None]).half().float()
+    gold, near = set(), set()
+    for r0 in range(0, n, 2000):
+        sblk = xh[r0:r0 + 2000] @ xh.T
+        ii, jj = torch.nonzero(sblk > thr - 1e-3, as_tuple=True)
+        for i, j, val in zip((ii + r0).tolist(), jj.tolist(), sblk[ii, jj].tolist()):
+            if i < j:
+                (gold if val > thr + 1e-3 else near).add((i, j))
+    got = {tuple(r) for r in p.tolist()}
+    assert c == len(got) and len(gold) >= planted - 5
+    assert gold <= got, sorted(gold - got)[:5]                   # nothing clearly above the threshold is missed
+    assert got <= gold | near, sorted(got - gold - near)[:5]     # nothing clearly below it is reported
+    want = {(min(i, j), max(i, j)) for i, j in zip(a.tolist(), b.tolist())}
+    assert len(want & got) >= planted - 5
+
+
 # ------------------------------------------------------------------------------------- measurement support of bench.py
 def test_measurement_probes_contract(gpu):
     """clipenc_clock_probe / clipenc_mfma_stream_probe: the two handle-free entries bench.py uses for `env.inkernel_clock_mhz`
