@@ -437,7 +437,7 @@ def vit_l14_336_step(dev, Ws, bs):
             "kernels_ms_per_step": {k: round(v[0], 3) for k, v in prof.items() if v[0] > 0 and not k.startswith("shape:")}}
 
 
-def embed_e2e(dev, n=2048, size=512, workers=16, batch=256):
+def embed_e2e(dev, n=4096, size=512, workers=16, batch=256):
     """The real-data rate of the embed driver (/root/reference/_1_embed_with_CLIP.py:95-184 -> embed_driver.Feature_Dataset):
     `n` generated JPEG files -> DataLoader workers decode -> GPU crop/resize front end -> ViT-L/14 encoder -> one .pt per image;
     DataLoader start-up included.  JPEG decode runs on the host cores, so this is a property of the box's CPU share too."""
