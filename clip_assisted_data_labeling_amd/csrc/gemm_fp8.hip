@@ -21,6 +21,9 @@
 #include "common.h"
 #include "gemm.h"
 
+#ifndef F8_MMA_ORDER
+#define F8_MMA_ORDER 1
+#endif
 // instantiations with the register room for the peeled zero-C first stage pair (the others spill with it)
 #define ZERO_C_SET(EPI, ACT) ((EPI) == 2 && (ACT) <= 0)
 
@@ -155,10 +158,12 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     __builtin_amdgcn_s_setprio(1);                                                          \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                        \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                           \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                      \
+      const int j = (F8_MMA_ORDER && (i & 1)) ? 1 - j_ : j_;      /* serpentine: one operand register set changes per MFMA (gemm_persist.hip) */ \
       acc[(half) * 2 + i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[kh * 2 + j], fa[kh * 2 + i],      \
                                    ((ZC) && kh == 0) ? zero16 : acc[(half) * 2 + i][j], 0, 0,                        \
                                                                               0, 0x7f7f7f7f, 0, 0x7f7f7f7f);        \
+    }                                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                          \
   } while (0)
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
