@@ -104,7 +104,12 @@ int fcreg_destroy(fcreg_t reg);
 /* Replaces `model(features.float())` (/root/reference/_5_predict_labels.py:135, utils/nn_model.py:38-41).
  * Row i of the input is the concatenation of n_seg segments of seg_len floats found at
  * x_dev + i*row_stride + seg_off[s] (n_seg*seg_len == sizes[0]); a plain [n_rows][in] matrix is
- * n_seg = 1, seg_off = {0}, row_stride = in.   y_dev: float32 [n_rows][sizes[n_layers]]. */
+ * n_seg = 1, seg_off = {0}, row_stride = in.   y_dev: float32 [n_rows][sizes[n_layers]].
+ * Reproducibility: a call is bitwise deterministic, but the score BITS of a row depend on how many rows the call scores: fewer
+ * than 4096 rows run a kernel that sums each neuron's products in input order, 4096 or more the store-scale kernel on the fp32
+ * matrix pipe with another (fixed) summation order.  Both are fp32 throughout and agree within 2e-6 absolute on sigmoid outputs
+ * (tests/test_gpu_fcreg_store.py asserts it); a store scored in one pass and re-scored in small batches matches to that
+ * tolerance, not bit for bit.  The north_star tolerance against the reference is 1e-4. */
 int fcreg_forward(fcreg_t reg, const float* x_dev, int n_rows, long row_stride, int n_seg, int seg_len,
                   const int* seg_off, float* y_dev, void* stream);
 
