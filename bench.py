@@ -404,13 +404,15 @@ def fp8_step(vit, reg, crops, cfg, n_img):
 
 
 def vit_l14_336_step(dev, Ws, bs):
-    """The reference's DEFAULT model (/root/reference/_1_embed_with_CLIP.py:190: ViT-L-14-336, 577 tokens) at full size: 128 images
+    """The reference's DEFAULT model (/root/reference/_1_embed_with_CLIP.py:190: ViT-L-14-336, 577 tokens) at full size: 120 images
     x 4 crops of 336 x 336 per step, bf16, fused regressor; images/s and the attention kernel's share of the step."""
     from clip_assisted_data_labeling_amd import vit_config
     from clip_assisted_data_labeling_amd.embedder import HipViT
     from clip_assisted_data_labeling_amd.nn_model import HipRegressor
     cfg = vit_config.ARCHS["ViT-L-14-336"]
-    n_img = 128
+    # 120 images = 480 crops x 577 tokens = 1 082 row tiles: 16.9 / 50.7 / 67.6 rounds of 256 workgroups for the three GEMM widths
+    # (128 images are 1 154 tiles = 18.03 rounds for the residual GEMMs: a nineteenth round with 8 busy CUs)
+    n_img = 120
     vit = HipViT(cfg, vit_config.seeded_state_dict(cfg, 0), dev, chunk_crops=n_img * CROPS_PER_IMAGE)
     reg = HipRegressor([torch.from_numpy(w) for w in Ws], [torch.from_numpy(b) for b in bs], 0.01, dev)
     try:
