@@ -90,6 +90,12 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_void_p]),
     "clipenc_op_gemm_fp8": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                     c_void_p, c_void_p, c_void_p]),
+    "clipenc_op_quant_block_fp8": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "clipenc_op_row_norm_consts": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "clipenc_op_gemm_fp8_lnf": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "clipenc_op_gemm_fp8_resid_q": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                            c_void_p, c_int, c_void_p]),
     "clipenc_forward_tokens": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
 }
 

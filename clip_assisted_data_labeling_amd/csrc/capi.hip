@@ -68,6 +68,7 @@ struct LayerDev8 {                                       // CLIPENC_PREC_FP8: e4
   float *s_qkv, *s_out, *s_fc, *s_proj;
   float* is_hid;                                         // [mlp_dim] 1 / static scale of the MLP hidden columns (folded into w_proj)
   float* is_attn;                                        // [width]   1 / static scale of the attention output (folded into w_out)
+  float *cs_qkv, *cs_fc;                                 // [3 width], [mlp_dim] column sums of the DEQUANTISED LN-folded rows (the folded mean term)
 };
 
 }  // namespace
@@ -75,16 +76,18 @@ struct LayerDev8 {                                       // CLIPENC_PREC_FP8: e4
 // one kind per device kernel, named exactly as rocprofv3 --kernel-trace prints it (template arguments included)
 enum { PK_PATCHIFY = 0, PK_GEMM_PATCH, PK_EMBED_LN_PRE, PK_GEMM_QKV, PK_ATTENTION, PK_GEMM_RESID, PK_GEMM_FC1, PK_HEAD, PK_FCREG,
        PK_SUB_OUT, PK_SUB_FC2,                // PK_SUB_*: the EPI_RESID launches split by shape
-       PK_QUANT_LN, PK_QUANT, PK_GEMM8_QKV, PK_GEMM8_FC1, PK_GEMM8_RESID, PK_SUB8_OUT, PK_SUB8_FC2, PK_COUNT };
+       PK_QUANT_LN, PK_QUANT, PK_GEMM8_QKV, PK_GEMM8_FC1, PK_GEMM8_RESID, PK_SUB8_OUT, PK_SUB8_FC2, PK_QUANT_BLOCK, PK_ROW_CONSTS,
+       PK_COUNT };
 static const char* const kProfileNames[PK_COUNT] = {
     "patchify_kernel<float, 14>", "gemm_persist_kernel<1, -1>", "embed_ln_pre_kernel<2>", "gemm_persist_kernel<2, -1>",
     "attn_stream_kernel<9, 7>", "gemm_persist_kernel<3, -1>", "gemm_persist_kernel<2, 0>", "head_kernel", "fcreg_kernel",
     "shape:out_proj(gemm_persist_kernel<3, -1>)", "shape:fc2(gemm_persist_kernel<3, -1>)",
-    "quant_ln16_kernel<8>", "quant_rows_kernel<unsigned short, false, 2, 4>", "gemm_fp8_kernel<0, -1>",
-    "gemm_fp8_kernel<2, 0>", "gemm_fp8_kernel<1, -1>", "shape:out_proj(gemm_fp8_kernel<1, -1>)",
-    "shape:fc2(gemm_fp8_kernel<1, -1>)"};
-// (template arguments: <EPI, ACT>; FC1 is <2, 0> with QuickGELU and <2, 1> with erf-GELU; the attention name is the
-//  ViT-L/14 instantiation, other token counts use attn_kernel<NKT> / attn_long_kernel<7>; quant_ln16_kernel<width / 128>)
+    "quant_ln16_kernel<8>", "quant_rows_kernel<unsigned short, false, 2, 4>", "gemm_fp8_kernel<0, -1, false>",
+    "gemm_fp8_kernel<2, 0, false>", "gemm_fp8_kernel<1, -1, false>", "shape:out_proj(gemm_fp8_kernel<1, -1, false>)",
+    "shape:fc2(gemm_fp8_kernel<1, -1, false>)", "quant_block_kernel<8>", "row_norm_consts_kernel"};
+// (template arguments: <EPI, ACT> and, fp8, <EPI, ACT, LNF>; FC1 is <2, 0> with QuickGELU and <2, 1> with erf-GELU; the fp8
+//  names above are the unfused tower's (widths over 1024), clipenc_profile_read substitutes the fused tower's; the attention
+//  name is the ViT-L/14 instantiation, other token counts use attn_kernel<NKT> / attn_long_kernel<7>; quant_ln16_kernel<width / 128>)
 
 struct ProfRec { int kind, sub; hipEvent_t a, b; double flops; };
 
@@ -148,7 +151,13 @@ struct clipenc_s {
   uint8_t* a8 = nullptr;                                 // workspace: quantised GEMM operand [T][width] (the e4m3 MLP hidden
                                                          // [T][mlp_dim] lives in the bf16 `hid` buffer)
   float* sa8 = nullptr;                                  //            its per-token scales [T]
+  // fused fp8 tower (width <= 1024): the residual stream's e4m3 block-exponent copy, written by the GEMM that produces the rows
+  uint8_t* x8 = nullptr;                                 // [T][width]
+  uint8_t* xe8 = nullptr;                                // [T][4] exponent bytes
+  float* st8 = nullptr;                                  // [width / 64][Tp][2] partial row statistics
+  float *rr8 = nullptr, *rd8 = nullptr;                  // [Tp] rstd, -mean * rstd
   int ws_precision = -1;
+  bool fp8_unfused = false;                              // diagnostic build: CLIPENC_FP8_UNFUSED=1 runs the separate LayerNorm-quantise pass at every width
   // workspace (sized for `chunk` crops)
   int chunk = 2048, ws_chunk = 0;
   DevBuf ws;
@@ -181,6 +190,10 @@ namespace {
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// The fp8 tower quantises the residual stream inside the GEMM that produces it (block-exponent rows, gemm.h) when a row's
+// exponents fit one dword: width a multiple of 256, at most 1024.  Wider towers run the separate LayerNorm-quantise pass.
+bool fp8_fused(const clipenc_config& g) { return g.width % 256 == 0 && g.width <= 1024; }
+
 // (Re)allocates the workspace of one pass of `chunk` crops at the handle's precision.  Called by clipenc_create,
 // clipenc_set_chunk and clipenc_set_precision only (hipMalloc / hipFree synchronise the device): the encode calls never
 // allocate.
@@ -199,6 +212,9 @@ int ensure_workspace(clipenc_s* e) {
   const size_t o_sc = take(parts * align_up((size_t)c, 256) * 8);
   const bool f8 = e->precision == CLIPENC_PREC_FP8;
   const size_t o_a8 = f8 ? take(T * (size_t)g.width) : 0, o_sa8 = f8 ? take(T * 4) : 0;
+  const bool f8f = f8 && fp8_fused(g);
+  const size_t o_x8 = f8f ? take(T * (size_t)g.width) : 0, o_xe8 = f8f ? take(Tp * 4) : 0;
+  const size_t o_st8 = f8f ? take((size_t)(g.width / 64) * Tp * 8) : 0, o_rr8 = f8f ? take(Tp * 4) : 0, o_rd8 = f8f ? take(Tp * 4) : 0;
   HIP_TRY(hipSetDevice(e->device));
   // allocate the new slab FIRST and swap it in on success: on failure the handle keeps its old, still valid workspace
   // (and the chunk / precision it was sized for), so no pointer ever refers to freed memory
@@ -212,6 +228,8 @@ int ensure_workspace(clipenc_s* e) {
   e->qkv = (bf16_t*)(b + o_qkv); e->attn = (bf16_t*)(b + o_at); e->hid = (bf16_t*)(b + o_h);
   e->stats0 = (float*)(b + o_s0); e->stats_a = (float*)(b + o_sa); e->stats_b = (float*)(b + o_sb); e->stats_c = (float*)(b + o_sc);
   e->a8 = f8 ? (uint8_t*)(b + o_a8) : nullptr; e->sa8 = f8 ? (float*)(b + o_sa8) : nullptr;
+  e->x8 = f8f ? (uint8_t*)(b + o_x8) : nullptr; e->xe8 = f8f ? (uint8_t*)(b + o_xe8) : nullptr;
+  e->st8 = f8f ? (float*)(b + o_st8) : nullptr; e->rr8 = f8f ? (float*)(b + o_rr8) : nullptr; e->rd8 = f8f ? (float*)(b + o_rd8) : nullptr;
   e->ws_chunk = c; e->ws_precision = e->precision;
   return 0;
 }
@@ -240,7 +258,91 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
   pf.end(st);
   const float* stats_in = e->stats0;
   int stats_parts = 1;
+  if (e->precision == CLIPENC_PREC_FP8 && fp8_fused(g) && !e->fp8_unfused) {
+    // Fused fp8 tower.  The residual stream keeps an e4m3 block-exponent copy x8 (+ exponent dwords xe8) next to its bf16 rows:
+    // the out-projection and FC2 GEMMs write it for the rows they produce (EPI_RESID_Q) together with partial row statistics,
+    // and the QKV / FC1 GEMMs read it with the LayerNorm folded into their epilogue (gemm.h: row_r, row_d, colsum) -- gamma sits
+    // in the fp8 weights and beta in the bias, as for bf16.  No pass over the residual stream between the GEMMs; only the
+    // tower's first block is quantised by a kernel of its own, and a one-thread-per-row kernel turns the statistics into
+    // (rstd, -mean * rstd) in front of each consumer.
+    const int Dw = g.width, Mh = g.mlp_dim, sparts = g.width / 64;
+    uint8_t* h8 = (uint8_t*)e->hid;
+    auto run8 = [&](GemmParams& q, int epi, int kind, int sub) -> hipError_t {
+      pf.begin(kind, 2.0 * (double)q.M * (double)q.N * (double)q.K, st, sub);
+      hipError_t err = ce_gemm_fp8(q, epi, st);
+      pf.end(st);
+      return err;
+    };
+    // LayerNorm-folded consumer on M rows of x8, `rstride` rows of the stream apart; row constants `ld_row` floats apart
+    auto lnf = [&](int M, int rstride, const uint8_t* W8, const float* sw, const float* cs, const float* bias, int N, int act, void* out,
+                   int ldo, int epi, const float* out_inv, int ld_row, int kind) -> hipError_t {
+      GemmParams q{};
+      q.A = e->x8; q.lda = rstride * Dw; q.W = W8; q.ldw = Dw; q.M = M; q.N = N; q.K = Dw; q.out = out; q.ldo = ldo; q.bias = bias;
+      q.scale_w = sw; q.colsum = cs; q.act = act; q.out_inv_scale = out_inv;
+      q.a_exp = e->xe8; q.ld_aexp = rstride * 4; q.row_r = e->rr8; q.row_d = e->rd8; q.ld_row = ld_row;
+      return run8(q, epi, kind, -1);
+    };
+    // x += A8 . W8^T + bias on M rows (`rstride` apart); quant: also their x8 / xe8 / statistics
+    auto resid = [&](const uint8_t* A8, int M, int lda, const uint8_t* W8, const float* sw, const float* bias, int K, int rstride,
+                     bool quant, int stats_ld, int sub) -> hipError_t {
+      GemmParams q{};
+      q.A = A8; q.lda = lda; q.W = W8; q.ldw = K; q.M = M; q.N = Dw; q.K = K; q.out = e->x; q.ldo = rstride * Dw; q.bias = bias;
+      q.scale_w = sw; q.act = -1; q.resid = e->x;
+      q.out8 = e->x8; q.ld8 = rstride * Dw; q.out_exp = e->xe8; q.ld_oexp = rstride * 4; q.stats_out = e->st8; q.stats_ld = stats_ld;
+      return run8(q, quant ? EPI_RESID_Q : EPI_RESID, PK_GEMM8_RESID, sub);
+    };
+    auto consts = [&](const float* stats, int parts, int ld, int n) -> hipError_t {
+      pf.begin(PK_ROW_CONSTS, 0.0, st);
+      hipError_t err = ce_row_norm_consts(stats, parts, (size_t)ld, n, Dw, g.ln_eps, e->rr8, e->rd8, 1, st);
+      pf.end(st);
+      return err;
+    };
+    if (n_layers > 0) {
+      pf.begin(PK_QUANT_BLOCK, 0.0, st);
+      HIP_TRY(ce_quant_block_fp8(e->x, (size_t)Dw, e->x8, (size_t)Dw, e->xe8, 4, nullptr, T, Dw, st));
+      pf.end(st);
+    }
+    const float* st_in = e->stats0;
+    int parts_in = 1;
+    for (int l = 0; l < n_layers; ++l) {
+      const LayerDev& L = e->layers[l];
+      const LayerDev8& Q = e->layers8[l];
+      const bool last = l == n_layers - 1;
+      HIP_TRY(consts(st_in, parts_in, Tp, T));
+      if (cls_only_last && last) {
+        // LAST block on the class-token rows only (see the bf16 branch below for the argument): K | V for every token, then Q,
+        // attention, out-proj and the MLP on the c CLS rows, which stay where they are (row stride = tokens rows) in x, x8 and xe8
+        const int stride = e->tokens;
+        const int Tpc = (int)align_up((size_t)c, 256);
+        HIP_TRY(lnf(T, 1, Q.w_qkv + (size_t)Dw * Dw, Q.s_qkv + Dw, Q.cs_qkv + Dw, L.b_qkv + Dw, 2 * Dw, -1, e->qkv + Dw, 3 * Dw,
+                    EPI_STORE_BF16, nullptr, 1, PK_GEMM8_QKV));
+        HIP_TRY(lnf(c, stride, Q.w_qkv, Q.s_qkv, Q.cs_qkv, L.b_qkv, Dw, -1, e->qkv, stride * 3 * Dw, EPI_STORE_BF16, nullptr, stride,
+                    PK_GEMM8_QKV));
+        pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * dD, st);
+        HIP_TRY(ce_attention(e->qkv, e->a8, c, e->tokens, g.width, g.heads, Q.is_attn, 1, st));   // O of rows 0..31 of every crop, e4m3
+        pf.end(st);
+        HIP_TRY(resid(e->a8, c, stride * Dw, Q.w_out, Q.s_out, L.b_out, Dw, stride, true, Tpc, PK_SUB8_OUT));
+        HIP_TRY(consts(e->st8, sparts, Tpc, c));               // compact: constants of CLS row i at [i]
+        HIP_TRY(lnf(c, stride, Q.w_fc, Q.s_fc, Q.cs_fc, L.b_fc, Mh, g.act, h8, Mh, EPI_STORE_FP8, Q.is_hid, 1, PK_GEMM8_FC1));
+        HIP_TRY(resid(h8, c, Mh, Q.w_proj, Q.s_proj, L.b_proj, Mh, stride, false, Tpc, PK_SUB8_FC2));
+        break;
+      }
+      HIP_TRY(lnf(T, 1, Q.w_qkv, Q.s_qkv, Q.cs_qkv, L.b_qkv, 3 * Dw, -1, e->qkv, 3 * Dw, EPI_STORE_BF16, nullptr, 1, PK_GEMM8_QKV));
+      pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * e->tokens * dD, st);
+      // attention writes O as e4m3 directly (static per-channel scale from the V rows of w_qkv, folded into w_out)
+      HIP_TRY(ce_attention(e->qkv, e->a8, c, e->tokens, g.width, g.heads, Q.is_attn, 0, st));
+      pf.end(st);
+      HIP_TRY(resid(e->a8, T, Dw, Q.w_out, Q.s_out, L.b_out, Dw, 1, true, Tp, PK_SUB8_OUT));
+      HIP_TRY(consts(e->st8, sparts, Tp, T));
+      // FC1 writes the hidden activations as e4m3 directly (static per-column scale, folded into w_proj): no bf16 round trip
+      HIP_TRY(lnf(T, 1, Q.w_fc, Q.s_fc, Q.cs_fc, L.b_fc, Mh, g.act, h8, Mh, EPI_STORE_FP8, Q.is_hid, 1, PK_GEMM8_FC1));
+      HIP_TRY(resid(h8, T, Mh, Q.w_proj, Q.s_proj, L.b_proj, Mh, 1, !last, Tp, PK_SUB8_FC2));   // (nothing reads x8 after the last block)
+      st_in = e->st8; parts_in = sparts;
+    }
+    return 0;
+  }
   if (e->precision == CLIPENC_PREC_FP8) {
+    // (widths over 1024)
     // per block: quantise the (normalised) GEMM operand row by row, run the e4m3 GEMM, scales + bias (+ act / residual)
     // in its epilogue.  LayerNorm: gamma sits in the fp8 weights, beta in the bias (as for bf16); the statistics are
     // computed by the quantiser itself.
@@ -452,6 +554,7 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
   e->cfg = g; e->device = device; e->tokens = tokens;
 #ifdef CLIPENC_DIAG                         // diagnostic library only: run the last block on every token (tests/test_gpu_cls_only.py)
   e->cls_only_last = getenv("CLIPENC_FULL_LAST_BLOCK") == nullptr;
+  e->fp8_unfused = getenv("CLIPENC_FP8_UNFUSED") != nullptr;
 #endif
   const int kreal = 3 * g.patch * g.patch;
   e->kpad = (int)align_up(kreal, 128);
@@ -566,12 +669,13 @@ int clipenc_set_precision(clipenc_t e, int precision) {
     const size_t D = g.width, M = g.mlp_dim;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
-    struct LOff { size_t w[4], s[4], is_hid, is_attn; };
+    struct LOff { size_t w[4], s[4], is_hid, is_attn, cs_qkv, cs_fc; };
     std::vector<LOff> lo(g.layers);
     const size_t rows[4] = {3 * D, D, M, D}, cols[4] = {D, D, D, M};
     for (auto& o : lo) {
       for (int i = 0; i < 4; ++i) { o.w[i] = take(rows[i] * cols[i]); o.s[i] = take(rows[i] * 4); }
       o.is_hid = take(M * 4); o.is_attn = take(D * 4);
+      o.cs_qkv = take(3 * D * 4); o.cs_fc = take(M * 4);
     }
     HIP_TRY(e->weights8.alloc(off));
     DevBuf tmp;                                            // [mlp_dim] static scales + fp32 [width][mlp_dim] folded w_proj
@@ -594,6 +698,10 @@ int clipenc_set_precision(clipenc_t e, int precision) {
       float* sc[4] = {Q.s_qkv, Q.s_out, Q.s_fc, Q.s_proj};
       for (int i = 0; i < 3; i += 2)
         HIP_TRY(ce_quant_rows_fp8(src[i], 0, cols[i], dst[i], cols[i], sc[i], (int)rows[i], (int)cols[i], 0, 0.f, nullptr));
+      // the folded mean term multiplies the column sums of the rows the GEMM actually multiplies by: the dequantised ones
+      Q.cs_qkv = (float*)(db + lo[l].cs_qkv); Q.cs_fc = (float*)(db + lo[l].cs_fc);
+      HIP_TRY(ce_colsum_fp8(Q.w_qkv, Q.s_qkv, (int)(3 * D), (int)D, Q.cs_qkv, nullptr));
+      HIP_TRY(ce_colsum_fp8(Q.w_fc, Q.s_fc, (int)M, (int)D, Q.cs_fc, nullptr));
       // attention output: a softmax-weighted mean of V rows, so the bound of the V third of the LN-folded w_qkv holds for it
       Q.is_attn = (float*)(db + lo[l].is_attn);
       HIP_TRY(ce_static_scale(L.w_qkv + 2 * D * D, L.b_qkv + 2 * D, (int)D, (int)D, s_hid, Q.is_attn, nullptr));
@@ -696,7 +804,15 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
   if (name) {
     *name = kProfileNames[kind];
     if (e->cfg.act == CLIPENC_ACT_GELU_ERF && kind == PK_GEMM_FC1) *name = "gemm_persist_kernel<2, 1>";
-    if (e->cfg.act == CLIPENC_ACT_GELU_ERF && kind == PK_GEMM8_FC1) *name = "gemm_fp8_kernel<2, 1>";
+    if (e->cfg.act == CLIPENC_ACT_GELU_ERF && kind == PK_GEMM8_FC1) *name = "gemm_fp8_kernel<2, 1, false>";
+    if (fp8_fused(e->cfg) && !e->fp8_unfused) {              // the fused fp8 tower's instantiations (run_tower)
+      if (kind == PK_GEMM8_QKV) *name = "gemm_fp8_kernel<0, -1, true>";
+      if (kind == PK_GEMM8_FC1) *name = e->cfg.act == CLIPENC_ACT_GELU_ERF ? "gemm_fp8_kernel<2, 1, true>" : "gemm_fp8_kernel<2, 0, true>";
+      if (kind == PK_GEMM8_RESID) *name = "gemm_fp8_kernel<3, -1, false>";
+      if (kind == PK_SUB8_OUT) *name = "shape:out_proj(gemm_fp8_kernel<3, -1, false>)";
+      if (kind == PK_SUB8_FC2) *name = "shape:fc2(gemm_fp8_kernel<3, -1, false>)";
+      if (kind == PK_QUANT_BLOCK) { static thread_local char qb[32]; snprintf(qb, sizeof qb, "quant_block_kernel<%d>", e->cfg.width / 128); *name = qb; }
+    }
     if (kind == PK_PATCHIFY || kind == PK_EMBED_LN_PRE) {   // (patchify: fp32 crops; uint8 / f16 inputs run the <unsigned char, P> / <_Float16, P> twins)
       static thread_local char nb[2][40];
       snprintf(nb[0], sizeof nb[0], "patchify_kernel<float, %d>", e->cfg.patch);
@@ -982,6 +1098,47 @@ int clipenc_op_gemm_fp8_q(const void* a8_dev, const void* w8_dev, int m, int n, 
   p.scale_a = scale_a_dev; p.scale_w = scale_w_dev; p.act = act; p.out_inv_scale = out_inv_scale_dev;
   hipError_t err = ce_gemm_fp8(p, EPI_STORE_FP8, (hipStream_t)stream);
   if (err != hipSuccess) return fail("gemm_fp8_q(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
+  return 0;
+}
+
+int clipenc_op_quant_block_fp8(const void* in_dev, int n_rows, int k, void* out8_dev, void* exp_dev, float* stats_dev,
+                               void* stream) {
+  if (!in_dev || !out8_dev || !exp_dev) return fail("NULL device pointer");
+  hipError_t err = ce_quant_block_fp8(in_dev, (size_t)k, out8_dev, (size_t)k, exp_dev, 4, stats_dev, n_rows, k, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("quant_block_fp8(%d,%d) failed: %s", n_rows, k, hipGetErrorString(err));
+  return 0;
+}
+
+int clipenc_op_row_norm_consts(const float* stats_dev, int parts, int ld, int n_rows, int width, float eps, float* row_r_dev,
+                               float* row_d_dev, void* stream) {
+  if (!stats_dev || !row_r_dev || !row_d_dev) return fail("NULL device pointer");
+  hipError_t err = ce_row_norm_consts(stats_dev, parts, (size_t)ld, n_rows, width, eps, row_r_dev, row_d_dev, 1, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("row_norm_consts(%d,%d) failed: %s", parts, n_rows, hipGetErrorString(err));
+  return 0;
+}
+
+int clipenc_op_gemm_fp8_lnf(const void* a8_dev, const void* exp_dev, const void* w8_dev, int m, int n, int k,
+                            const float* row_r_dev, const float* row_d_dev, const float* scale_w_dev, const float* colsum_dev,
+                            const float* bias_dev, int act, const float* out_inv_scale_dev, void* out_dev, void* stream) {
+  if (!exp_dev) return fail("gemm_fp8_lnf: NULL exponent rows");
+  GemmParams p{};
+  p.A = a8_dev; p.lda = k; p.W = w8_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out_dev; p.ldo = n; p.bias = bias_dev;
+  p.scale_w = scale_w_dev; p.colsum = colsum_dev; p.act = act; p.out_inv_scale = out_inv_scale_dev;
+  p.a_exp = (const unsigned char*)exp_dev; p.ld_aexp = 4; p.row_r = row_r_dev; p.row_d = row_d_dev; p.ld_row = 1;
+  hipError_t err = ce_gemm_fp8(p, out_inv_scale_dev ? EPI_STORE_FP8 : EPI_STORE_BF16, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("gemm_fp8_lnf(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
+  return 0;
+}
+
+int clipenc_op_gemm_fp8_resid_q(const void* a8_dev, const void* w8_dev, int m, int n, int k, const float* scale_w_dev,
+                                const float* bias_dev, void* x_inout_dev, void* out8_dev, void* exp_dev, float* stats_dev,
+                                int stats_ld, void* stream) {
+  GemmParams p{};
+  p.A = a8_dev; p.lda = k; p.W = w8_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = x_inout_dev; p.ldo = n; p.bias = bias_dev;
+  p.scale_w = scale_w_dev; p.act = -1; p.resid = x_inout_dev;
+  p.out8 = out8_dev; p.ld8 = n; p.out_exp = (unsigned char*)exp_dev; p.ld_oexp = 4; p.stats_out = stats_dev; p.stats_ld = stats_ld;
+  hipError_t err = ce_gemm_fp8(p, EPI_RESID_Q, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("gemm_fp8_resid_q(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
   return 0;
 }
 

@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 
 enum { CE_DT_BF16 = 0, CE_DT_F16 = 1 };
-enum { EPI_STORE_F32 = 0, EPI_STORE_BF16 = 1, EPI_LNFOLD = 2, EPI_RESID = 3, EPI_THRESH = 4, EPI_STORE_FP8 = 5 };
+enum { EPI_STORE_F32 = 0, EPI_STORE_BF16 = 1, EPI_LNFOLD = 2, EPI_RESID = 3, EPI_THRESH = 4, EPI_STORE_FP8 = 5, EPI_RESID_Q = 6 };
 
 struct GemmParams {
   const void* A; int lda;        // [M][lda] 16-bit elements, K-contiguous
@@ -32,13 +32,27 @@ struct GemmParams {
   const float* scale_a;          // [M] per-token activation scale (NULL: 1)
   const float* scale_w;          // [N] per-output-channel weight scale
   const float* out_inv_scale;    // [N] EPI_STORE_FP8: out8[m][n] = e4m3(value * out_inv_scale[n])  (static per-column scale)
+  // fp8 path, block-exponent rows (the residual stream of the fp8 tower): an e4m3 row carries one E8M0 exponent byte per 256
+  // columns, x[m][k] ~ a8[m][k] * 2^(exp[m][k / 256] - 127), applied by the scaled MFMA itself.
+  //   consumer (a_exp != NULL, EPI_STORE_BF16 / EPI_STORE_FP8; K <= 1024): the LayerNorm of the rows is folded in,
+  //     out = row_r[m] * scale_w[n] * acc + row_d[m] * colsum[n] + bias[n]     (row_r = rstd, row_d = -mean * rstd)
+  //   producer (EPI_RESID_Q; N <= 1024): besides the bf16 residual rows it writes their e4m3 copy, exponents and row statistics
+  const unsigned char* a_exp;    // [M][ld_aexp] bytes; the dword at row m holds the exponents of column blocks 0..3
+  int ld_aexp;                   // bytes between rows of a_exp (multiple of 4)
+  const float* row_r;            // [M * ld_row]
+  const float* row_d;            // [M * ld_row]
+  int ld_row;                    // floats between rows of row_r / row_d
+  void* out8; int ld8;           // EPI_RESID_Q: e4m3 copy of the new rows [M][ld8] bytes
+  unsigned char* out_exp;        //              exponent byte of (row m, block n0 / 256) at out_exp[m * ld_oexp + n0 / 256]
+  int ld_oexp;
+                                 //              stats_out [N / 64][stats_ld][2]: (sum, sum of squares) of the stored bf16 row over 64 columns
 #ifdef CLIPENC_DIAG                // diagnostic build only (make diag -> libclipenc_hip_diag.so, used by tools/): the product
   unsigned long long* dbg;       // kernels carry no stamp hooks.  Optional [tiles][8] timing stamps.
 #endif
 };
 
 hipError_t ce_gemm_nt(const GemmParams& p, int dtype, int epi, hipStream_t stream);
-hipError_t ce_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);           // fp8 e4m3 operands; EPI_STORE_BF16 / EPI_RESID / EPI_STORE_FP8
+hipError_t ce_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);           // fp8 e4m3 operands; EPI_STORE_BF16 / EPI_RESID / EPI_STORE_FP8 / EPI_RESID_Q
 hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream);   // bf16; EPI_STORE_BF16 / LNFOLD / RESID
 hipError_t ce_gemm_tri_persist(const GemmParams& p, hipStream_t stream);            // f16 E.E^T, upper triangle, EPI_THRESH (gemm_tri.hip)
 #include <vector>

@@ -18,11 +18,30 @@
 // row r at position c ^ ((r >> 1) & 7); a lane reads chunks (4kh + 2h, 4kh + 2h + 1) of its row: conflict-free for the
 // 32-row fragments (checked against the ds_read_b128 lane groups).  Every wave stages blocks of ONE parity (block index
 // = wave + 8i), so the swizzle term of the block parity is a per-wave constant of the DMA source offset.
+//
+// Block-exponent rows (LNF = true consumers, EPI 3 producer): the residual stream's e4m3 copy carries one E8M0 exponent byte per
+// (row, 256 columns), x ~ a8 * 2^(e - 127), and the consumer hands that byte to the MFMA as the A operand's block scale (both
+// hardware K blocks of an MFMA lie inside one 256-column block, so every lane of a row supplies the same byte and the k
+// assignment above stays free).  That is what lets the PRODUCING GEMM quantise its own output tile: the exponent comes from the
+// tile's own 256 columns, no row-wide reduction across tiles, and the LayerNorm of the row is folded into the consumer's
+// epilogue from row statistics (gemm.h).  It replaces the separate LayerNorm-quantise pass over the residual stream
+// (quant_fp8.hip: 1.6 GB of HBM traffic per call, twice per block).
 #include "common.h"
 #include "gemm.h"
 
 #ifndef F8_MMA_ORDER
 #define F8_MMA_ORDER 1
+#endif
+// developer switches (tools/gemm_variants.sh): F8_LNF_ZERO_C = peeled zero-C first stage pair in the LNF variants too;
+// F8_EPI3_PARTS = how much of the quantising epilogue runs (3 all, 2 no e4m3 rows, 1 no exchange either, 0 = EPI 1)
+#ifndef F8_LNF_ZERO_C
+#define F8_LNF_ZERO_C 1
+#endif
+#ifndef F8_EPI3_PARTS
+#define F8_EPI3_PARTS 3
+#endif
+#ifndef F8_LNF_DBG               // timing bisection only (results wrong): 1 unit scale operand, 2 no exponent reads either,
+#define F8_LNF_DBG 0             // 4 no exponent DMA
 #endif
 // instantiations with the register room for the peeled zero-C first stage pair (the others spill with it)
 #define ZERO_C_SET(EPI, ACT) ((EPI) == 2 && (ACT) <= 0)
@@ -36,6 +55,7 @@ constexpr int TR_OFF = RING;                // 8 x 4 KiB wave-private images
 constexpr int LDS_BYTES = RING + 32768;     // 163840
 
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 
 #define LDS_PTR(off) ((__attribute__((address_space(3))) void*)(smem + (off)))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -78,9 +98,16 @@ __device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n)
 
 // EPI: 0 = scale + bias (+ activation) -> bf16;  1 = scale + bias + residual (bf16, in place) -> bf16;
 //      2 = scale + bias (+ activation), then * out_inv_scale[n] -> e4m3 (the next GEMM's operand, no bf16 round trip)
-template <int EPI, int ACT>
+//      3 = as 1, and the e4m3 block-exponent copy of the new rows + their (sum, sum of squares) per 64 columns
+// LNF: A rows are block-exponent rows (a_exp) and the epilogue applies the folded LayerNorm (row_r, row_d, colsum)
+template <int EPI, int ACT, bool LNF>
 __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
-  constexpr bool ZERO_C_OK = ZERO_C_SET(EPI, ACT);
+  constexpr bool ZERO_C_OK = ZERO_C_SET(EPI, ACT) && (!LNF || F8_LNF_ZERO_C);
+  constexpr bool RES = EPI == 1 || EPI == 3;
+  // wave image, LNF: [0,256) weight scales, [256,512) column sums, [512,768) biases, [1024,1536) row_r, [1536,2048) row_d,
+  // [2560,2816) inverse output scales (EPI 2), [3072,3584) the NEXT tile's exponent dwords (row-major, landed by DMA during this
+  // tile's last two stages), [3584,4096) this tile's exponent dwords (read by every phase)
+  constexpr int E_NEXT = 3072, E_CUR = 3584;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
@@ -111,12 +138,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   const int a_base = wr * 16 * 1024;                     // + buffer + mt*4096
   const int w_base = WREG + wc * 8 * 1024;               // + buffer + nt*4096
 
-  // epilogue image: [32 rows][128 B] per wave, 16-B chunk index XOR row&7
+  // epilogue image: [32 rows][128 B] per wave, 16-B chunk index XOR row&7 (its per-lane addresses are derived in the epilogue)
   char* tr = smem + TR_OFF + w * 4096;
-  const int tw_base = r32 * 128 + h * 8;
-  const int tw_sw = r32 & 7;
-  const int tr_base = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);   // + k*1024: rows 8k + (lane>>3)
-  const int row_l = lane >> 3;
 #define TW_ADDR(c) (tr + tw_base + ((((c)) ^ tw_sw) << 4))
 
   int idx = blockIdx.x;
@@ -152,6 +175,15 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   // one A row half for both k halves (fa[2 kh + i])
 #define LD_W2(b) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int j = 0; j < 2; ++j) LD_FRAG(fb[kh * 2 + j], (b) * BUF + w_base + j * 4096, kh);
 #define LD_A2(b, half) _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int i = 0; i < 2; ++i) LD_FRAG(fa[kh * 2 + i], (b) * BUF + a_base + ((half) * 2 + i) * 4096, kh);
+  // LNF: the exponent byte of this stage pair's 256-column block for the two 32-row tiles of the phase (byte 0 of the register is
+  // what opsel 0 selects; sh = 8 * block index)
+#define LD_SC(half, sh)                                                                     \
+  do {                                                                                      \
+    if constexpr (LNF && !(F8_LNF_DBG & 2)) {                                               \
+      _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
+        sc[i] = (int)(*(const unsigned*)(tr + E_CUR + (((half) * 2 + i) * 32 + r32) * 4) >> (sh)); \
+    }                                                                                       \
+  } while (0)
   // ZC: the first MFMA of every accumulator of a tile takes the constant 0 as C (gemm_persist.hip)
 #define MMA(half, ZC)                                                                       \
   do {                                                                                      \
@@ -162,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       const int j = (F8_MMA_ORDER && (i & 1)) ? 1 - j_ : j_;      /* serpentine: one operand register set changes per MFMA (gemm_persist.hip) */ \
       acc[(half) * 2 + i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[kh * 2 + j], fa[kh * 2 + i],      \
                                    ((ZC) && kh == 0) ? zero16 : acc[(half) * 2 + i][j], 0, 0,                        \
-                                                                              0, 0x7f7f7f7f, 0, 0x7f7f7f7f);        \
+                                                                  0, 0x7f7f7f7f, 0, (LNF && !(F8_LNF_DBG & 1)) ? sc[i] : 0x7f7f7f7f); \
     }                                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                          \
   } while (0)
@@ -181,14 +213,15 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   // one K=128 stage on buffer b = two phases of 8 MFMAs (512 cycles) per wave (gemm_persist.hip).  PA: W (both k halves)
   // and A(half 0), PA_ISSUE = the A(half 1) rows of stage s+1 into the other buffer; PB: A(half 1), PB_ISSUE = W and
   // A(half 0) of stage s+2 into this one; each phase's counted wait sits behind its own pieces (the 8 newest stay in flight)
-#define STAGE(b, VMWAIT, PA_ISSUE, PB_ISSUE) STAGE_Z(b, 0, VMWAIT, PA_ISSUE, PB_ISSUE)
-#define STAGE_Z(b, ZC, VMWAIT, PA_ISSUE, PB_ISSUE)                                          \
+  // (sh: 8 * index of the stage's 256-column block, used by the LNF variants only)
+#define STAGE(b, sh, VMWAIT, PA_ISSUE, PB_ISSUE) STAGE_Z(b, sh, 0, VMWAIT, PA_ISSUE, PB_ISSUE)
+#define STAGE_Z(b, sh, ZC, VMWAIT, PA_ISSUE, PB_ISSUE)                                      \
   do {                                                                                      \
-    LD_W2(b) __builtin_amdgcn_sched_barrier(0); LD_A2(b, 0)                                 \
+    LD_W2(b) __builtin_amdgcn_sched_barrier(0); LD_A2(b, 0) LD_SC(0, sh);                   \
     PA_ISSUE;                                                                               \
     VMWAIT;                                                                                 \
     SYNC_MMA(0, ZC);                                                                        \
-    LD_A2(b, 1)                                                                             \
+    LD_A2(b, 1) LD_SC(1, sh);                                                               \
     PB_ISSUE;                                                                               \
     VMWAIT;                                                                                 \
     SYNC_MMA(1, ZC);                                                                        \
@@ -197,7 +230,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   // First two waits after an epilogue: what they need was issued before the epilogue's stores and vmcnt retires in order,
   // so they may leave the NST row stores of a complete tile outstanding as well (see gemm_persist.hip); one opaque
   // instruction for the compiler.
-  constexpr int NST = EPI == 2 ? 8 : 16;     // row stores per wave and tile
+  constexpr int NST = EPI == 2 ? 8 : EPI == 3 ? (F8_EPI3_PARTS >= 3 ? 28 : F8_EPI3_PARTS >= 1 ? 20 : 16) : 16;     // stores per wave and tile (EPI 3: 16 bf16 rows, 8 e4m3 rows, 4 statistics; the
+                                                             // exponent bytes, written by one wave column only, are not counted)
 #define VM_RELAX                                                                            \
   do {                                                                                      \
     const int sel_ = __builtin_amdgcn_readfirstlane(relax > 0 ? 1 : 0);                     \
@@ -208,9 +242,17 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   // the column constants (weight scales, biases, EPI 2: inverse output scales) of the tile are staged into the wave's image at
   // the top of the tile (below): those pieces sit between the previous tile's stores and the first waits (the per-row
   // scale pieces, issued only with per-token scales, are not counted: the wait is then two pieces stricter than need be)
-  constexpr int CB_PIECES = EPI == 2 ? 3 : 2;
+  constexpr int CB_PIECES = LNF ? (EPI == 2 ? 8 : 7) : (EPI == 2 ? 3 : 2);
 
   // ---- cold prologue of the first tile ----
+  // E_ROWS(m0v, dst): the exponent dwords of the wave's 128 rows of the tile at m0v, two DMA pieces (lane = row)
+#define E_ROWS(m0v, dst, lane_v)                                                                                       \
+  do {                                                                                                                 \
+    const int r0_ = (m0v) + wr * 128 + (lane_v);                                                                       \
+    glds4_at((const char*)p.a_exp, (unsigned)min(r0_, p.M - 1) * (unsigned)p.ld_aexp, lds0 + (unsigned)(TR_OFF + w * 4096 + (dst))); \
+    glds4_at((const char*)p.a_exp, (unsigned)min(r0_ + 64, p.M - 1) * (unsigned)p.ld_aexp, lds0 + (unsigned)(TR_OFF + w * 4096 + (dst) + 256)); \
+  } while (0)
+  if constexpr (LNF) E_ROWS(cur.m0, E_CUR, lane);             // oldest pieces: landed with the first counted wait below
   ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 0); ISSUE_AH1(0, Ablk, aoff10, aoff11, 0);
   ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 128);           // A(half 1) of stage 1 follows in PA of stage 0
   VM8;                                                      // W and A(half 0) of stage 0 have landed
@@ -221,6 +263,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     f32x16_t acc[4][2];
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     i32x8_t fa[4], fb[4];
+    [[maybe_unused]] int sc[2];
 
     // Column constants of this tile's 64 columns per wave and the per-token scales of its 128 rows, by LDS-DMA into the wave's
     // (idle until the epilogue) 4-KiB image: [0, 256) weight scales, [1024, 1280) biases, [2560, 2816) inverse output scales
@@ -230,15 +273,30 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     {
       int lane_t;                                              // the lane id from the hardware (not kept across the main loop)
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
-      const unsigned coff = (unsigned)(cur.n0 + wc * 64) * 4u + (unsigned)(lane_t & 15) * 16u;
       const unsigned ti = lds0 + (unsigned)(TR_OFF + w * 4096);
-      glds16_at((const char*)p.scale_w, coff, ti);
-      glds16_at((const char*)p.bias, coff, ti + 1024);
-      if constexpr (EPI == 2) glds16_at((const char*)p.out_inv_scale, coff, ti + 2560);
-      if (p.scale_a) {
+      if constexpr (LNF) {
+        // one dword per lane = the wave's 64 columns / 64 of its 128 rows per piece
+        const unsigned coff4 = (unsigned)(cur.n0 + wc * 64 + lane_t) * 4u;
+        glds4_at((const char*)p.scale_w, coff4, ti);
+        glds4_at((const char*)p.colsum, coff4, ti + 256);
+        glds4_at((const char*)p.bias, coff4, ti + 512);
+        if constexpr (EPI == 2) glds4_at((const char*)p.out_inv_scale, coff4, ti + 2560);
         const int r0 = cur.m0 + wr * 128 + lane_t;
-        glds4_at((const char*)p.scale_a, (unsigned)min(r0, p.M - 1) * 4u, ti + 3584);
-        glds4_at((const char*)p.scale_a, (unsigned)min(r0 + 64, p.M - 1) * 4u, ti + 3840);
+        const unsigned ro0 = (unsigned)min(r0, p.M - 1) * (unsigned)p.ld_row * 4u, ro1 = (unsigned)min(r0 + 64, p.M - 1) * (unsigned)p.ld_row * 4u;
+        glds4_at((const char*)p.row_r, ro0, ti + 1024);
+        glds4_at((const char*)p.row_r, ro1, ti + 1280);
+        glds4_at((const char*)p.row_d, ro0, ti + 1536);
+        glds4_at((const char*)p.row_d, ro1, ti + 1792);
+      } else {
+        const unsigned coff = (unsigned)(cur.n0 + wc * 64) * 4u + (unsigned)(lane_t & 15) * 16u;
+        glds16_at((const char*)p.scale_w, coff, ti);
+        glds16_at((const char*)p.bias, coff, ti + 1024);
+        if constexpr (EPI == 2) glds16_at((const char*)p.out_inv_scale, coff, ti + 2560);
+        if (p.scale_a) {
+          const int r0 = cur.m0 + wr * 128 + lane_t;
+          glds4_at((const char*)p.scale_a, (unsigned)min(r0, p.M - 1) * 4u, ti + 3584);
+          glds4_at((const char*)p.scale_a, (unsigned)min(r0 + 64, p.M - 1) * 4u, ti + 3840);
+        }
       }
     }
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
@@ -246,11 +304,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     constexpr bool ZERO_C = ZERO_C_OK;
     if (ZERO_C && kend > 256) {
       // first stage pair of the tile: every accumulator starts from the constant 0 in its first MFMA
-      STAGE_Z(0, 1, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 256));
-      STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 384));
+      STAGE_Z(0, 0, 1, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, 256));
+      STAGE(1, 0, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, 384));
       for (int kb = 256; kb < kend - 256; kb += 256) {
-        STAGE(0, VM8, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
-        STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
+        STAGE(0, kb >> 5, VM8, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
+        STAGE(1, kb >> 5, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
       }
     } else {
 #pragma unroll
@@ -259,8 +317,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
         for (int j = 0; j < 2; ++j) acc[i][j] = zero16;
       if constexpr (!ZERO_C) {
         for (int kb = 0; kb < kend - 256; kb += 256) {
-          STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
-          STAGE(1, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
+          STAGE(0, kb >> 5, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Ablk, Wblk, aoff00, aoff01, kb + 256));
+          STAGE(1, kb >> 5, VM8, ISSUE_AH1(0, Ablk, aoff10, aoff11, kb + 256), ISSUE_WAH0(1, Ablk, Wblk, aoff00, aoff01, kb + 384));
         }
       }
     }
@@ -285,11 +343,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     const int arow_b = 8 * w + dg_b;
 #define AOFF_B(r) ((unsigned)((min(nxt.m0 + (r), p.M - 1) - nxt.m0) * lda_b) + dch_b)
     aoff00 = AOFF_B(arow_b); aoff01 = AOFF_B(arow_b + 128);
+    // LNF: the next tile's exponent dwords -> E_NEXT.  Older than every piece of the last two stages, so the final counted wait
+    // of the main loop (all but the 8 newest pieces) covers them: the epilogue reads them without a wait of its own.
+    if constexpr (LNF && !(F8_LNF_DBG & 4)) E_ROWS(nxt.m0, E_NEXT, lane_b);
     {
       const int kb = kend - 256;
-      STAGE(0, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Anext, Wnext, aoff00, aoff01, 0));
+      STAGE(0, kb >> 5, VM_RELAX, ISSUE_AH1(1, Ablk, aoff10, aoff11, kb + 128), ISSUE_WAH0(0, Anext, Wnext, aoff00, aoff01, 0));
       aoff10 = AOFF_B(arow_b + 64); aoff11 = AOFF_B(arow_b + 192);
-      STAGE(1, VM8, ISSUE_AH1(0, Anext, aoff10, aoff11, 0), ISSUE_WAH0(1, Anext, Wnext, aoff00, aoff01, 128));
+      STAGE(1, kb >> 5, VM8, ISSUE_AH1(0, Anext, aoff10, aoff11, 0), ISSUE_WAH0(1, Anext, Wnext, aoff00, aoff01, 128));
     }
 #undef AOFF_B
     // pin the accumulators here: without a use in this block LLVM sinks the tail's 32 MFMAs below the conditional
@@ -302,37 +363,102 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
 
     // ------------------------------- epilogue of tile `cur` -------------------------------
     // lane (r32, h) of m-tile mt holds row mw0 + mt*32 + r32, columns nb + nt*32 + 8g + 4h + (0..3) in acc[mt][nt][4g..4g+3]
+    // (every per-lane constant of the epilogue comes from the hardware's lane id HERE: derived at the top of the kernel they are
+    // loop invariants that hipcc keeps across the main loop -- in scratch, reloaded below behind a vmcnt(0) that drains the DMA
+    // pipeline and the tile's stores)
+    int lane_e;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+    const int r32e = lane_e & 31, he = lane_e >> 5;
+    const int tw_base = r32e * 128 + he * 8;
+    const int tw_sw = r32e & 7;
+    const int tr_base = (lane_e >> 3) * 128 + (((lane_e & 7) ^ (lane_e >> 3)) << 4);   // + k*1024: rows 8k + (lane>>3)
+    const int row_l = lane_e >> 3;
     const int mw0 = cur.m0 + wr * 128;
     const int nb = cur.n0 + wc * 64;
-    const size_t gcol = (size_t)nb + (lane & 7) * 8;
-    // pass 1 (keeps registers low): acc <- acc * sw[n] + bias[n] / sa[m], so that pass 2 only multiplies by sa[m]
-    float sa[4];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) sa[mt] = p.scale_a ? *(const float*)(tr + 3584 + (mt * 32 + r32) * 4) : 1.0f;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int nl = (c >> 2) * 32 + (c & 3) * 8 + h * 4;          // column within the wave's 64
-      const f32x4_t sw = *(const f32x4_t*)(tr + nl * 4);
-      const f32x4_t bs = *(const f32x4_t*)(tr + 1024 + nl * 4);
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-        const float rsa = __builtin_amdgcn_rcpf(sa[mt]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          acc[mt][c >> 2][(c & 3) * 4 + e] = fmaf(acc[mt][c >> 2][(c & 3) * 4 + e], sw[e], bs[e] * rsa);
-      }
-    }
-    uint4 rres[4];                           // residual rows: 4 x 16 B per 32-row block, one block in flight
+    const size_t gcol = (size_t)nb + (lane_e & 7) * 8;
+    uint4 rres[4];                           // residual rows: 4 x 16 B per 32-row block, one block in flight (the first block's
+                                             // loads are issued here: their latency passes under pass 1)
 #define LOAD_RES(k)                                                                           \
   do {                                                                                        \
     const int m_ = mw0 + (k) * 8 + row_l;                                                     \
     rres[(k) & 3] = uint4{0, 0, 0, 0};                                                        \
     if (m_ < p.M) rres[(k) & 3] = *(const uint4*)((const bf16_t*)p.resid + (size_t)m_ * p.ldo + gcol); \
   } while (0)
-    if constexpr (EPI == 1) {
+    if constexpr (RES) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) LOAD_RES(k);
     }
+    // The bias and the folded mean term are rank-1 updates of the accumulator and go to the matrix pipe, idle in the epilogue:
+    //   out = sa[m] sw[n] (acc + rowA[m] colA[n] + rowB[m] colB[n])
+    //   LNF:   sa = row_r, rowA = row_d / row_r (= -mean), colA = colsum / sw, rowB = 1 / row_r, colB = bias / sw
+    //   else:  sa = scale_a (or 1), rowA = 0, rowB = 1 / sa, colB = bias / sw
+    // as ONE bf16 MFMA of 32 cycles per accumulator: every factor is split into bf16 (hi, lo), the k slots 0-3 hold the four
+    // products of the first term and 4-7 those of the second (relative error 2^-16 of each term; fp32 accumulation).  As VALU
+    // work the same update is 2 instructions per element and wave -- 256 per lane and tile at ~5 cycles each, two waves per
+    // SIMD: the largest single item of the epilogue.  What remains of pass 1 is acc *= sw[n].
+    float sa[4];
+    [[maybe_unused]] unsigned e_hop[4];                          // LNF: the next tile's exponent dwords, E_NEXT -> registers -> E_CUR
+    {
+      constexpr int SW_OFF = 0, CS_OFF = 256, BS_OFF = LNF ? 512 : 1024;
+      auto split = [](float x) -> unsigned {                     // bf16 hi | lo << 16 with hi + lo = x to 2^-16
+        const float hi = __uint_as_float(pack_bf16x2(x, 0.f) << 16);
+        return pack_bf16x2(x, x - hi);
+      };
+      u32x4_t rowf[4], colf[2];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float ra = 0.f, rb;
+        if constexpr (LNF) {
+          sa[mt] = *(const float*)(tr + 1024 + (mt * 32 + r32e) * 4);
+          rb = __builtin_amdgcn_rcpf(sa[mt]);
+          ra = *(const float*)(tr + 1536 + (mt * 32 + r32e) * 4) * rb;
+          e_hop[mt] = *(const unsigned*)(tr + E_NEXT + (mt * 32 + r32e) * 4);
+        } else {
+          sa[mt] = p.scale_a ? *(const float*)(tr + 3584 + (mt * 32 + r32e) * 4) : 1.0f;
+          rb = __builtin_amdgcn_rcpf(sa[mt]);
+        }
+        const unsigned wa = he == 0 ? split(ra) : 0u, wb = he == 0 ? split(rb) : 0u;   // k slots 8-15 (lanes 32-63): zeros
+        rowf[mt] = u32x4_t{wa, wa, wb, wb};
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int n = nt * 32 + r32e;                             // the lane's column of this 32-column tile
+        const float swn = *(const float*)(tr + SW_OFF + n * 4);
+        const float isw = swn != 0.f ? __builtin_amdgcn_rcpf(swn) : 0.f;   // (a zero weight scale zeroes the column, bias included)
+        const float cb = *(const float*)(tr + BS_OFF + n * 4) * isw;
+        float ca = 0.f;
+        if constexpr (LNF) ca = *(const float*)(tr + CS_OFF + n * 4) * isw;
+        const unsigned sca = split(ca), scb = split(cb);
+        // [hi, hi, lo, lo] against the rows' [hi, lo, hi, lo]
+        const unsigned z = he == 0 ? 0xffffffffu : 0u;
+        colf[nt] = u32x4_t{((sca & 0xffffu) * 0x10001u) & z, ((sca >> 16) * 0x10001u) & z, ((scb & 0xffffu) * 0x10001u) & z, ((scb >> 16) * 0x10001u) & z};
+      }
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, colf[nt]), __builtin_bit_cast(bf16x8_t, rowf[mt]),
+                                                                acc[mt][nt], 0, 0, 0);
+      // pass 1 (keeps registers low): acc <- acc * sw[n], so that pass 2 only multiplies by sa[m]; the scales of column group
+      // c + 1 are read before group c is computed (one LDS latency per tile, not eight)
+#define NL(c) (((c) >> 2) * 32 + ((c) & 3) * 8 + he * 4)          /* column within the wave's 64 */
+      f32x4_t sw_n = *(const f32x4_t*)(tr + SW_OFF + NL(0) * 4);
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const f32x4_t sw = sw_n;
+        if (c + 1 < 8) sw_n = *(const f32x4_t*)(tr + SW_OFF + NL(c + 1) * 4);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mt][c >> 2][(c & 3) * 4 + e] *= sw[e];
+        }
+        // the results exist HERE: without a use hipcc sinks this arithmetic into pass 2 and keeps the constants live until then
+        if ((c & 3) == 3) asm volatile("" : "+v"(acc[0][c >> 2]), "+v"(acc[1][c >> 2]), "+v"(acc[2][c >> 2]), "+v"(acc[3][c >> 2]));
+      }
+#undef NL
+    }
+    // EPI 3: per 32-row block the row's max |x| over the wave's 64 columns (before the bf16 rounding)
+    [[maybe_unused]] float amax[4] = {0.f, 0.f, 0.f, 0.f};
 
     if constexpr (EPI == 2) {
       // fp8 image: [32 rows][80 B pitch] per wave (64 data bytes; the pitch keeps the dword writes 2-way conflicted at most),
@@ -344,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const int nt = c >> 2, g = c & 3;
-          const int col = nt * 32 + g * 8 + h * 4;
+          const int col = nt * 32 + g * 8 + he * 4;
           const f32x4_t is = *(const f32x4_t*)(isc + col);
           float v[4];
 #pragma unroll
@@ -353,39 +479,40 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
           int wd = 0;
           wd = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], wd, false);
           wd = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], wd, true);
-          *(int*)(tr + r32 * 80 + col) = wd;
+          *(int*)(tr + r32e * 80 + col) = wd;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-          const int row = k * 16 + (lane >> 2);
-          const uint4 v = *(const uint4*)(tr + row * 80 + (lane & 3) * 16);
+          const int row = k * 16 + (lane_e >> 2);
+          const uint4 v = *(const uint4*)(tr + row * 80 + (lane_e & 3) * 16);
           const int m = mw0 + mt * 32 + row;
-          if (m < p.M) *(uint4*)((char*)p.out + (size_t)m * p.ldo + nb + (lane & 3) * 16) = v;
+          if (m < p.M) *(uint4*)((char*)p.out + (size_t)m * p.ldo + nb + (lane_e & 3) * 16) = v;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
     } else {
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      if constexpr (EPI == 1) {
+      if constexpr (RES) {
         // residual rows of this 32-row block: row-major image -> fragment layout
 #pragma unroll
         for (int k = 0; k < 4; ++k) *(uint4*)(tr + k * 1024 + tr_base) = rres[k];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // cross-lane hand-off through the image
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // cross-lane_e hand-off through the image
         if (mt + 1 < 4) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) LOAD_RES(mt * 4 + 4 + k);
         }
       }
       uint2 pk[8];
+      [[maybe_unused]] float rs = 0.f, rss = 0.f;               // EPI 3: sum and sum of squares of the ROUNDED values, as stored
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
         const int nt = c >> 2, g = c & 3;
         f32x4_t v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][g * 4 + e] * sa[mt];
-        if constexpr (EPI == 1) {
+        if constexpr (RES) {
           const uint2 rr = *(const uint2*)TW_ADDR(c);
           v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
           v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
@@ -394,8 +521,28 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
           for (int e = 0; e < 4; ++e) v[e] = act_apply_t<ACT>(v[e]);
         }
         pk[c] = uint2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        if constexpr (EPI == 3 && F8_EPI3_PARTS >= 1) {
+          amax[mt] = __builtin_fmaxf(amax[mt], __builtin_fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])));
+          amax[mt] = __builtin_fmaxf(amax[mt], __builtin_fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3])));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mt][nt][g * 4 + e] = v[e];      // kept for the quantising pass below
+          const bf16x2_t ones2 = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
+          const bf16x2_t p0 = __builtin_bit_cast(bf16x2_t, pk[c].x), p1 = __builtin_bit_cast(bf16x2_t, pk[c].y);
+          rs = __builtin_amdgcn_fdot2_f32_bf16(p0, ones2, rs, false);
+          rs = __builtin_amdgcn_fdot2_f32_bf16(p1, ones2, rs, false);
+          rss = __builtin_amdgcn_fdot2_f32_bf16(p0, p0, rss, false);
+          rss = __builtin_amdgcn_fdot2_f32_bf16(p1, p1, rss, false);
+        }
       }
-      if constexpr (EPI == 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads done before the image is rewritten
+      if constexpr (EPI == 3) {
+        // the other 32 of the wave's 64 columns sit in lane_e ^ 32
+        rs += __shfl_xor(rs, 32);
+        rss += __shfl_xor(rss, 32);
+        amax[mt] = __builtin_fmaxf(amax[mt], __shfl_xor(amax[mt], 32));
+        const int m = mw0 + mt * 32 + r32e;
+        if (he == 0 && m < p.M) *(float2*)(p.stats_out + ((size_t)((cur.n0 >> 6) + wc) * p.stats_ld + m) * 2) = float2{rs, rss};
+      }
+      if constexpr (RES) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads done before the image is rewritten
 #pragma unroll
       for (int c = 0; c < 8; ++c) *(uint2*)TW_ADDR(c) = pk[c];
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -410,6 +557,60 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     }
 #undef LOAD_RES
 
+    if constexpr (EPI == 3 && F8_EPI3_PARTS >= 2) {
+      // ---- the e4m3 copy of the tile's new rows.  One exponent per (row, this tile's 256 columns): the four waves of a wave
+      // row exchange their row maxima through their images ([3584, 4096): untouched by the tile-top DMA of this variant), then
+      // x * 2^-e with |x * 2^-e| < 256 goes through the image as e4m3, 64 B per row and wave.
+      if (he == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *(float*)(tr + 3584 + (mt * 32 + r32e) * 4) = amax[mt];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (not __syncthreads: its vmcnt(0) would drain the tile's stores)
+      float mul[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        float a = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a = __builtin_fmaxf(a, *(const float*)(smem + TR_OFF + (wr * 4 + q) * 4096 + 3584 + (mt * 32 + r32e) * 4));
+        // |x| < 2^(ex - 126) with ex the biased exponent of the row maximum: e = ex - 134 puts it below 2^8 (e4m3 reaches 448)
+        const int ex = (int)((__float_as_uint(a) >> 23) & 0xffu);
+        const int eb = max(ex - 7, 0);                            // the E8M0 byte, e + 127
+        mul[mt] = __uint_as_float((unsigned)(254 - eb) << 23);    // 2^-e
+        const int m = mw0 + mt * 32 + r32e;
+        if (wc == 0 && he == 0 && m < p.M) p.out_exp[(size_t)m * p.ld_oexp + (cur.n0 >> 8)] = (unsigned char)eb;
+      }
+      if constexpr (F8_EPI3_PARTS >= 3) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const int nt = c >> 2, g = c & 3;
+          const int col = nt * 32 + g * 8 + he * 4;
+          int wd = 0;
+          wd = __builtin_amdgcn_cvt_pk_fp8_f32(acc[mt][nt][g * 4 + 0] * mul[mt], acc[mt][nt][g * 4 + 1] * mul[mt], wd, false);
+          wd = __builtin_amdgcn_cvt_pk_fp8_f32(acc[mt][nt][g * 4 + 2] * mul[mt], acc[mt][nt][g * 4 + 3] * mul[mt], wd, true);
+          *(int*)(tr + r32e * 80 + col) = wd;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int row = k * 16 + (lane_e >> 2);
+          const uint4 v = *(const uint4*)(tr + row * 80 + (lane_e & 3) * 16);
+          const int m = mw0 + mt * 32 + row;
+          if (m < p.M) *(uint4*)((char*)p.out8 + (size_t)m * p.ld8 + nb + (lane_e & 3) * 16) = v;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      }
+    }
+    if constexpr (LNF) {
+      // the next tile's exponent dwords take their place for its main loop (the image above is done with)
+      if (he == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) *(unsigned*)(tr + E_CUR + (mt * 32 + r32e) * 4) = e_hop[mt];
+      }
+    }
+
     if (!has_next) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant DMA before the LDS is released
       break;
@@ -419,17 +620,17 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   }
 }
 
-template <int EPI, int ACT>
+template <int EPI, int ACT, bool LNF = false>
 hipError_t launch_fp8(const GemmParams& p, hipStream_t stream) {
   static DeviceKernelSetup setup;             // per device: LDS opt-in + CU count (common.h)
   int n_cu = 0;
-  if (hipError_t e = setup.ensure((const void*)gemm_fp8_kernel<EPI, ACT>, LDS_BYTES, &n_cu); e != hipSuccess) return e;
+  if (hipError_t e = setup.ensure((const void*)gemm_fp8_kernel<EPI, ACT, LNF>, LDS_BYTES, &n_cu); e != hipSuccess) return e;
   const int tiles = ((p.M + BM - 1) / BM) * (p.N / BN);
   int grid = n_cu > 0 ? n_cu : 256;
   grid -= grid % 8;
   if (grid < 8) grid = 8;
   if (tiles < grid) grid = tiles;
-  hipLaunchKernelGGL((gemm_fp8_kernel<EPI, ACT>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_fp8_kernel<EPI, ACT, LNF>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
   return hipGetLastError();
 }
 
@@ -447,6 +648,29 @@ hipError_t ce_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream) {
   if (epi == EPI_RESID) {
     if (!p.resid) return hipErrorInvalidValue;
     return launch_fp8<1, -1>(p, stream);
+  }
+  if (epi == EPI_RESID_Q) {
+    // one exponent byte per (row, 256-column tile), four of them in a dword: N <= 1024
+    if (!p.resid || p.scale_a || !p.out8 || !p.out_exp || !p.stats_out || p.N > 1024 || p.ld8 < p.N || p.ld8 % 16 != 0 || p.ld_oexp < 4 ||
+        p.stats_ld < p.M || ((uintptr_t)p.out8 & 15) || ((uintptr_t)p.stats_out & 7))
+      return hipErrorInvalidValue;
+    return launch_fp8<3, -1>(p, stream);
+  }
+  if (p.a_exp) {
+    // block-exponent A rows with the folded LayerNorm; per-token scales do not combine with it
+    if (p.scale_a || !p.row_r || !p.row_d || !p.colsum || p.K > 1024 || p.ld_aexp < 4 || p.ld_aexp % 4 != 0 || p.ld_row < 1 ||
+        ((uintptr_t)p.a_exp & 3) || (size_t)(p.M - 1) * p.ld_aexp >= 0x7fffffffull || (size_t)(p.M - 1) * p.ld_row * 4 >= 0x7fffffffull)
+      return hipErrorInvalidValue;
+    if (epi == EPI_STORE_FP8) {
+      if (!p.out_inv_scale) return hipErrorInvalidValue;
+      if (p.act == CE_ACT_QUICK_GELU) return launch_fp8<2, CE_ACT_QUICK_GELU, true>(p, stream);
+      if (p.act == CE_ACT_GELU_ERF) return launch_fp8<2, CE_ACT_GELU_ERF, true>(p, stream);
+      return launch_fp8<2, -1, true>(p, stream);
+    }
+    if (epi != EPI_STORE_BF16) return hipErrorInvalidValue;
+    if (p.act == CE_ACT_QUICK_GELU) return launch_fp8<0, CE_ACT_QUICK_GELU, true>(p, stream);
+    if (p.act == CE_ACT_GELU_ERF) return launch_fp8<0, CE_ACT_GELU_ERF, true>(p, stream);
+    return launch_fp8<0, -1, true>(p, stream);
   }
   if (epi == EPI_STORE_FP8) {
     if (!p.out_inv_scale) return hipErrorInvalidValue;

@@ -187,6 +187,99 @@ __global__ __launch_bounds__(256) void quant_ln16_kernel(const bf16_t* __restric
   }
 }
 
+// ---- block-exponent rows (gemm_fp8.hip, gemm.h): x[row][k] ~ e4m3 * 2^(exp[row][k / 256] - 127) ----
+// The same row layout as above (16 lanes per row, lane i holds the 16-B pieces i, i + 16, ...): a 256-column block is the pieces
+// 32 b .. 32 b + 31 = two values of c in all 16 lanes, so its maximum is one DPP-row reduction.  The exponent rule is the
+// GEMM epilogue's (gemm_fp8.hip, EPI 3): biased exponent ex of the block's max |x|, byte = max(ex - 7, 0), |x * 2^-e| < 256.
+// Also writes the row's (sum, sum of squares), the statistics the consuming GEMM's folded LayerNorm needs.
+template <int NCH>                                              // K = 128 * NCH, NCH even
+__global__ __launch_bounds__(256) void quant_block_kernel(const bf16_t* __restrict__ in, size_t ld_in, uint8_t* __restrict__ out,
+                                                          size_t ld_out, uint8_t* __restrict__ exps, size_t ld_exp,
+                                                          float* __restrict__ stats, int n_rows) {
+  const int lane = threadIdx.x & 63, sub = lane & 15, rr = lane >> 4;
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
+  for (int row0 = wave * 4; row0 < n_rows; row0 += n_waves * 4) {
+    const int row = min(row0 + rr, n_rows - 1);
+    const bf16_t* src = in + (size_t)row * ld_in + sub * 8;
+    float v[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) load8<bf16_t>(src + c * 128, v[c]);
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s += v[c][j]; ss = fmaf(v[c][j], v[c][j], ss); }
+    s = row16_sum(s);
+    ss = row16_sum(ss);
+    unsigned ebytes = 0;
+    float mul[NCH / 2];
+#pragma unroll
+    for (int b = 0; b < NCH / 2; ++b) {
+      float amax = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fmaxf(fabsf(v[2 * b][j]), fabsf(v[2 * b + 1][j])));
+      amax = row16_max(amax);
+      const int ex = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+      const int eb = max(ex - 7, 0);
+      mul[b] = __uint_as_float((unsigned)(254 - eb) << 23);
+      ebytes |= (unsigned)eb << (8 * b);
+    }
+    if (row0 + rr < n_rows) {
+      uint8_t* dst = out + (size_t)row * ld_out + sub * 8;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const float m = mul[c >> 1];
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][0] * m, v[c][1] * m, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][2] * m, v[c][3] * m, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][4] * m, v[c][5] * m, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[c][6] * m, v[c][7] * m, w1, true);
+        *(uint2*)(dst + c * 128) = uint2{(uint32_t)w0, (uint32_t)w1};
+      }
+      if (sub == 0) {
+        *(unsigned*)(exps + (size_t)row * ld_exp) = ebytes;
+        if (stats) *(float2*)(stats + (size_t)row * 2) = float2{s, ss};
+      }
+    }
+  }
+}
+
+// (row_r, row_d) = (rstd, -mean * rstd) of every row from its `parts` partial (sum, sum of squares): the per-row constants of the
+// LayerNorm folded into the fp8 GEMM's epilogue.  One thread per row; stats [parts][ld][2].
+__global__ __launch_bounds__(256) void row_norm_consts_kernel(const float* __restrict__ stats, int parts, size_t ld, int n_rows,
+                                                              float inv_width, float eps, float* __restrict__ row_r,
+                                                              float* __restrict__ row_d, int ld_row) {
+  const int row = blockIdx.x * 256 + threadIdx.x;
+  if (row >= n_rows) return;
+  float s = 0.f, ss = 0.f;
+  for (int q = 0; q < parts; ++q) {
+    const float2 t = *(const float2*)(stats + ((size_t)q * ld + row) * 2);
+    s += t.x; ss += t.y;
+  }
+  const float mean = s * inv_width;
+  const float var = fmaxf(ss * inv_width - mean * mean, 0.f);
+  const float r = rsqrtf(var + eps);
+  row_r[(size_t)row * ld_row] = r;
+  row_d[(size_t)row * ld_row] = -mean * r;
+}
+
+// colsum[n] = scale[n] * sum_k e4m3(W8[n][k]): the column sums of the DEQUANTISED weight rows, what the folded mean term of
+// the fp8 GEMM multiplies.  One wave per row.
+__global__ __launch_bounds__(256) void colsum_fp8_kernel(const uint8_t* __restrict__ W8, const float* __restrict__ scale, int N, int K,
+                                                         float* __restrict__ colsum) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float s = 0.f;
+  for (int c = lane * 4; c < K; c += 256) {
+    const int wd = *(const int*)(W8 + (size_t)n * K + c);
+    const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(wd, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(wd, true);
+    s += (lo[0] + lo[1]) + (hi[0] + hi[1]);
+  }
+  s = wave_sum(s);
+  if (lane == 0) colsum[n] = s * scale[n];
+}
+
 // Static (data-free) output scale of a LayerNorm-fed linear layer, from the Cauchy-Schwarz bound
 //   |LN(x) . w'_n + b'_n| <= sqrt(K) * ||w'_n||_2 + |b'_n|      (||LN(x) without affine||_2 <= sqrt(K))
 // widened by 1.07 for the e4m3 rounding of both operands and by a 1.2 margin:  s[n] = bound / 448 * 1.2, inv_s = 1/s.
@@ -239,6 +332,39 @@ hipError_t ce_scale_cols(const void* W_bf16, const float* s, float* out_f32, int
   const size_t total = (size_t)N * K;
   hipLaunchKernelGGL(scale_cols_kernel, dim3((unsigned)((total / 8 + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)W_bf16, s,
                      out_f32, total, K);
+  return hipGetLastError();
+}
+
+// bf16 rows of K = 256 .. 1024 elements (K % 256 == 0) -> e4m3 rows + one exponent dword per row (bytes 0 .. K/256 - 1) and,
+// if stats != NULL, the row's (sum, sum of squares) at stats[row][2]
+hipError_t ce_quant_block_fp8(const void* in, size_t ld_in, void* out8, size_t ld_out, void* exps, size_t ld_exp, float* stats,
+                              int n_rows, int K, hipStream_t stream) {
+  if (n_rows < 1 || K < 256 || K > 1024 || K % 256 != 0 || ld_in < (size_t)K || ld_out < (size_t)K || ld_in % 8 != 0 ||
+      ld_out % 8 != 0 || ld_exp < 4 || ld_exp % 4 != 0 || (((uintptr_t)in | (uintptr_t)out8) & 15) || ((uintptr_t)exps & 3) ||
+      ((uintptr_t)stats & 7))
+    return hipErrorInvalidValue;
+  const int waves = (n_rows + 3) / 4;
+  dim3 grid((unsigned)std::min((waves + 3) / 4, 16384)), block(256);
+#define QB(NCH_)                                                                                                                  \
+  case NCH_: hipLaunchKernelGGL((quant_block_kernel<NCH_>), grid, block, 0, stream, (const bf16_t*)in, ld_in, (uint8_t*)out8,     \
+                                ld_out, (uint8_t*)exps, ld_exp, stats, n_rows);                                                   \
+    return hipGetLastError();
+  switch (K / 128) { QB(2) QB(4) QB(6) QB(8) default: break; }
+#undef QB
+  return hipErrorInvalidValue;
+}
+
+hipError_t ce_row_norm_consts(const float* stats, int parts, size_t ld, int n_rows, int width, float eps, float* row_r, float* row_d,
+                              int ld_row, hipStream_t stream) {
+  if (n_rows < 1 || parts < 1 || ld < (size_t)n_rows || width < 1 || ld_row < 1) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(row_norm_consts_kernel, dim3((n_rows + 255) / 256), dim3(256), 0, stream, stats, parts, ld, n_rows,
+                     1.0f / (float)width, eps, row_r, row_d, ld_row);
+  return hipGetLastError();
+}
+
+hipError_t ce_colsum_fp8(const void* W8, const float* scale, int N, int K, float* colsum, hipStream_t stream) {
+  if (N < 1 || K < 4 || K % 4 != 0 || ((uintptr_t)W8 & 3)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(colsum_fp8_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const uint8_t*)W8, scale, N, K, colsum);
   return hipGetLastError();
 }
 

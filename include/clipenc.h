@@ -268,6 +268,28 @@ int clipenc_op_gemm_fp8(const void* a8_dev, const void* w8_dev, int m, int n, in
 int clipenc_op_gemm_fp8_q(const void* a8_dev, const void* w8_dev, int m, int n, int k, const float* scale_a_dev,
                           const float* scale_w_dev, const float* bias_dev, int act, const float* out_inv_scale_dev,
                           void* out8_dev, void* stream);
+/* Block-exponent e4m3 rows, the residual stream's operand form in the fused CLIPENC_PREC_FP8 tower (width <= 1024):
+ *   x[r][k] ~ e4m3(out8[r][k]) * 2^(exp[r][k / 256] - 127),   exp byte = max(ex - 7, 0) with ex the biased fp32 exponent of the
+ *   block's max |x| (so |x * 2^-e| < 256), four bytes per row (exp_dev [n_rows][4], bytes past k / 256 are 0);
+ * stats_dev (may be NULL) receives the row's (sum, sum of squares) [n_rows][2].  in: bf16 [n_rows][k], k = 256 .. 1024, k % 256 == 0 */
+int clipenc_op_quant_block_fp8(const void* in_dev, int n_rows, int k, void* out8_dev, void* exp_dev, float* stats_dev,
+                               void* stream);
+/* (row_r, row_d)[r] = (rstd, -mean * rstd) of row r from `parts` partial (sum, sum of squares): stats_dev [parts][ld][2] */
+int clipenc_op_row_norm_consts(const float* stats_dev, int parts, int ld, int n_rows, int width, float eps, float* row_r_dev,
+                               float* row_d_dev, void* stream);
+/* The LayerNorm-folded fp8 GEMM on block-exponent rows (QKV / FC1 of the fused tower):
+ *   v = act(row_r[m] * scale_w[n] * (A8 (2^exp) . W8^T)[m][n] + row_d[m] * colsum[n] + bias[n])
+ * stored as bf16 (out_inv_scale_dev == NULL) or as e4m3(v * out_inv_scale[n]);  N % 256 == 0, K % 256 == 0, K <= 1024 */
+int clipenc_op_gemm_fp8_lnf(const void* a8_dev, const void* exp_dev, const void* w8_dev, int m, int n, int k,
+                            const float* row_r_dev, const float* row_d_dev, const float* scale_w_dev, const float* colsum_dev,
+                            const float* bias_dev, int act, const float* out_inv_scale_dev, void* out_dev, void* stream);
+/* The residual fp8 GEMM that also quantises what it produces (out-projection / FC2 of the fused tower):
+ *   x[m][n] = bf16(x[m][n] + (A8 . W8^T)[m][n] * scale_w[n] + bias[n])   in place, and for the new rows their block-exponent
+ *   copy (out8_dev [m][n], exp_dev [m][4]: the fp32 value before the bf16 rounding is what gets quantised) and
+ *   stats_dev [n / 64][stats_ld][2]: (sum, sum of squares) of the stored bf16 row over each 64 columns.  N = 256 .. 1024 */
+int clipenc_op_gemm_fp8_resid_q(const void* a8_dev, const void* w8_dev, int m, int n, int k, const float* scale_w_dev,
+                                const float* bias_dev, void* x_inout_dev, void* out8_dev, void* exp_dev, float* stats_dev,
+                                int stats_ld, void* stream);
 /* qkv bf16 [n_crops*n_tok][3*width] -> out bf16 [n_crops*n_tok][width]; head dim 64, n_tok <= 640 */
 int clipenc_op_attention(const void* qkv_dev, void* out_dev, int n_crops, int n_tok, int width, int heads,
                          void* stream);

@@ -9,13 +9,35 @@ lib = _lib.load(); dev = torch.device("cuda", 0); st = _lib.current_stream_ptr(d
 M = int(os.environ.get("AB_M", "526336"))
 def rnd8(r, c):
     return (torch.randn(r, c, device=dev) * 0.5).to(torch.float8_e4m3fn)
-for name, N, K, kind in (("qkv", 3072, 1024, "bf16"), ("out_proj", 1024, 1024, "resid"), ("fc1", 4096, 1024, "q"), ("fc2", 1024, 4096, "resid")):
+SHAPES = (("qkv", 3072, 1024, "bf16"), ("out_proj", 1024, 1024, "resid"), ("fc1", 4096, 1024, "q"), ("fc2", 1024, 4096, "resid"),
+          # the fused tower's forms of the same four (block-exponent rows, include/clipenc.h)
+          ("qkv_lnf", 3072, 1024, "lnf"), ("out_proj_q", 1024, 1024, "resid_q"), ("fc1_lnf", 4096, 1024, "lnf_q"),
+          ("fc2_q", 1024, 4096, "resid_q"))
+ONLY = os.environ.get("AB_ONLY")
+for name, N, K, kind in SHAPES:
+    if ONLY and name not in ONLY.split(","):
+        continue
     a = rnd8(M, K); w = rnd8(N, K)
     sa = torch.rand(M, device=dev) + 0.5; sw = torch.rand(N, device=dev) * 0.01; bias = torch.randn(N, device=dev)
     inv = torch.rand(N, device=dev) + 0.5
     if kind == "q":
         out = torch.empty(M, N, device=dev, dtype=torch.uint8)
         run = lambda: lib.clipenc_op_gemm_fp8_q(a.data_ptr(), w.data_ptr(), M, N, K, None, sw.data_ptr(), bias.data_ptr(), 0, inv.data_ptr(), out.data_ptr(), st)
+    elif kind in ("lnf", "lnf_q"):
+        a = (torch.randn(M, K, device=dev) * 60).clamp(-255, 255).to(torch.float8_e4m3fn)
+        eb = torch.randint(120, 130, (M, 4), device=dev, dtype=torch.uint8)
+        rr = torch.rand(M, device=dev) + 0.5; rd = torch.randn(M, device=dev); cs = torch.randn(N, device=dev)
+        out = torch.empty(M, N, device=dev, dtype=torch.uint8 if kind == "lnf_q" else torch.bfloat16)
+        run = lambda: lib.clipenc_op_gemm_fp8_lnf(a.data_ptr(), eb.data_ptr(), w.data_ptr(), M, N, K, rr.data_ptr(), rd.data_ptr(), sw.data_ptr(),
+                                                  cs.data_ptr(), bias.data_ptr(), 0 if kind == "lnf_q" else -1,
+                                                  inv.data_ptr() if kind == "lnf_q" else None, out.data_ptr(), st)
+    elif kind == "resid_q":
+        out = torch.randn(M, N, device=dev).to(torch.bfloat16)
+        q8 = torch.empty(M, N, device=dev, dtype=torch.uint8); eb = torch.empty(M, 4, device=dev, dtype=torch.uint8)
+        ld = (M + 255) // 256 * 256
+        stt = torch.empty(N // 64, ld, 2, device=dev)
+        run = lambda: lib.clipenc_op_gemm_fp8_resid_q(a.data_ptr(), w.data_ptr(), M, N, K, sw.data_ptr(), bias.data_ptr(), out.data_ptr(),
+                                                      q8.data_ptr(), eb.data_ptr(), stt.data_ptr(), ld, st)
     elif kind == "resid":
         out = torch.randn(M, N, device=dev).to(torch.bfloat16)
         run = lambda: lib.clipenc_op_gemm_fp8(a.data_ptr(), w.data_ptr(), M, N, K, None, sw.data_ptr(), bias.data_ptr(), -1, out.data_ptr(), out.data_ptr(), st)
