@@ -328,7 +328,8 @@ def cpu_baseline(cfg, sd, Ws, bs):
 
 
 KERNEL_SOURCES = (("gemm_fp8", ("gemm_fp8.hip",)), ("gemm_persist", ("gemm_persist.hip", "gemm_tri.hip")), ("attn_", ("attention.hip",)),
-                  ("quant_", ("quant_fp8.hip",)), ("fcreg", ("fcreg.hip",)), ("", ("elementwise.hip",)))
+                  ("quant_", ("quant_fp8.hip",)), ("row_norm_consts", ("quant_fp8.hip",)), ("fcreg", ("fcreg.hip",)),
+                  ("", ("elementwise.hip",)))
 
 
 def kernel_source_sha(kernel_name):

@@ -21,7 +21,7 @@ def per_kernel(path, names):
     dur = collections.defaultdict(float)
     for r in csv.DictReader(open(path)):
         k = r["Kernel_Name"]
-        if not any(s in k for s in ("gemm", "attn", "fcreg", "head_kernel", "patchify", "embed_ln", "quant_")):
+        if not any(s in k for s in ("gemm", "attn", "fcreg", "head_kernel", "patchify", "embed_ln", "quant_", "row_norm")):
             continue
         if r["Counter_Name"] in names:
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
