@@ -113,7 +113,9 @@ def test_gemm_rejects_bad_shapes(gpu):
                                                   (2, 289, 4), (2, 577, 16), (1, 640, 4),
                                                   (8, 257, 16), (20, 250, 4), (70, 225, 1),        # >= 64 tasks: streaming kernel
                                                   (16, 240, 4), (16, 241, 4), (4, 256, 16), (4, 272, 16), (4, 273, 16), (4, 288, 16),   # its last 16-key step: padding only / one real key / full
-                                                  (8, 260, 8), (9, 230, 8), (64, 257, 1)])       # a last block of 4 / 6 / 1 real queries: the loader wave's 16-query path
+                                                  (8, 260, 8), (9, 230, 8), (64, 257, 1),        # a last block of 4 / 6 / 1 real queries
+                                                  # 19 / 20 key tiles of the online-softmax kernel with 2 .. 32 real queries in the last block and a full / one-key last tile
+                                                  (2, 578, 4), (1, 592, 4), (1, 593, 4), (2, 608, 2), (1, 609, 4)])
 def test_attention_matches_fp32_reference(gpu, n_crops, n_tok, heads):
     lib = _lib.load()
     width = heads * 64
