@@ -77,3 +77,52 @@ def test_encoder_repeatability_under_load(gpu):
     sub = vit.encode(crops[123:130])
     assert one_minus_cos(sub.cpu(), first[123:130].cpu()).max().item() < 1e-6
     vit.close()
+
+
+@pytest.mark.parametrize("m,k2", [(131329, 1024), (70001, 4096)])
+def test_fused_fp8_chain_is_stable_over_repeats_and_row_prefixes(gpu, m, k2):
+    """The fused fp8 tower's hand-synchronised pieces in one chain: the residual GEMM that quantises its own rows (cross-wave
+    exchange of the row maxima through LDS + one extra workgroup barrier per tile), the row constants, and the LayerNorm-folded
+    consumer (exponent dwords of the NEXT tile fetched by LDS-DMA under the current one and carried through registers across
+    the epilogue).  Many tiles per workgroup, a ragged last M-tile, twelve back-to-back runs bitwise equal; and every row's
+    result must not depend on how many rows follow it (the first 5 000 rows of the full problem = the 5 000-row problem)."""
+    lib = _lib.load()
+    st = _lib.current_stream_ptr(gpu)
+    F8 = torch.float8_e4m3fn
+    n = 1024
+    g = torch.Generator(device=gpu).manual_seed(m)
+    a8 = (torch.randn(m, k2, device=gpu, generator=g) * 40).clamp(-448, 448).to(F8).view(torch.uint8)
+    w8 = (torch.randn(n, k2, device=gpu, generator=g) * 40).clamp(-448, 448).to(F8).view(torch.uint8)
+    w2 = (torch.randn(768, n, device=gpu, generator=g) * 40).clamp(-448, 448).to(F8).view(torch.uint8)
+    sw = torch.rand(n, device=gpu, generator=g) * 1e-4 + 1e-5
+    sw2 = torch.rand(768, device=gpu, generator=g) * 1e-3 + 1e-4
+    bias = torch.randn(n, device=gpu, generator=g)
+    cs2, b2 = torch.randn(768, device=gpu, generator=g), torch.randn(768, device=gpu, generator=g)
+    x0 = (torch.randn(m, n, device=gpu, generator=g) * torch.logspace(-2, 2, m, device=gpu).view(m, 1)).to(torch.bfloat16)
+
+    def run(rows):
+        ld = (rows + 255) // 256 * 256
+        x = x0[:rows].clone()
+        q = torch.full((rows, n), 0x7f, dtype=torch.uint8, device=gpu)
+        eb = torch.full((rows, 4), 0xff, dtype=torch.uint8, device=gpu)
+        stt = torch.full((n // 64, ld, 2), float("nan"), device=gpu)
+        r = torch.empty(rows, device=gpu)
+        d = torch.empty(rows, device=gpu)
+        out = torch.full((rows, 768), float("nan"), dtype=torch.bfloat16, device=gpu)
+        _lib.check(lib.clipenc_op_gemm_fp8_resid_q(a8.data_ptr(), w8.data_ptr(), rows, n, k2, sw.data_ptr(), bias.data_ptr(), x.data_ptr(),
+                                                   q.data_ptr(), eb.data_ptr(), stt.data_ptr(), ld, st), "resid_q")
+        _lib.check(lib.clipenc_op_row_norm_consts(stt.data_ptr(), n // 64, ld, rows, n, 1e-5, r.data_ptr(), d.data_ptr(), st), "consts")
+        _lib.check(lib.clipenc_op_gemm_fp8_lnf(q.data_ptr(), eb.data_ptr(), w2.data_ptr(), rows, 768, n, r.data_ptr(), d.data_ptr(),
+                                               sw2.data_ptr(), cs2.data_ptr(), b2.data_ptr(), -1, None, out.data_ptr(), st), "lnf")
+        return x, q, eb, out
+
+    first = run(m)
+    assert all(torch.isfinite(t.float()).all() for t in (first[0], first[3]))
+    assert not torch.isnan(first[1].view(F8).float()).any() and (first[2] != 0xff).all()
+    for it in range(11):
+        again = run(m)
+        for t0, t1, name in zip(first, again, ("x", "x8", "exponents", "consumer output")):
+            assert torch.equal(t0, t1), f"run {it + 1}: {name} differs from run 0"
+    head = run(5000)
+    for t0, t1, name in zip(first, head, ("x", "x8", "exponents", "consumer output")):
+        assert torch.equal(t0[:5000], t1), f"{name}: the first 5000 rows depend on the rows behind them"
