@@ -1,0 +1,290 @@
+// Baseline JPEG decoding arithmetic shared by the HIP kernels (jpeg_decode.hip) and the CPU checker (oracle/jpeg_ref.cpp):
+// the entropy decoder of ITU-T T.81 Annex F.2.2 and the three sample-domain steps exactly as the reference's image loader
+// performs them -- /root/reference/utils/embedder.py:167 opens every file with PIL.Image.open(...).convert('RGB'), and Pillow's
+// JPEG plugin is libjpeg-turbo with its defaults: the "islow" integer inverse DCT (Loeffler-Ligtenberg-Moschytz, 13-bit
+// constants, two passes), "fancy" (triangle-filter) chroma upsampling for 2x1 and 2x2 subsampled components, and the 16-bit
+// fixed-point YCbCr -> RGB tables of JFIF.  All three are integer algorithms, so the decoded pixels can be -- and are tested to
+// be -- identical to Pillow's, bit for bit (tests/test_cpu_jpeg.py against the checker, tests/test_gpu_jpeg.py on the device).
+// Restated from the published algorithms (T.81; the LL&M factorisation with libjpeg's documented scaling; JFIF 1.02); the
+// reference repository holds no JPEG code of its own.
+#pragma once
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define JPG_HD __host__ __device__ __forceinline__
+#else
+#define JPG_HD static inline
+#endif
+
+namespace jpg {
+
+enum { MAX_COMPS = 3 };
+
+// One Huffman table, prepared on the host (jpeg_host.cpp): 9-bit lookahead + the canonical-code arrays of T.81 F.2.2.3
+struct HuffTable {
+  uint16_t look[512];        // index = next 9 bits: (code length << 8) | symbol, 0 = the code is longer than 9 bits
+  int32_t maxcode[18];       // largest code of length l (1..16), -1 if none; [17] = sentinel above every 16-bit code
+  int32_t valoffset[17];     // huffval index of the first code of length l, minus that code
+  uint8_t huffval[256];
+};
+
+// Per-image decode plan (host-built; every offset is relative to the batch's device arena)
+struct ImageDesc {
+  int32_t width, height;                 // luma / output size
+  int32_t ncomp;                         // 1 (grey) or 3 (Y Cb Cr)
+  int32_t hs[MAX_COMPS], vs[MAX_COMPS];  // sampling factors
+  int32_t hmax, vmax;
+  int32_t mcus_x, mcus_y;                // interleaved scan: MCUs per row / column (1 component: 8 x 8 blocks)
+  int32_t bw[MAX_COMPS], bh[MAX_COMPS];  // blocks per row / column of the component's (padded) plane
+  int32_t dw[MAX_COMPS], dh[MAX_COMPS];  // real ("downsampled") size of the component in samples
+  int32_t restart_interval;              // MCUs between RSTn markers, 0 = none
+  int32_t dc_tab[MAX_COMPS], ac_tab[MAX_COMPS];   // index into huff[4]: 0,1 = DC tables 0,1; 2,3 = AC tables 0,1
+  uint16_t quant[MAX_COMPS][64];         // natural (row-major) order
+  uint64_t data_off;                     // entropy-coded segment, 16-byte aligned, padded with 0xFF 0xD9 ...
+  uint32_t data_len;
+  uint64_t coef_off[MAX_COMPS];          // int16 [bh][bw][64], zeroed before the entropy kernel
+  uint64_t plane_off[MAX_COMPS];         // uint8 [bh * 8][bw * 8]
+  uint64_t rgb_off;                      // uint8 [height][width][3]
+  uint64_t block_base;                   // index of the image's first 8 x 8 block in the batch-wide block numbering
+  uint32_t n_blocks;
+  int32_t status;                        // written by the entropy kernel: 0 ok, 1 = ran off the data / bad code
+  HuffTable huff[4];
+};
+
+JPG_HD int zigzag_to_natural(int k) {
+  constexpr uint8_t t[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                             41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                             30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+  return t[k & 63];
+}
+
+// ------------------------------------------------------------------------------------------------ entropy-coded segment
+// Bytes come from 8-byte words (the segment starts 16-byte aligned and is padded, so whole words can always be read);
+// 0xFF 0x00 is a data byte 0xFF, 0xFF 0xFF.. are fill bytes, 0xFF <other> is a marker: it ends the data (zero bits are fed
+// from there on, as libjpeg does) until a restart consumes it.
+struct BitReader {
+  const uint64_t* wp;
+  uint64_t word;
+  int wleft;
+  uint64_t bitbuf;             // next bits at the top
+  int bits;
+  int marker;                  // 0 = none pending
+  uint32_t consumed, limit;    // bytes taken from the segment / its padded length
+};
+
+JPG_HD void br_init(BitReader& br, const uint8_t* base, uint32_t padded_len) {
+  br.wp = (const uint64_t*)base; br.word = 0; br.wleft = 0; br.bitbuf = 0; br.bits = 0; br.marker = 0; br.consumed = 0;
+  br.limit = padded_len;
+}
+
+JPG_HD int br_raw_byte(BitReader& br) {
+  if (br.consumed >= br.limit) return 0xD9;                    // (cannot happen with the host's padding; keeps a bad file inside its buffer)
+  if (br.wleft == 0) { br.word = *br.wp++; br.wleft = 8; }
+  const int b = (int)(br.word & 0xffu);
+  br.word >>= 8; br.wleft--; br.consumed++;
+  return b;
+}
+
+JPG_HD void br_fill(BitReader& br) {
+  while (br.bits <= 56) {
+    int b = 0;
+    if (!br.marker) {
+      b = br_raw_byte(br);
+      if (b == 0xFF) {
+        int b2 = br_raw_byte(br);
+        while (b2 == 0xFF) b2 = br_raw_byte(br);               // fill bytes
+        if (b2 != 0) { br.marker = b2; b = 0; }
+      }
+    }
+    br.bitbuf |= (uint64_t)b << (56 - br.bits);
+    br.bits += 8;
+  }
+}
+
+JPG_HD int br_peek16(BitReader& br) {
+  if (br.bits < 16) br_fill(br);
+  return (int)(br.bitbuf >> 48);
+}
+
+JPG_HD void br_skip(BitReader& br, int n) { br.bitbuf <<= n; br.bits -= n; }
+
+JPG_HD int br_get(BitReader& br, int n) {                      // n = 1 .. 16
+  if (br.bits < n) br_fill(br);
+  const int v = (int)(br.bitbuf >> (64 - n));
+  br_skip(br, n);
+  return v;
+}
+
+// one Huffman symbol (T.81 F.2.2.3 DECODE with a 9-bit lookahead); -1 = no such code
+JPG_HD int huff_decode(BitReader& br, const HuffTable& t) {
+  const int c = br_peek16(br);
+  const int e = t.look[c >> 7];
+  if (e) { br_skip(br, e >> 8); return e & 0xff; }
+  int l = 10;
+  while (l <= 16 && (c >> (16 - l)) > t.maxcode[l]) ++l;
+  if (l > 16) return -1;
+  br_skip(br, l);
+  return t.huffval[((c >> (16 - l)) + t.valoffset[l]) & 0xff];
+}
+
+JPG_HD int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }   // T.81 F.2.2.1 EXTEND
+
+// one 8 x 8 block: DC difference + AC run-lengths -> the NONZERO coefficients into coef (natural order; the rest stays 0)
+JPG_HD bool decode_block(BitReader& br, const HuffTable& dc, const HuffTable& ac, int& pred, int16_t* coef) {
+  int s = huff_decode(br, dc);
+  if (s < 0 || s > 11) return false;
+  if (s) pred += extend(br_get(br, s), s);
+  coef[0] = (int16_t)pred;
+  for (int k = 1; k < 64;) {
+    const int rs = huff_decode(br, ac);
+    if (rs < 0) return false;
+    const int r = rs >> 4;
+    s = rs & 15;
+    if (s == 0) {
+      if (r != 15) break;                                      // EOB
+      k += 16;                                                 // ZRL
+      continue;
+    }
+    k += r;
+    if (k > 63) return false;
+    coef[zigzag_to_natural(k)] = (int16_t)extend(br_get(br, s), s);
+    ++k;
+  }
+  return true;
+}
+
+// after a restart interval: drop the bit remainder, the pending marker must be RSTn
+JPG_HD bool br_restart(BitReader& br) {
+  br.bitbuf = 0; br.bits = 0;
+  if (!br.marker) {                                            // the marker has not been run into yet: it is the next thing in the data
+    int b = br_raw_byte(br);
+    if (b != 0xFF) return false;
+    while (b == 0xFF) b = br_raw_byte(br);
+    br.marker = b;
+  }
+  if (br.marker < 0xD0 || br.marker > 0xD7) return false;
+  br.marker = 0;
+  return true;
+}
+
+// the whole scan of one image, sequentially: coef planes of every component
+JPG_HD int decode_scan(const ImageDesc& d, const uint8_t* arena_data, int16_t* const coef[MAX_COMPS], const HuffTable* huff) {
+  BitReader br;
+  br_init(br, arena_data, d.data_len);
+  int pred[MAX_COMPS] = {0, 0, 0};
+  int to_restart = d.restart_interval;
+  for (int my = 0; my < d.mcus_y; ++my) {
+    for (int mx = 0; mx < d.mcus_x; ++mx) {
+      if (d.restart_interval) {
+        if (to_restart == 0) {
+          if (!br_restart(br)) return 1;
+          pred[0] = pred[1] = pred[2] = 0;
+          to_restart = d.restart_interval;
+        }
+        --to_restart;
+      }
+      for (int c = 0; c < d.ncomp; ++c) {
+        const int h = d.ncomp == 1 ? 1 : d.hs[c], v = d.ncomp == 1 ? 1 : d.vs[c];
+        for (int by = 0; by < v; ++by)
+          for (int bx = 0; bx < h; ++bx) {
+            const int brow = my * v + by, bcol = mx * h + bx;
+            if (!decode_block(br, huff[d.dc_tab[c]], huff[d.ac_tab[c]], pred[c], coef[c] + ((size_t)brow * d.bw[c] + bcol) * 64)) return 1;
+          }
+      }
+    }
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ inverse DCT ("islow")
+// Dequantise + 8 x 8 inverse DCT, LL&M with CONST_BITS = 13, PASS1_BITS = 2: columns first into a 32-bit workspace scaled
+// by 4, then rows; the result goes through libjpeg's range-limit table (centre + clamp, index taken modulo 1024).
+JPG_HD uint8_t idct_range_limit(int x) {
+  const int i = x & 1023;
+  return (uint8_t)(i < 128 ? i + 128 : i < 512 ? 255 : i < 896 ? 0 : i - 896);
+}
+
+JPG_HD void idct_1d(const int in[8], int out[8]) {             // outputs NOT descaled: out[0..7] = the eight sums
+  constexpr int F_0_298631336 = 2446, F_0_390180644 = 3196, F_0_541196100 = 4433, F_0_765366865 = 6270, F_0_899976223 = 7373,
+                F_1_175875602 = 9633, F_1_501321110 = 12299, F_1_847759065 = 15137, F_1_961570560 = 16069, F_2_053119869 = 16819,
+                F_2_562915447 = 20995, F_3_072711026 = 25172;
+  int z2 = in[2], z3 = in[6];
+  int z1 = (z2 + z3) * F_0_541196100;
+  int tmp2 = z1 + z3 * (-F_1_847759065);
+  int tmp3 = z1 + z2 * F_0_765366865;
+  z2 = in[0]; z3 = in[4];
+  int tmp0 = (int)((unsigned)(z2 + z3) << 13);
+  int tmp1 = (int)((unsigned)(z2 - z3) << 13);
+  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
+  z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
+  int z4 = tmp1 + tmp3;
+  const int z5 = (z3 + z4) * F_1_175875602;
+  tmp0 *= F_0_298631336; tmp1 *= F_2_053119869; tmp2 *= F_3_072711026; tmp3 *= F_1_501321110;
+  z1 *= -F_0_899976223; z2 *= -F_2_562915447; z3 *= -F_1_961570560; z4 *= -F_0_390180644;
+  z3 += z5; z4 += z5;
+  tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
+  out[0] = tmp10 + tmp3; out[7] = tmp10 - tmp3;
+  out[1] = tmp11 + tmp2; out[6] = tmp11 - tmp2;
+  out[2] = tmp12 + tmp1; out[5] = tmp12 - tmp1;
+  out[3] = tmp13 + tmp0; out[4] = tmp13 - tmp0;
+}
+
+JPG_HD int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// coef: 64 int16 (natural order), quant: 64 uint16 (natural order); out: 8 rows, `pitch` bytes apart
+JPG_HD void idct_block(const int16_t* coef, const uint16_t* quant, uint8_t* out, int pitch) {
+  int ws[64];
+  for (int c = 0; c < 8; ++c) {
+    int in[8], o[8];
+    for (int r = 0; r < 8; ++r) in[r] = (int)coef[r * 8 + c] * (int)quant[r * 8 + c];
+    idct_1d(in, o);
+    for (int r = 0; r < 8; ++r) ws[r * 8 + c] = descale(o[r], 13 - 2);
+  }
+  for (int r = 0; r < 8; ++r) {
+    int o[8];
+    idct_1d(ws + r * 8, o);
+    for (int c = 0; c < 8; ++c) out[r * pitch + c] = idct_range_limit(descale(o[c], 13 + 2 + 3));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ upsampling + colour
+// Sample (x, y) of a component at full resolution.  p: the component's plane (pitch bytes per row), dw x dh its real size,
+// (h, v) = (hmax / hs, vmax / vs) its expansion: 1 x 1 is a copy; 2 x 1 and 2 x 2 use the triangle filters of libjpeg
+// ("fancy upsampling": 3/4 + 1/4 horizontally with alternating rounding, 9/16 + 3/16 + 3/16 + 1/16 for 2 x 2; the rows above the
+// first and below the last real row are those rows again) when the plane is more than 2 samples wide, sample replication
+// otherwise -- as libjpeg chooses.
+JPG_HD int upsampled(const uint8_t* p, int pitch, int dw, int dh, int h, int v, int x, int y) {
+  if (h == 1 && v == 1) return p[(size_t)y * pitch + x];
+  if (h == 2 && v == 1) {
+    const uint8_t* row = p + (size_t)y * pitch;
+    const int i = x >> 1;
+    if (dw <= 2) return row[i];
+    if (x & 1) return i == dw - 1 ? row[i] : (row[i] * 3 + row[i + 1] + 2) >> 2;
+    return i == 0 ? row[0] : (row[i] * 3 + row[i - 1] + 1) >> 2;
+  }
+  if (h == 2 && v == 2) {
+    const int i = x >> 1, r = y >> 1;
+    if (dw <= 2) return p[(size_t)r * pitch + i];
+    int rn = (y & 1) ? r + 1 : r - 1;                          // the nearer neighbouring row
+    rn = rn < 0 ? 0 : rn > dh - 1 ? dh - 1 : rn;
+    const uint8_t* r0 = p + (size_t)r * pitch;
+    const uint8_t* r1 = p + (size_t)rn * pitch;
+    const int cur = r0[i] * 3 + r1[i];
+    if (x & 1) return i == dw - 1 ? (cur * 4 + 7) >> 4 : (cur * 3 + (r0[i + 1] * 3 + r1[i + 1]) + 7) >> 4;
+    return i == 0 ? (cur * 4 + 8) >> 4 : (cur * 3 + (r0[i - 1] * 3 + r1[i - 1]) + 8) >> 4;
+  }
+  return -1;                                                   // (the host refuses every other sampling)
+}
+
+JPG_HD uint8_t clamp255(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }
+
+// JFIF YCbCr -> RGB in libjpeg's 16-bit fixed point (1.40200, 0.34414, 0.71414, 1.77200; the two green terms share one rounding)
+JPG_HD void ycc_to_rgb(int y, int cb, int cr, uint8_t* rgb) {
+  const int xb = cb - 128, xr = cr - 128;
+  rgb[0] = clamp255(y + ((91881 * xr + 32768) >> 16));
+  rgb[1] = clamp255(y + ((-22554 * xb + 32768 - 46802 * xr) >> 16));
+  rgb[2] = clamp255(y + ((116130 * xb + 32768) >> 16));
+}
+
+}  // namespace jpg

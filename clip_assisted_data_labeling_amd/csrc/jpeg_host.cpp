@@ -1,0 +1,166 @@
+// JPEG marker parser + Huffman table builder (host only; see jpeg_host.h).  Follows ITU-T T.81 Annex B (marker syntax) and
+// Annex C (table generation); the colour-space decision is JFIF's / Adobe's APP14 convention as libjpeg applies it.
+#include "jpeg_host.h"
+
+#include <string.h>
+
+namespace jpg {
+
+const char* reason_text(int code) {
+  static const char* const t[] = {"ok", "not a JPEG file", "progressive / lossless / hierarchical", "sample precision is not 8 bits",
+                                  "neither 1 nor 3 components", "chroma sampling other than 4:4:4, 4:2:2 (2x1), 4:2:0 (2x2)",
+                                  "more than one scan / non-interleaved", "colour space other than grey or YCbCr", "missing table",
+                                  "arithmetic coding", "larger than 16384 x 16384", "truncated", "corrupt header"};
+  return code >= 0 && code <= JPG_CORRUPT ? t[code] : "?";
+}
+
+bool build_huff(const uint8_t counts[16], const uint8_t* vals, int nvals, HuffTable* t) {
+  memset(t, 0, sizeof *t);
+  int total = 0;
+  for (int l = 0; l < 16; ++l) total += counts[l];
+  if (total != nvals || total > 256) return false;
+  memcpy(t->huffval, vals, (size_t)total);
+  int code = 0, k = 0;
+  for (int l = 1; l <= 16; ++l) {
+    const int n = counts[l - 1];
+    if (n) {
+      t->valoffset[l] = k - code;
+      for (int i = 0; i < n; ++i, ++k, ++code) {
+        if (code >= (1 << l)) return false;                      // over-subscribed
+        if (l <= 9) {
+          const int first = code << (9 - l);
+          for (int f = 0; f < (1 << (9 - l)); ++f) t->look[first + f] = (uint16_t)((l << 8) | vals[k]);
+        }
+      }
+      t->maxcode[l] = code - 1;
+    } else {
+      t->maxcode[l] = -1;
+      t->valoffset[l] = 0;
+    }
+    code <<= 1;
+  }
+  t->maxcode[17] = 0x7fffffff;
+  return true;
+}
+
+namespace {
+inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
+}
+
+int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, size_t* scan_len) {
+  memset(d, 0, sizeof *d);
+  if (len < 4 || data[0] != 0xFF || data[1] != 0xD8) return JPG_NOT_JPEG;
+  uint16_t qt[4][64];
+  bool have_qt[4] = {false, false, false, false}, have_ht[4] = {false, false, false, false};
+  int comp_id[MAX_COMPS] = {0, 0, 0}, comp_tq[MAX_COMPS] = {0, 0, 0};
+  bool have_sof = false, jfif = false, adobe = false;
+  int adobe_transform = -1;
+  size_t pos = 2;
+  for (;;) {
+    while (pos < len && data[pos] != 0xFF) ++pos;                // (garbage between segments is skipped, as libjpeg does)
+    while (pos < len && data[pos] == 0xFF) ++pos;
+    if (pos >= len) return JPG_TRUNCATED;
+    const int m = data[pos++];
+    if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
+    if (m == 0xD9) return JPG_TRUNCATED;                          // EOI before any scan
+    if (pos + 2 > len) return JPG_TRUNCATED;
+    const int seg = be16(data + pos);
+    if (seg < 2 || pos + (size_t)seg > len) return JPG_TRUNCATED;
+    const uint8_t* s = data + pos + 2;
+    const int n = seg - 2;
+    if (m == 0xE0 && n >= 5 && !memcmp(s, "JFIF\0", 5)) jfif = true;
+    else if (m == 0xEE && n >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_transform = s[11]; }
+    else if (m == 0xDB) {                                         // DQT
+      int i = 0;
+      while (i < n) {
+        const int pq = s[i] >> 4, tq = s[i] & 15;
+        ++i;
+        if (tq > 3 || pq > 1 || i + 64 * (pq + 1) > n) return JPG_CORRUPT;
+        for (int k = 0; k < 64; ++k) {
+          const int v = pq ? be16(s + i + 2 * k) : s[i + k];
+          qt[tq][zigzag_to_natural(k)] = (uint16_t)v;
+        }
+        i += 64 * (pq + 1);
+        have_qt[tq] = true;
+      }
+    } else if (m == 0xC4) {                                       // DHT
+      int i = 0;
+      while (i < n) {
+        if (i + 17 > n) return JPG_CORRUPT;
+        const int tc = s[i] >> 4, th = s[i] & 15;
+        int total = 0;
+        for (int l = 0; l < 16; ++l) total += s[i + 1 + l];
+        if (tc > 1 || i + 17 + total > n) return JPG_CORRUPT;
+        if (th > 1) return JPG_TABLES;                            // (ids 2, 3: extended sequential only; not met in practice)
+        if (!build_huff(s + i + 1, s + i + 17, total, &d->huff[tc * 2 + th])) return JPG_CORRUPT;
+        have_ht[tc * 2 + th] = true;
+        i += 17 + total;
+      }
+    } else if (m == 0xDD) {                                       // DRI
+      if (n < 2) return JPG_CORRUPT;
+      d->restart_interval = be16(s);
+    } else if (m == 0xC0 || m == 0xC1) {                          // SOF0 / SOF1: sequential Huffman
+      if (n < 6) return JPG_CORRUPT;
+      if (s[0] != 8) return JPG_PRECISION;
+      d->height = be16(s + 1); d->width = be16(s + 3); d->ncomp = s[5];
+      if (d->width < 1 || d->height < 1) return JPG_CORRUPT;     // (height 0 = DNL marker: not supported)
+      if (d->width > 16384 || d->height > 16384) return JPG_TOO_LARGE;
+      if (d->ncomp != 1 && d->ncomp != 3) return JPG_COMPONENTS;
+      if (n < 6 + 3 * d->ncomp) return JPG_CORRUPT;
+      for (int c = 0; c < d->ncomp; ++c) {
+        comp_id[c] = s[6 + 3 * c];
+        d->hs[c] = s[7 + 3 * c] >> 4; d->vs[c] = s[7 + 3 * c] & 15;
+        comp_tq[c] = s[8 + 3 * c];
+        if (comp_tq[c] > 3 || d->hs[c] < 1 || d->vs[c] < 1) return JPG_CORRUPT;
+      }
+      have_sof = true;
+    } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+      return (m == 0xC9 || m == 0xCA || m == 0xCB || m == 0xCD || m == 0xCE || m == 0xCF) ? JPG_ARITHMETIC : JPG_PROGRESSIVE;
+    } else if (m == 0xCC) {
+      return JPG_ARITHMETIC;
+    } else if (m == 0xDA) {                                       // SOS
+      if (!have_sof) return JPG_CORRUPT;
+      if (n < 1 || s[0] != d->ncomp) return JPG_MULTI_SCAN;
+      if (n < 1 + 2 * d->ncomp + 3) return JPG_CORRUPT;
+      for (int c = 0; c < d->ncomp; ++c) {
+        if (s[1 + 2 * c] != comp_id[c]) return JPG_MULTI_SCAN;   // (components in frame order)
+        const int td = s[2 + 2 * c] >> 4, ta = s[2 + 2 * c] & 15;
+        if (td > 1 || ta > 1) return JPG_TABLES;
+        if (!have_ht[td] || !have_ht[2 + ta]) return JPG_TABLES;
+        d->dc_tab[c] = td; d->ac_tab[c] = 2 + ta;
+      }
+      const uint8_t* e = s + 1 + 2 * d->ncomp;
+      if (e[0] != 0 || e[1] != 63 || e[2] != 0) return JPG_PROGRESSIVE;
+      // colour space (libjpeg's rules): 1 component = grey; 3 components: JFIF = YCbCr, Adobe transform 0 = RGB, 1 = YCbCr,
+      // otherwise by the component ids (1 2 3 = YCbCr, 'R' 'G' 'B' = RGB, anything else YCbCr)
+      if (d->ncomp == 3) {
+        bool ycc = true;
+        if (jfif) ycc = true;
+        else if (adobe) ycc = adobe_transform == 1;
+        else if (comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') ycc = false;
+        if (!ycc) return JPG_COLORSPACE;
+        if (d->hs[1] != 1 || d->vs[1] != 1 || d->hs[2] != 1 || d->vs[2] != 1) return JPG_SAMPLING;
+        if (!((d->hs[0] == 1 && d->vs[0] == 1) || (d->hs[0] == 2 && d->vs[0] == 1) || (d->hs[0] == 2 && d->vs[0] == 2))) return JPG_SAMPLING;
+        d->hmax = d->hs[0]; d->vmax = d->vs[0];
+      } else {
+        d->hs[0] = d->vs[0] = 1;                                  // a single-component scan is never interleaved: 8 x 8 "MCUs"
+        d->hmax = d->vmax = 1;
+      }
+      d->mcus_x = (d->width + 8 * d->hmax - 1) / (8 * d->hmax);
+      d->mcus_y = (d->height + 8 * d->vmax - 1) / (8 * d->vmax);
+      for (int c = 0; c < d->ncomp; ++c) {
+        if (!have_qt[comp_tq[c]]) return JPG_TABLES;
+        memcpy(d->quant[c], qt[comp_tq[c]], sizeof d->quant[c]);
+        d->bw[c] = d->mcus_x * d->hs[c]; d->bh[c] = d->mcus_y * d->vs[c];
+        d->dw[c] = (d->width * d->hs[c] + d->hmax - 1) / d->hmax;
+        d->dh[c] = (d->height * d->vs[c] + d->vmax - 1) / d->vmax;
+      }
+      *scan_off = pos + (size_t)seg;
+      *scan_len = len - *scan_off;
+      return JPG_OK;
+    }
+    pos += (size_t)seg;
+  }
+}
+
+}  // namespace jpg

@@ -1,0 +1,25 @@
+// Host side of the JPEG decoder: marker parsing and table preparation (no device code; also compiled into the CPU checker
+// oracle/jpeg_ref.cpp).  Supported: baseline / extended-sequential Huffman JPEG, 8 bits, one interleaved scan, greyscale or
+// YCbCr with 4:4:4, 4:2:2 (2x1) or 4:2:0 (2x2) chroma, restart intervals.  Everything else is reported with a reason code and
+// left to the caller (the embed driver hands such files to Pillow).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include "jpeg_core.h"
+
+namespace jpg {
+
+enum {
+  JPG_OK = 0, JPG_NOT_JPEG = 1, JPG_PROGRESSIVE = 2, JPG_PRECISION = 3, JPG_COMPONENTS = 4, JPG_SAMPLING = 5, JPG_MULTI_SCAN = 6,
+  JPG_COLORSPACE = 7, JPG_TABLES = 8, JPG_ARITHMETIC = 9, JPG_TOO_LARGE = 10, JPG_TRUNCATED = 11, JPG_CORRUPT = 12
+};
+
+// Fills every field of *d that does not depend on the batch layout (sizes, sampling, tables); *scan_off / *scan_len = the
+// entropy-coded data (from behind the SOS header to the end of the file).  Returns JPG_OK or the reason the file is not decodable here.
+int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, size_t* scan_len);
+// T.81 Annex C + F.2.2.3: code lengths -> lookahead / maxcode / valoffset; false if the lengths do not describe a prefix code
+bool build_huff(const uint8_t counts[16], const uint8_t* vals, int nvals, HuffTable* t);
+const char* reason_text(int code);
+
+}  // namespace jpg
