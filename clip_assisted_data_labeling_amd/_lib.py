@@ -97,6 +97,11 @@ SIGNATURES = {
     "clipenc_op_gemm_fp8_resid_q": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                             c_void_p, c_int, c_void_p]),
     "clipenc_forward_tokens": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "jpegdec_create": (c_int, [c_int, c_void_p]),
+    "jpegdec_destroy": (c_int, [c_void_p]),
+    "jpegdec_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jpegdec_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jpegdec_reason": (ctypes.c_char_p, [c_int]),
 }
 
 # include/clipenc_diag.h: only in libclipenc_hip_diag.so (`make diag`), bound when present (developer tools)

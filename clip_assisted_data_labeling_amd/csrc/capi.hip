@@ -16,6 +16,7 @@
 
 #include "common.h"
 #include "gemm.h"
+#include "jpeg_host.h"
 #include "kernels.h"
 
 namespace {
@@ -168,6 +169,11 @@ struct clipenc_s {
 struct preproc_s {
   int device = 0;
   PreprocState* st = nullptr;
+};
+
+struct jpegdec_s {
+  int device = 0;
+  JpegDecState* st = nullptr;
 };
 
 struct fctrain_s {
@@ -1140,6 +1146,47 @@ int clipenc_op_gemm_fp8_resid_q(const void* a8_dev, const void* w8_dev, int m, i
   hipError_t err = ce_gemm_fp8(p, EPI_RESID_Q, (hipStream_t)stream);
   if (err != hipSuccess) return fail("gemm_fp8_resid_q(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
   return 0;
+}
+
+int jpegdec_create(int device, jpegdec_t* out) {
+  if (!out) return fail("jpegdec_create: NULL argument");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail("device %d out of range (%d visible)", device, ndev);
+  jpegdec_s* d = new jpegdec_s();
+  d->device = device;
+  d->st = ce_jpegdec_create();
+  *out = d;
+  return 0;
+}
+
+int jpegdec_destroy(jpegdec_t d) {
+  if (!d) return 0;
+  (void)hipSetDevice(d->device);
+  ce_jpegdec_destroy(d->st);
+  delete d;
+  return 0;
+}
+
+int jpegdec_plan(jpegdec_t d, const void* const* files, const size_t* sizes, int n, int* status, int* widths, int* heights,
+                 unsigned long long* rgb_offsets, unsigned long long* rgb_bytes) {
+  if (!d || !files || !sizes || !status || !widths || !heights || !rgb_offsets || !rgb_bytes) return fail("jpegdec_plan: NULL argument");
+  if (n < 0) return fail("jpegdec_plan: n %d < 0", n);
+  ce_jpegdec_plan(d->st, files, sizes, n, status, widths, heights, rgb_offsets, rgb_bytes);
+  return 0;
+}
+
+int jpegdec_run(jpegdec_t d, void* rgb_dev, int* status, void* stream) {
+  if (!d || !status) return fail("jpegdec_run: NULL argument");
+  HIP_TRY(hipSetDevice(d->device));
+  hipError_t err = ce_jpegdec_run(d->st, rgb_dev, status, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("jpegdec_run failed: %s", hipGetErrorString(err));
+  return 0;
+}
+
+const char* jpegdec_reason(int code) {
+  if (code >= 100) return "invalid or truncated entropy-coded data";
+  return jpg::reason_text(code);
 }
 
 int preproc_create(int device, preproc_t* out) {

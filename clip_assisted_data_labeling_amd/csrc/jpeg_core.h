@@ -10,7 +10,7 @@
 #pragma once
 #include <stdint.h>
 
-#ifdef __HIPCC__
+#ifdef __HIP__               /* a HIP translation unit (jpeg_decode.hip); plain C++ everywhere else */
 #define JPG_HD __host__ __device__ __forceinline__
 #else
 #define JPG_HD static inline
@@ -47,7 +47,7 @@ struct ImageDesc {
   uint64_t rgb_off;                      // uint8 [height][width][3]
   uint64_t block_base;                   // index of the image's first 8 x 8 block in the batch-wide block numbering
   uint32_t n_blocks;
-  int32_t status;                        // written by the entropy kernel: 0 ok, 1 = ran off the data / bad code
+  uint32_t data_real;                    // bytes of data_len that come from the file (the rest is the host's padding)
   HuffTable huff[4];
 };
 
@@ -69,11 +69,12 @@ struct BitReader {
   uint64_t bitbuf;             // next bits at the top
   int bits;
   int marker;                  // 0 = none pending
+  int fake;                    // zero bits appended behind a marker that are still unconsumed at most `bits`: consuming one = the data ran out
   uint32_t consumed, limit;    // bytes taken from the segment / its padded length
 };
 
 JPG_HD void br_init(BitReader& br, const uint8_t* base, uint32_t padded_len) {
-  br.wp = (const uint64_t*)base; br.word = 0; br.wleft = 0; br.bitbuf = 0; br.bits = 0; br.marker = 0; br.consumed = 0;
+  br.wp = (const uint64_t*)base; br.word = 0; br.wleft = 0; br.bitbuf = 0; br.bits = 0; br.marker = 0; br.fake = 0; br.consumed = 0;
   br.limit = padded_len;
 }
 
@@ -96,6 +97,7 @@ JPG_HD void br_fill(BitReader& br) {
         if (b2 != 0) { br.marker = b2; b = 0; }
       }
     }
+    if (br.marker) br.fake += 8;
     br.bitbuf |= (uint64_t)b << (56 - br.bits);
     br.bits += 8;
   }
@@ -153,9 +155,13 @@ JPG_HD bool decode_block(BitReader& br, const HuffTable& dc, const HuffTable& ac
   return true;
 }
 
+// true if bits that were never in the file have been consumed (a truncated file: Pillow refuses those, "image file is truncated")
+JPG_HD bool br_starved(const BitReader& br) { return br.bits < br.fake; }
+
 // after a restart interval: drop the bit remainder, the pending marker must be RSTn
 JPG_HD bool br_restart(BitReader& br) {
-  br.bitbuf = 0; br.bits = 0;
+  if (br_starved(br)) return false;
+  br.bitbuf = 0; br.bits = 0; br.fake = 0;
   if (!br.marker) {                                            // the marker has not been run into yet: it is the next thing in the data
     int b = br_raw_byte(br);
     if (b != 0xFF) return false;
@@ -193,7 +199,16 @@ JPG_HD int decode_scan(const ImageDesc& d, const uint8_t* arena_data, int16_t* c
       }
     }
   }
-  return 0;
+  if (br_starved(br)) return 2;
+  // behind the last MCU the next marker must be EOI and must come from the file, not from the padding: Pillow refuses a file that
+  // ends before it ("image file is truncated")
+  if (!br.marker) {
+    int b = br_raw_byte(br);
+    while (b != 0xFF && br.consumed < br.limit) b = br_raw_byte(br);
+    while (b == 0xFF && br.consumed < br.limit) b = br_raw_byte(br);
+    br.marker = b;
+  }
+  return (br.marker == 0xD9 && br.consumed <= d.data_real) ? 0 : 3;
 }
 
 // ------------------------------------------------------------------------------------------------ inverse DCT ("islow")

@@ -35,6 +35,14 @@ hipError_t ce_colsum_fp8(const void* W8, const float* scale, int N, int K, float
 hipError_t ce_static_scale(const void* W_bf16, const float* bias, int N, int K, float* s, float* inv_s, hipStream_t stream);
 hipError_t ce_scale_cols(const void* W_bf16, const float* s, float* out_f32, int N, int K, hipStream_t stream);
 
+// jpeg_decode.hip (+ jpeg_host.cpp): baseline JPEG files -> RGB uint8 on the device, bit-identical to Pillow
+struct JpegDecState;
+JpegDecState* ce_jpegdec_create();
+void ce_jpegdec_destroy(JpegDecState* s);
+void ce_jpegdec_plan(JpegDecState* s, const void* const* files, const size_t* sizes, int n, int* status, int* widths, int* heights,
+                     unsigned long long* rgb_offsets, unsigned long long* rgb_bytes);
+hipError_t ce_jpegdec_run(JpegDecState* s, void* rgb_dev, int* status, hipStream_t stream);
+
 // fctrain.hip
 struct FcTrainState;
 FcTrainState* ce_fctrain_create(int n_layers, const int* sizes, const float* const* W, const float* const* b, float slope, hipError_t* err);

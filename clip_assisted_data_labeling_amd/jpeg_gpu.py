@@ -1,0 +1,67 @@
+"""JPEG files -> uint8 RGB tensors on the GPU (libclipenc_hip.so: jpegdec_*), the decode step of the reference's image loader.
+
+/root/reference/utils/embedder.py:167 opens every image with `PIL.Image.open(path).convert('RGB')` inside DataLoader workers;
+on real data that host-side decode is what bounds the embed driver.  `GpuJpegDecoder.decode` takes the file BYTES of a batch,
+parses the headers on the host and decodes on the device with Pillow's (libjpeg-turbo's default) integer arithmetic, so the
+pixels are identical to Pillow's.  Files it does not take (progressive, CMYK, 4:4:0, ... — `reason`) come back as None and
+the caller decodes them with Pillow.  No CPU fallback inside: without the HIP library this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+
+
+class GpuJpegDecoder:
+    def __init__(self, device="cuda"):
+        self.lib = _lib.load()
+        d = torch.device(device)
+        self.device = torch.device("cuda", d.index if d.index is not None else torch.cuda.current_device())
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.jpegdec_create(self.device.index, ctypes.byref(h)), "jpegdec_create")
+        self.handle = h
+
+    def reason(self, code: int) -> str:
+        return self.lib.jpegdec_reason(int(code)).decode()
+
+    @torch.no_grad()
+    def decode(self, files: Sequence[bytes]) -> Tuple[List[Optional[torch.Tensor]], List[int]]:
+        """files: the bytes of each file -> (images, status): images[i] a uint8 [H, W, 3] tensor on the GPU (a view into one
+        batch buffer) or None when status[i] != 0 (1..12: not decodable here, see `reason`; >= 100: corrupt entropy data)."""
+        n = len(files)
+        if n == 0:
+            return [], []
+        bufs = [bytes(f) if not isinstance(f, bytes) else f for f in files]
+        ptrs = (ctypes.c_char_p * n)(*bufs)
+        sizes = (ctypes.c_size_t * n)(*[len(b) for b in bufs])
+        status = (ctypes.c_int * n)()
+        widths = (ctypes.c_int * n)()
+        heights = (ctypes.c_int * n)()
+        offsets = (ctypes.c_ulonglong * n)()
+        total = ctypes.c_ulonglong()
+        _lib.check(self.lib.jpegdec_plan(self.handle, ptrs, sizes, n, status, widths, heights, offsets, ctypes.byref(total)), "jpegdec_plan")
+        rgb = torch.empty(max(int(total.value), 1), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.jpegdec_run(self.handle, rgb.data_ptr(), status, _lib.current_stream_ptr(self.device)), "jpegdec_run")
+        images: List[Optional[torch.Tensor]] = []
+        for i in range(n):
+            if status[i] != 0:
+                images.append(None)
+                continue
+            h, w, o = heights[i], widths[i], int(offsets[i])
+            images.append(rgb[o:o + h * w * 3].view(h, w, 3))
+        return images, [int(s) for s in status]
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.jpegdec_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass

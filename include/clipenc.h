@@ -245,6 +245,26 @@ int clipenc_clock_probe(int device, unsigned long long* out2_dev, int spin_us, v
 int clipenc_mfma_stream_probe(int device, int fp8, const void* operands_dev, float* sink_dev, long long iters,
                               double* flop_out, void* stream);
 
+/* ---- JPEG files -> RGB on the device: the decode step of the reference's image loader
+ * (/root/reference/utils/embedder.py:167, PIL.Image.open(path).convert('RGB')), bit-identical to Pillow's libjpeg-turbo defaults
+ * (integer "islow" inverse DCT, triangle-filter chroma upsampling, JFIF colour conversion).  Decodable here: baseline and
+ * extended-sequential Huffman JPEG, 8 bits, one interleaved scan, greyscale or YCbCr 4:4:4 / 4:2:2 (2x1) / 4:2:0 (2x2), restart
+ * intervals.  Anything else gets a reason code from jpegdec_plan and is left to the caller (the embed driver gives such files to
+ * Pillow).  One batch at a time per handle: plan (host only), then run. */
+typedef struct jpegdec_s* jpegdec_t;
+int jpegdec_create(int device, jpegdec_t* out);
+int jpegdec_destroy(jpegdec_t d);
+/* files[i] / sizes[i]: the file bytes in host memory (they must stay valid until jpegdec_run returns).  status[i]: 0 = will be
+ * decoded, 1..12 = why not (jpegdec_reason); widths / heights: for every file whose header could be read; rgb_offsets[i]: where
+ * image i's uint8 [height][width][3] starts in an output buffer of *rgb_bytes bytes (images 256-byte aligned). */
+int jpegdec_plan(jpegdec_t d, const void* const* files, const size_t* sizes, int n, int* status, int* widths, int* heights,
+                 unsigned long long* rgb_offsets, unsigned long long* rgb_bytes);
+/* Decodes the planned batch into rgb_dev (device memory, >= *rgb_bytes of the plan) and waits for it.  status[] (the array the
+ * plan filled, or a copy): entries of decoded images become 0, or 100 + code if their entropy-coded data was invalid or short
+ * (their pixels are then undefined). */
+int jpegdec_run(jpegdec_t d, void* rgb_dev, int* status, void* stream);
+const char* jpegdec_reason(int code);
+
 /* Operator-level entry points (used by the parity tests to pin each kernel on its own). */
 #define CLIPENC_DT_BF16 0
 #define CLIPENC_DT_F16 1

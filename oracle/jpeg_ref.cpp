@@ -32,6 +32,7 @@ int jpeg_ref_decode(const uint8_t* data, size_t len, uint8_t* rgb) {
   memcpy(seg.data(), data + so, sl);
   for (size_t i = sl; i + 1 < padded; i += 2) { ((uint8_t*)seg.data())[i] = 0xFF; ((uint8_t*)seg.data())[i + 1] = 0xD9; }
   d.data_len = (uint32_t)padded;
+  d.data_real = (uint32_t)sl;
   std::vector<std::vector<int16_t>> coef(d.ncomp);
   std::vector<std::vector<uint8_t>> plane(d.ncomp);
   int16_t* cp[jpg::MAX_COMPS] = {nullptr, nullptr, nullptr};

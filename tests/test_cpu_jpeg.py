@@ -1,0 +1,71 @@
+"""The JPEG decoding arithmetic of the HIP kernels (csrc/jpeg_core.h + jpeg_host.cpp), run on the CPU by the checker
+oracle/jpeg_ref.cpp, against Pillow -- the decoder behind /root/reference/utils/embedder.py:167.  Integer algorithms on both
+sides: every pixel must be equal.  (The device run of the same sources is tests/test_gpu_jpeg.py.)"""
+import io
+
+import numpy as np
+import pytest
+from PIL import Image, ImageFile
+
+from oracle import jpeg_oracle
+
+ImageFile.MAXBLOCK = 1 << 24
+
+
+def _smooth(rs, h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(xx / 17.0 + yy / 29.0), 128 + 90 * np.cos(xx / 11.0 - yy / 23.0), 128 + 80 * np.sin((xx + yy) / 7.0)], -1)
+    return np.clip(img + rs.randn(h, w, 3) * 12, 0, 255).astype(np.uint8)
+
+
+def _jpeg(img, **kw):
+    b = io.BytesIO()
+    (img if isinstance(img, Image.Image) else Image.fromarray(img)).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def _pil(data):
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+@pytest.mark.parametrize("subsampling", [0, 1, 2])
+def test_checker_equals_pillow_over_sizes_and_qualities(subsampling):
+    rs = np.random.RandomState(subsampling)
+    for (h, w) in [(8, 8), (16, 16), (37, 53), (1, 1), (2, 3), (5, 2), (17, 1), (3, 5), (4, 6), (100, 133), (241, 319)]:
+        for q in (30, 75, 100):
+            for opt in (False, True):
+                data = _jpeg(_smooth(rs, h, w), quality=q, subsampling=subsampling, optimize=opt)
+                assert np.array_equal(jpeg_oracle.decode(data), _pil(data)), (h, w, q, opt)
+
+
+def test_checker_equals_pillow_on_noise_grey_restart_markers_and_saturated_colours():
+    rs = np.random.RandomState(7)
+    noise = rs.randint(0, 256, (123, 211, 3), dtype=np.uint8)
+    files = [_jpeg(noise, quality=q, subsampling=ss) for q in (5, 50, 90, 100) for ss in (0, 1, 2)]
+    files += [_jpeg(rs.randint(0, 256, (77, 91), dtype=np.uint8), quality=80), _jpeg(rs.randint(0, 256, (9, 200), dtype=np.uint8), quality=100, optimize=True)]
+    files += [_jpeg(noise, quality=85, subsampling=ss, **kw) for ss in (0, 1, 2)
+              for kw in ({"restart_marker_blocks": 1}, {"restart_marker_blocks": 5}, {"restart_marker_rows": 1}, {"restart_marker_rows": 3})]
+    ext = np.zeros((40, 40, 3), np.uint8)
+    ext[:20, :20] = 255; ext[20:, :20] = (255, 0, 0); ext[:20, 20:] = (0, 0, 255)
+    files += [_jpeg(ext, quality=100, subsampling=2), _jpeg(ext, quality=10, subsampling=2), _jpeg(rs.randint(0, 256, (512, 512, 3), dtype=np.uint8), quality=90)]
+    for i, data in enumerate(files):
+        assert np.array_equal(jpeg_oracle.decode(data), _pil(data)), i
+
+
+def test_parser_reasons_and_truncation_like_pillow():
+    rs = np.random.RandomState(1)
+    noise = Image.fromarray(rs.randint(0, 256, (64, 80, 3), dtype=np.uint8))
+    good = _jpeg(noise, quality=80)
+    assert jpeg_oracle.info(good) == (0, 80, 64, 3)
+    assert jpeg_oracle.info(_jpeg(noise, quality=80, progressive=True))[0] == 2
+    assert jpeg_oracle.info(_jpeg(noise.convert("CMYK"), quality=80))[0] == 4
+    assert jpeg_oracle.info(_jpeg(noise, quality=80, keep_rgb=True))[0] == 7
+    assert jpeg_oracle.info(b"\x89PNG\r\n\x1a\n" + b"0" * 50)[0] == 1 and jpeg_oracle.info(b"")[0] == 1
+    # Pillow refuses a file whose data or EOI marker is cut off and accepts bytes behind EOI; so does the decoder
+    for cut in (len(good) // 2, len(good) - 10, len(good) - 2, len(good) - 1):
+        with pytest.raises(ValueError):
+            jpeg_oracle.decode(good[:cut])
+        with pytest.raises(OSError):
+            _pil(good[:cut])
+    tail = good + b"abc\xff\x00xyz" * 5
+    assert np.array_equal(jpeg_oracle.decode(tail), _pil(tail))

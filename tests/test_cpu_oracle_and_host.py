@@ -67,7 +67,7 @@ def test_dedup_oracle_matches_reference_golden(golden_dir):
 # ------------------------------------------------------------------ C ABI: load + symbols
 def test_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "clipenc.h")).read()
-    declared = set(re.findall(r"\b((?:clipenc|fcreg|fctrain|dedup|preproc|simsearch|diversity)_[a-z_0-9]+)\s*\(", header))
+    declared = set(re.findall(r"\b((?:clipenc|fcreg|fctrain|dedup|preproc|simsearch|diversity|jpegdec)_[a-z_0-9]+)\s*\(", header))
     assert {"clipenc_create", "clipenc_encode", "fcreg_forward", "clipenc_encode_score", "dedup_find_pairs"} <= declared
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     lib = _lib.load()

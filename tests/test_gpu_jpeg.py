@@ -1,0 +1,94 @@
+"""GPU JPEG decoder (jpeg_decode.hip) against Pillow, the decoder behind /root/reference/utils/embedder.py:167
+(`Image.open(path).convert('RGB')`): integer arithmetic on both sides, so the bar is bit-exact."""
+import io
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image, ImageFile
+
+from clip_assisted_data_labeling_amd.jpeg_gpu import GpuJpegDecoder
+
+pytestmark = pytest.mark.gpu
+ImageFile.MAXBLOCK = 1 << 24
+
+
+def _smooth(rs, h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([128 + 100 * np.sin(xx / 17.0 + yy / 29.0), 128 + 90 * np.cos(xx / 11.0 - yy / 23.0), 128 + 80 * np.sin((xx + yy) / 7.0)], -1)
+    return np.clip(img + rs.randn(h, w, 3) * 12, 0, 255).astype(np.uint8)
+
+
+def _jpeg(arr, **kw):
+    b = io.BytesIO()
+    (arr if isinstance(arr, Image.Image) else Image.fromarray(arr)).save(b, "JPEG", **kw)
+    return b.getvalue()
+
+
+def _pil(data):
+    return np.asarray(Image.open(io.BytesIO(data)).convert("RGB"))
+
+
+def test_decoder_matches_pillow_bit_for_bit_over_sizes_samplings_qualities(gpu):
+    rs = np.random.RandomState(0)
+    files = []
+    for (h, w) in [(8, 8), (16, 16), (37, 53), (64, 48), (1, 1), (2, 3), (5, 2), (17, 1), (3, 5), (100, 133), (241, 319), (480, 640)]:
+        for ss in (0, 1, 2):
+            for q in (30, 90, 100):
+                files.append(_jpeg(_smooth(rs, h, w), quality=q, subsampling=ss, optimize=bool((h + q) & 1)))
+    noise = rs.randint(0, 256, (123, 211, 3), dtype=np.uint8)
+    files += [_jpeg(noise, quality=q, subsampling=ss) for q in (5, 50, 100) for ss in (0, 1, 2)]
+    files += [_jpeg(rs.randint(0, 256, (77, 91), dtype=np.uint8), quality=80)]                       # greyscale
+    files += [_jpeg(noise, quality=85, subsampling=ss, **kw) for ss in (0, 2)
+              for kw in ({"restart_marker_blocks": 1}, {"restart_marker_blocks": 5}, {"restart_marker_rows": 3})]
+    ext = np.zeros((40, 40, 3), np.uint8)
+    ext[:20, :20] = 255; ext[20:, :20] = (255, 0, 0); ext[:20, 20:] = (0, 0, 255)
+    files += [_jpeg(ext, quality=100, subsampling=2), _jpeg(ext, quality=10, subsampling=2)]
+    dec = GpuJpegDecoder(gpu)
+    images, status = dec.decode(files)
+    assert status == [0] * len(files)
+    for i, (img, data) in enumerate(zip(images, files)):
+        ref = _pil(data)
+        assert tuple(img.shape) == ref.shape, i
+        assert np.array_equal(img.cpu().numpy(), ref), f"file {i} ({ref.shape}) differs from Pillow"
+    # a second batch through the same handle (buffers are reused, the arena may grow)
+    big = [_jpeg(rs.randint(0, 256, (512, 512, 3), dtype=np.uint8), quality=90) for _ in range(5)] + [_jpeg(_smooth(rs, 1200, 1600), quality=92)]
+    images, status = dec.decode(big)
+    assert status == [0] * len(big)
+    for img, data in zip(images, big):
+        assert np.array_equal(img.cpu().numpy(), _pil(data))
+    dec.close()
+
+
+def test_decoder_reports_what_it_does_not_take_and_corrupt_data(gpu):
+    rs = np.random.RandomState(1)
+    noise = Image.fromarray(rs.randint(0, 256, (64, 80, 3), dtype=np.uint8))
+    good = _jpeg(noise, quality=80)
+    files = [good, _jpeg(noise, quality=80, progressive=True), _jpeg(noise.convert("CMYK"), quality=80), b"\x89PNG\r\n\x1a\n" + b"0" * 64,
+             _jpeg(noise, quality=80, keep_rgb=True), good[: len(good) // 2], b"", good]
+    dec = GpuJpegDecoder(gpu)
+    images, status = dec.decode(files)
+    assert status[0] == 0 and status[7] == 0
+    assert status[1] == 2 and status[2] == 4 and status[3] == 1 and status[4] == 7 and status[6] == 1
+    assert "progressive" in dec.reason(2) and "colour" in dec.reason(7)
+    # half a file: the header parses, the entropy data runs out -> flagged by the device (or, if the cut fell inside the header, by the parser)
+    assert status[5] >= 100 or status[5] == 11
+    assert all((im is None) == (s != 0) for im, s in zip(images, status))
+    ref = _pil(good)
+    assert np.array_equal(images[0].cpu().numpy(), ref) and np.array_equal(images[7].cpu().numpy(), ref)
+    dec.close()
+
+
+def test_decoded_images_feed_the_gpu_front_end_like_pillow_decoded_ones(gpu):
+    """decode -> crop geometry + bicubic resize on the device: the same crops as from Pillow-decoded arrays."""
+    from clip_assisted_data_labeling_amd.preprocess import GpuCropper
+    rs = np.random.RandomState(2)
+    files = [_jpeg(_smooth(rs, h, w), quality=88, subsampling=ss) for (h, w, ss) in [(300, 400, 2), (512, 384, 1), (257, 257, 0)]]
+    dec = GpuJpegDecoder(gpu)
+    images, status = dec.decode(files)
+    assert status == [0, 0, 0]
+    cropper = GpuCropper(224, gpu)
+    a, names_a = cropper.batch(images)
+    b, names_b = cropper.batch([torch.from_numpy(_pil(f).copy()) for f in files])
+    assert names_a == names_b and torch.equal(a, b)
+    cropper.close(); dec.close()
