@@ -442,8 +442,9 @@ def vit_l14_336_step(dev, Ws, bs):
 
 def embed_e2e(dev, n=4096, size=512, workers=16, batch=256):
     """The real-data rate of the embed driver (/root/reference/_1_embed_with_CLIP.py:95-184 -> embed_driver.Feature_Dataset):
-    `n` generated JPEG files -> DataLoader workers decode -> GPU crop/resize front end -> ViT-L/14 encoder -> one .pt per image;
-    DataLoader start-up included.  JPEG decode runs on the host cores, so this is a property of the box's CPU share too."""
+    `n` generated JPEG files -> decode -> GPU crop/resize front end -> ViT-L/14 encoder -> one .pt per image, start-up included.
+    Two runs over the same files: JPEG decode in DataLoader workers on the host cores (a property of the box's CPU share too), and
+    JPEG decode on the GPU (embed_driver --gpu_decode: the main process only reads the bytes).  Returns (host result, gpu result)."""
     import shutil
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
@@ -461,21 +462,26 @@ def embed_e2e(dev, n=4096, size=512, workers=16, batch=256):
         workers = max(1, min(workers, len(os.sched_getaffinity(0))))
         import contextlib
         import io
-        with contextlib.redirect_stdout(io.StringIO()):
-            enc = CLIP_Encoder(f"{MODEL}/seed0", None, device=f"cuda:{dev.index}")
-            ds = embed_driver.Feature_Dataset(tmp, f"{MODEL}/seed0", batch, shuffle_filenames=False, num_workers=workers, encoder=enc,
-                                              device=f"cuda:{dev.index}", gpu_preprocess=True, force_reencode=True)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n_emb = ds.process()[0]
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-        n_pt = sum(f.endswith(".pt") for f in os.listdir(tmp))
-        enc.model.close()
-        return {"workload": f"embed_driver on {n} generated {size}x{size} JPEG files: host decode ({workers} DataLoader workers) -> GPU front end "
-                            f"-> ViT-L/14 bf16 -> one .pt per image, loader start-up included",
-                "value": round(n_emb / dt, 1), "unit": "images/s", "seconds": round(dt, 2), "images": int(n_emb), "pt_files_written": n_pt,
-                "workers": workers, "batch": batch}
+        out = []
+        for gpu_decode in (False, True):
+            with contextlib.redirect_stdout(io.StringIO()):
+                enc = CLIP_Encoder(f"{MODEL}/seed0", None, device=f"cuda:{dev.index}")
+                ds = embed_driver.Feature_Dataset(tmp, f"{MODEL}/seed0", batch, shuffle_filenames=False, num_workers=workers, encoder=enc,
+                                                  device=f"cuda:{dev.index}", gpu_preprocess=True, force_reencode=True, gpu_decode=gpu_decode)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                n_emb = ds.process()[0]
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            n_pt = sum(f.endswith(".pt") for f in os.listdir(tmp))
+            enc.model.close()
+            how = ("JPEG decode on the GPU (bit-identical to Pillow), the main process reads the bytes" if gpu_decode
+                   else f"host decode ({workers} DataLoader workers)")
+            out.append({"workload": f"embed_driver on {n} generated {size}x{size} noise JPEG files (quality 90, 4:2:0, ~230 KB each: the entropy "
+                                    f"decoder's worst case): {how} -> GPU front end -> ViT-L/14 bf16 -> one .pt per image, start-up included",
+                        "value": round(n_emb / dt, 1), "unit": "images/s", "seconds": round(dt, 2), "images": int(n_emb), "pt_files_written": n_pt,
+                        "workers": 0 if gpu_decode else workers, "batch": batch})
+        return tuple(out)
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -744,7 +750,7 @@ def main():
                 torch.cuda.empty_cache()
             if "e2e" in want:
                 try:
-                    sec["embed_e2e"] = embed_e2e(dev)
+                    sec["embed_e2e"], sec["embed_e2e_gpu_decode"] = embed_e2e(dev)
                 except Exception as exc:                               # host-side (loader workers, /tmp): never lose the line to it
                     sec["embed_e2e"] = {"error": f"{type(exc).__name__}: {exc}"}
             line["secondary"] = sec

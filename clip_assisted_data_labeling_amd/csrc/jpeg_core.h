@@ -1,10 +1,10 @@
-// Baseline JPEG decoding arithmetic shared by the HIP kernels (jpeg_decode.hip) and the CPU checker (oracle/jpeg_ref.cpp):
+// Baseline JPEG decoding arithmetic shared by the HIP kernels (jpeg_decode.hip) and the CPU checker of the test infrastructure (jpeg_ref.cpp):
 // the entropy decoder of ITU-T T.81 Annex F.2.2 and the three sample-domain steps exactly as the reference's image loader
 // performs them -- /root/reference/utils/embedder.py:167 opens every file with PIL.Image.open(...).convert('RGB'), and Pillow's
 // JPEG plugin is libjpeg-turbo with its defaults: the "islow" integer inverse DCT (Loeffler-Ligtenberg-Moschytz, 13-bit
 // constants, two passes), "fancy" (triangle-filter) chroma upsampling for 2x1 and 2x2 subsampled components, and the 16-bit
 // fixed-point YCbCr -> RGB tables of JFIF.  All three are integer algorithms, so the decoded pixels can be -- and are tested to
-// be -- identical to Pillow's, bit for bit (tests/test_cpu_jpeg.py against the checker, tests/test_gpu_jpeg.py on the device).
+// be -- identical to Pillow's, bit for bit (tests/test_cpu_jpeg.py through the checker, tests/test_gpu_jpeg.py on the device).
 // Restated from the published algorithms (T.81; the LL&M factorisation with libjpeg's documented scaling; JFIF 1.02); the
 // reference repository holds no JPEG code of its own.
 #pragma once
@@ -57,6 +57,8 @@ JPG_HD int zigzag_to_natural(int k) {
                              30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
   return t[k & 63];
 }
+// (the entropy kernel keeps a copy of that table in LDS and passes it as `zz`: a constant array is a global-memory load per
+// coefficient on the device)
 
 // ------------------------------------------------------------------------------------------------ entropy-coded segment
 // Bytes come from 8-byte words (the segment starts 16-byte aligned and is padded, so whole words can always be read);
@@ -64,7 +66,7 @@ JPG_HD int zigzag_to_natural(int k) {
 // from there on, as libjpeg does) until a restart consumes it.
 struct BitReader {
   const uint64_t* wp;
-  uint64_t word;
+  uint64_t word, ahead;        // `ahead` is the word behind `word`, loaded one word early: its latency passes under 8 bytes of decoding
   int wleft;
   uint64_t bitbuf;             // next bits at the top
   int bits;
@@ -76,11 +78,15 @@ struct BitReader {
 JPG_HD void br_init(BitReader& br, const uint8_t* base, uint32_t padded_len) {
   br.wp = (const uint64_t*)base; br.word = 0; br.wleft = 0; br.bitbuf = 0; br.bits = 0; br.marker = 0; br.fake = 0; br.consumed = 0;
   br.limit = padded_len;
+  br.ahead = *br.wp++;                                         // (the segment is at least 32 bytes long with its padding)
 }
 
 JPG_HD int br_raw_byte(BitReader& br) {
   if (br.consumed >= br.limit) return 0xD9;                    // (cannot happen with the host's padding; keeps a bad file inside its buffer)
-  if (br.wleft == 0) { br.word = *br.wp++; br.wleft = 8; }
+  if (br.wleft == 0) {
+    br.word = br.ahead; br.wleft = 8;
+    if (br.consumed + 16 <= br.limit) br.ahead = *br.wp++;     // never reads past the padded segment
+  }
   const int b = (int)(br.word & 0xffu);
   br.word >>= 8; br.wleft--; br.consumed++;
   return b;
@@ -132,7 +138,7 @@ JPG_HD int huff_decode(BitReader& br, const HuffTable& t) {
 JPG_HD int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }   // T.81 F.2.2.1 EXTEND
 
 // one 8 x 8 block: DC difference + AC run-lengths -> the NONZERO coefficients into coef (natural order; the rest stays 0)
-JPG_HD bool decode_block(BitReader& br, const HuffTable& dc, const HuffTable& ac, int& pred, int16_t* coef) {
+JPG_HD bool decode_block(BitReader& br, const HuffTable& dc, const HuffTable& ac, const uint8_t* zz, int& pred, int16_t* coef) {
   int s = huff_decode(br, dc);
   if (s < 0 || s > 11) return false;
   if (s) pred += extend(br_get(br, s), s);
@@ -149,7 +155,7 @@ JPG_HD bool decode_block(BitReader& br, const HuffTable& dc, const HuffTable& ac
     }
     k += r;
     if (k > 63) return false;
-    coef[zigzag_to_natural(k)] = (int16_t)extend(br_get(br, s), s);
+    coef[zz[k]] = (int16_t)extend(br_get(br, s), s);
     ++k;
   }
   return true;
@@ -173,29 +179,54 @@ JPG_HD bool br_restart(BitReader& br) {
   return true;
 }
 
-// the whole scan of one image, sequentially: coef planes of every component
-JPG_HD int decode_scan(const ImageDesc& d, const uint8_t* arena_data, int16_t* const coef[MAX_COMPS], const HuffTable* huff) {
+// what the scan walk needs of an ImageDesc, by value (registers on the device: the descriptor itself lives in global memory,
+// and every coefficient store could alias it)
+struct ScanGeom {
+  int ncomp, mcus_x, mcus_y, restart_interval;
+  int h[MAX_COMPS], v[MAX_COMPS], bw[MAX_COMPS], dc[MAX_COMPS], ac[MAX_COMPS];
+  uint32_t data_len, data_real;
+};
+
+JPG_HD ScanGeom scan_geom(const ImageDesc& d) {
+  ScanGeom g;
+  g.ncomp = d.ncomp; g.mcus_x = d.mcus_x; g.mcus_y = d.mcus_y; g.restart_interval = d.restart_interval;
+  for (int c = 0; c < MAX_COMPS; ++c) {
+    g.h[c] = d.ncomp == 1 ? 1 : d.hs[c]; g.v[c] = d.ncomp == 1 ? 1 : d.vs[c];
+    g.bw[c] = d.bw[c]; g.dc[c] = d.dc_tab[c]; g.ac[c] = d.ac_tab[c];
+  }
+  g.data_len = d.data_len; g.data_real = d.data_real;
+  return g;
+}
+
+// the whole scan of one image, sequentially: coef planes of every component.  0 = ok, 1 = invalid code / coefficient index /
+// restart marker, 2 = the data ran out, 3 = no EOI marker behind the scan
+JPG_HD int decode_scan(const ScanGeom g, const uint8_t* arena_data, int16_t* const coef[MAX_COMPS], const HuffTable* huff, const uint8_t* zz) {
   BitReader br;
-  br_init(br, arena_data, d.data_len);
-  int pred[MAX_COMPS] = {0, 0, 0};
-  int to_restart = d.restart_interval;
-  for (int my = 0; my < d.mcus_y; ++my) {
-    for (int mx = 0; mx < d.mcus_x; ++mx) {
-      if (d.restart_interval) {
+  br_init(br, arena_data, g.data_len);
+  int pred0 = 0, pred1 = 0, pred2 = 0;
+  int to_restart = g.restart_interval;
+  for (int my = 0; my < g.mcus_y; ++my) {
+    for (int mx = 0; mx < g.mcus_x; ++mx) {
+      if (g.restart_interval) {
         if (to_restart == 0) {
           if (!br_restart(br)) return 1;
-          pred[0] = pred[1] = pred[2] = 0;
-          to_restart = d.restart_interval;
+          pred0 = pred1 = pred2 = 0;
+          to_restart = g.restart_interval;
         }
         --to_restart;
       }
-      for (int c = 0; c < d.ncomp; ++c) {
-        const int h = d.ncomp == 1 ? 1 : d.hs[c], v = d.ncomp == 1 ? 1 : d.vs[c];
-        for (int by = 0; by < v; ++by)
-          for (int bx = 0; bx < h; ++bx) {
-            const int brow = my * v + by, bcol = mx * h + bx;
-            if (!decode_block(br, huff[d.dc_tab[c]], huff[d.ac_tab[c]], pred[c], coef[c] + ((size_t)brow * d.bw[c] + bcol) * 64)) return 1;
-          }
+#if defined(__HIP__)
+#pragma unroll
+#endif
+      for (int c = 0; c < MAX_COMPS; ++c) {
+        if (c < g.ncomp) {
+          int& pred = c == 0 ? pred0 : c == 1 ? pred1 : pred2;
+          for (int by = 0; by < g.v[c]; ++by)
+            for (int bx = 0; bx < g.h[c]; ++bx) {
+              const int brow = my * g.v[c] + by, bcol = mx * g.h[c] + bx;
+              if (!decode_block(br, huff[g.dc[c]], huff[g.ac[c]], zz, pred, coef[c] + ((size_t)brow * g.bw[c] + bcol) * 64)) return 1;
+            }
+        }
       }
     }
   }
@@ -208,7 +239,7 @@ JPG_HD int decode_scan(const ImageDesc& d, const uint8_t* arena_data, int16_t* c
     while (b == 0xFF && br.consumed < br.limit) b = br_raw_byte(br);
     br.marker = b;
   }
-  return (br.marker == 0xD9 && br.consumed <= d.data_real) ? 0 : 3;
+  return (br.marker == 0xD9 && br.consumed <= g.data_real) ? 0 : 3;
 }
 
 // ------------------------------------------------------------------------------------------------ inverse DCT ("islow")

@@ -26,17 +26,19 @@ namespace {
 __global__ __launch_bounds__(64) void jpeg_entropy_kernel(const ImageDesc* __restrict__ descs, int* __restrict__ status,
                                                           uint8_t* __restrict__ arena) {
   __shared__ jpg::HuffTable tabs[4];
+  __shared__ uint8_t zz[64];
   const ImageDesc& d = descs[blockIdx.x];
   {
     const uint32_t* src = (const uint32_t*)d.huff;
     uint32_t* dst = (uint32_t*)tabs;
     for (int i = threadIdx.x; i < (int)(sizeof(tabs) / 4); i += 64) dst[i] = src[i];
+    zz[threadIdx.x] = (uint8_t)jpg::zigzag_to_natural(threadIdx.x);
   }
   __syncthreads();
   if (threadIdx.x != 0) return;
   int16_t* coef[jpg::MAX_COMPS];
   for (int c = 0; c < jpg::MAX_COMPS; ++c) coef[c] = (int16_t*)(arena + d.coef_off[c]);
-  status[blockIdx.x] = jpg::decode_scan(d, arena + d.data_off, coef, tabs);
+  status[blockIdx.x] = jpg::decode_scan(jpg::scan_geom(d), arena + d.data_off, coef, tabs, zz);
 }
 
 // image of a batch-wide index: descs[i].base <= idx < descs[i + 1].base

@@ -1,5 +1,5 @@
 // Host side of the JPEG decoder: marker parsing and table preparation (no device code; also compiled into the CPU checker
-// oracle/jpeg_ref.cpp).  Supported: baseline / extended-sequential Huffman JPEG, 8 bits, one interleaved scan, greyscale or
+// the tests' jpeg_ref.cpp).  Supported: baseline / extended-sequential Huffman JPEG, 8 bits, one interleaved scan, greyscale or
 // YCbCr with 4:4:4, 4:2:2 (2x1) or 4:2:0 (2x2) chroma, restart intervals.  Everything else is reported with a reason code and
 // left to the caller (the embed driver hands such files to Pillow).
 #pragma once

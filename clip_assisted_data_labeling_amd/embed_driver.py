@@ -109,8 +109,15 @@ def already_embedded(feature_path: str, model_name: str) -> bool:
 class Feature_Dataset:
     def __init__(self, root_dir, model_name, batch_size, model_path=None, force_reencode=False,
                  shuffle_filenames=True, num_workers=0, crop_names=None, encoder=None, device="cuda",
-                 gpu_preprocess=False, packed_store=None, shard_images=8192):
+                 gpu_preprocess=False, packed_store=None, shard_images=8192, gpu_decode=False, decode_chunk=2048):
         self.device = device
+        # gpu_decode: no decoding workers at all -- the main process reads file bytes (a small thread pool), the GPU decodes
+        # the JPEGs (jpeg_gpu.GpuJpegDecoder, bit-identical to Pillow) `decode_chunk` files at a time (the entropy decoder is
+        # one serial stream per file: its parallelism is the number of files in flight) and the GPU front end crops / resizes.
+        # Files the decoder does not take (progressive, CMYK, PNG, ...) are decoded by Pillow here, as the reference does.
+        self.gpu_decode = bool(gpu_decode)
+        self.decode_chunk = max(int(decode_chunk), 1)
+        gpu_preprocess = gpu_preprocess or self.gpu_decode
         self.packed_store = packed_store
         self.shard_images = int(shard_images)     # images per sealed shard = the most a killed rank can lose
         self.root_dir = root_dir
@@ -146,6 +153,10 @@ class Feature_Dataset:
         if gpu_preprocess:                                 # crop geometry + bicubic resize on the GPU (bit-exact with Pillow)
             from .preprocess import GpuCropper
             self.cropper = GpuCropper(self.encoder.img_resolution, self.device, self.crop_names)
+        self.jpeg = None
+        if self.gpu_decode:
+            from .jpeg_gpu import GpuJpegDecoder
+            self.jpeg = GpuJpegDecoder(self.device)
 
     def __len__(self):
         return len(self.img_filepaths)
@@ -181,7 +192,7 @@ class Feature_Dataset:
         on_gpu = torch.device(self.device).type == "cuda" and torch.cuda.is_available()
         # decoded images reach the main process in page-locked memory (the loader's pin thread copies them there in the
         # background), so the per-image upload is an asynchronous DMA instead of a 0.6 ms synchronous pageable copy
-        loader = DataLoader(dataset, pin_memory=on_gpu, **kwargs)
+        loader = DataLoader(dataset, pin_memory=on_gpu, **kwargs) if self.jpeg is None else []   # (gpu_decode: no workers)
 
         def finish(batch, features):
             """Host side of one batch: embeddings [sum crops, E] (CPU fp32) -> the store."""
@@ -221,9 +232,54 @@ class Feature_Dataset:
         # decodes / crops batch i+1 and writes batch i-1 to the store; the only waits are on that older batch's copy event.
         pending = None                                     # (batch meta, pinned host tensor, event)
 
+        def gpu_decoded_batches():
+            """`decode_chunk` files at a time: bytes (read ahead by a thread pool while the GPU works on the chunk before) ->
+            GPU JPEG decode -> encode batches of (uint8 [H, W, 3] device tensor, "", path, True)"""
+            nonlocal n_failed
+            import numpy as np
+            from concurrent.futures import ThreadPoolExecutor
+
+            def read(path):
+                try:
+                    with open(path, "rb") as f:
+                        return f.read()
+                except Exception as e:
+                    print(f"Error loading or processing image {path}: {e}")
+                    return None
+
+            chunks = [todo[i:i + self.decode_chunk] for i in range(0, len(todo), self.decode_chunk)]
+            with ThreadPoolExecutor(max(2, min(16, self.num_workers or 8))) as pool:
+                ahead = [pool.submit(lambda c=c: [read(p) for p in c]) for c in chunks[:1]]
+                for ci, chunk in enumerate(chunks):
+                    if ci + 1 < len(chunks):
+                        ahead.append(pool.submit(lambda c=chunks[ci + 1]: [read(p) for p in c]))
+                    blobs = ahead.pop(0).result()
+                    images, status = self.jpeg.decode([b if b is not None else b"" for b in blobs])
+                    acc = []
+                    for path, blob, img, st in zip(chunk, blobs, images, status):
+                        if img is None and blob is not None:      # not a baseline JPEG the device takes: Pillow, as the reference
+                            try:
+                                import io
+                                arr = np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"), dtype=np.uint8)
+                                img = torch.from_numpy(arr.copy())
+                            except Exception as e:
+                                print(f"Error loading or processing image {path}: {e}")
+                        if img is None:
+                            n_failed += 1
+                            continue
+                        acc.append((img, "", path, True))
+                        if len(acc) == self.batch_size:
+                            yield acc
+                            acc = []
+                    if acc:
+                        yield acc
+
         def encode_batches():
             """loader batches regrouped into encode batches of `batch_size` images"""
             nonlocal n_failed
+            if self.jpeg is not None:
+                yield from gpu_decoded_batches()
+                return
             acc = []
             for ok_part, bad in loader:
                 n_failed += len(bad)
@@ -286,6 +342,9 @@ def main(argv=None):
     parser.add_argument("--model_path", type=str, default=None, help="Local directory (or file) holding the model weights")
     parser.add_argument("--gpu_preprocess", action="store_true",
                         help="Workers only decode; crops, bicubic resize and normalise run on the GPU (bit-exact with Pillow)")
+    parser.add_argument("--gpu_decode", action="store_true",
+                        help="JPEG files are decoded on the GPU too (bit-identical to Pillow; implies --gpu_preprocess); other "
+                             "formats and JPEG variants the decoder does not take go through Pillow in the main process")
     parser.add_argument("--packed_store", type=str, default=None,
                         help="Write embeddings to packed shards in this directory instead of one .pt per image")
     args = parser.parse_args(argv)
@@ -298,7 +357,8 @@ def main(argv=None):
         print(f"\n--- Processing model: {model_name} ---")
         Feature_Dataset(args.root_dir, model_name, args.batch_size, model_path=args.model_path,
                         force_reencode=args.force_reencode, num_workers=args.num_workers, crop_names=CROP_NAMES,
-                        device=device, gpu_preprocess=args.gpu_preprocess, packed_store=args.packed_store).process()
+                        device=device, gpu_preprocess=args.gpu_preprocess, packed_store=args.packed_store,
+                        gpu_decode=args.gpu_decode).process()
 
 
 if __name__ == "__main__":

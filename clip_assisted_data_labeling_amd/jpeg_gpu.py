@@ -29,31 +29,49 @@ class GpuJpegDecoder:
         return self.lib.jpegdec_reason(int(code)).decode()
 
     @torch.no_grad()
-    def decode(self, files: Sequence[bytes]) -> Tuple[List[Optional[torch.Tensor]], List[int]]:
-        """files: the bytes of each file -> (images, status): images[i] a uint8 [H, W, 3] tensor on the GPU (a view into one
-        batch buffer) or None when status[i] != 0 (1..12: not decodable here, see `reason`; >= 100: corrupt entropy data)."""
+    def decode(self, files: Sequence[bytes], max_batch_pixels: int = 400_000_000) -> Tuple[List[Optional[torch.Tensor]], List[int]]:
+        """files: the bytes of each file -> (images, status): images[i] a uint8 [H, W, 3] tensor on the GPU (a view into a
+        batch buffer) or None when status[i] != 0 (1..12: not decodable here, see `reason`; >= 100: corrupt or truncated entropy
+        data).  The device works on all files of a call at once -- the entropy decoder is one serial stream per file, so its
+        throughput IS the number of files in flight -- except that a call is split into groups of at most `max_batch_pixels`
+        pixels (7.5 bytes of device scratch + output per pixel: 3 GB at the default)."""
         n = len(files)
         if n == 0:
             return [], []
         bufs = [bytes(f) if not isinstance(f, bytes) else f for f in files]
-        ptrs = (ctypes.c_char_p * n)(*bufs)
-        sizes = (ctypes.c_size_t * n)(*[len(b) for b in bufs])
-        status = (ctypes.c_int * n)()
-        widths = (ctypes.c_int * n)()
-        heights = (ctypes.c_int * n)()
-        offsets = (ctypes.c_ulonglong * n)()
-        total = ctypes.c_ulonglong()
-        _lib.check(self.lib.jpegdec_plan(self.handle, ptrs, sizes, n, status, widths, heights, offsets, ctypes.byref(total)), "jpegdec_plan")
-        rgb = torch.empty(max(int(total.value), 1), dtype=torch.uint8, device=self.device)
-        _lib.check(self.lib.jpegdec_run(self.handle, rgb.data_ptr(), status, _lib.current_stream_ptr(self.device)), "jpegdec_run")
-        images: List[Optional[torch.Tensor]] = []
-        for i in range(n):
-            if status[i] != 0:
-                images.append(None)
-                continue
-            h, w, o = heights[i], widths[i], int(offsets[i])
-            images.append(rgb[o:o + h * w * 3].view(h, w, 3))
-        return images, [int(s) for s in status]
+        images: List[Optional[torch.Tensor]] = [None] * n
+        status_all = [0] * n
+        start = 0
+        while start < n:
+            # headers of the rest (host only, microseconds per file), then as many files as fit the pixel budget
+            m = n - start
+            ptrs = (ctypes.c_char_p * m)(*bufs[start:])
+            sizes = (ctypes.c_size_t * m)(*[len(b) for b in bufs[start:]])
+            status = (ctypes.c_int * m)()
+            widths = (ctypes.c_int * m)()
+            heights = (ctypes.c_int * m)()
+            offsets = (ctypes.c_ulonglong * m)()
+            total = ctypes.c_ulonglong()
+            _lib.check(self.lib.jpegdec_plan(self.handle, ptrs, sizes, m, status, widths, heights, offsets, ctypes.byref(total)), "jpegdec_plan")
+            take, pixels = 0, 0
+            while take < m:
+                px = widths[take] * heights[take] if status[take] == 0 else 0
+                if take > 0 and pixels + px > max_batch_pixels:
+                    break
+                pixels += px
+                take += 1
+            if take < m:                                          # plan again for the group that fits
+                _lib.check(self.lib.jpegdec_plan(self.handle, ptrs, sizes, take, status, widths, heights, offsets, ctypes.byref(total)),
+                           "jpegdec_plan")
+            rgb = torch.empty(max(int(total.value), 1), dtype=torch.uint8, device=self.device)
+            _lib.check(self.lib.jpegdec_run(self.handle, rgb.data_ptr(), status, _lib.current_stream_ptr(self.device)), "jpegdec_run")
+            for i in range(take):
+                status_all[start + i] = int(status[i])
+                if status[i] == 0:
+                    h, w, o = heights[i], widths[i], int(offsets[i])
+                    images[start + i] = rgb[o:o + h * w * 3].view(h, w, 3)
+            start += take
+        return images, status_all
 
     def close(self):
         if getattr(self, "handle", None):

@@ -41,7 +41,9 @@ int jpeg_ref_decode(const uint8_t* data, size_t len, uint8_t* rgb) {
     plane[c].assign((size_t)d.bw[c] * d.bh[c] * 64, 0);
     cp[c] = coef[c].data();
   }
-  const int st = jpg::decode_scan(d, (const uint8_t*)seg.data(), cp, d.huff);
+  uint8_t zz[64];
+  for (int k = 0; k < 64; ++k) zz[k] = (uint8_t)jpg::zigzag_to_natural(k);
+  const int st = jpg::decode_scan(jpg::scan_geom(d), (const uint8_t*)seg.data(), cp, d.huff, zz);
   if (st) return 100 + st;
   for (int c = 0; c < d.ncomp; ++c) {
     const int pitch = d.bw[c] * 8;

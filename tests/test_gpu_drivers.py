@@ -56,6 +56,24 @@ def test_embed_predict_dedup_pipeline(gpu, tmp_path):
         new = torch.load(os.path.join(root, f), weights_only=True)
         assert all(torch.equal(new[MODEL][c], old[MODEL][c]) for c in CROP_NAMES), f
 
+    # ... and so is the store written with the JPEG decode on the GPU as well (no decoding worker at all), including the files the
+    # device decoder hands to Pillow: a progressive JPEG and a PNG are added for this run
+    Image.open(os.path.join(root, "a002.jpg")).save(os.path.join(root, "b_prog.jpg"), quality=90, progressive=True)
+    Image.open(os.path.join(root, "a004.jpg")).save(os.path.join(root, "b_png.png"))
+    ref_run = embed_driver.Feature_Dataset(root, MODEL, 4, shuffle_filenames=False, num_workers=0, device="cuda", force_reencode=True,
+                                           gpu_preprocess=True)
+    assert ref_run.process() == (11, 0, 0)
+    before = {f: torch.load(os.path.join(root, f), weights_only=True) for f in sorted(os.listdir(root)) if f.endswith(".pt")}
+    assert len(before) == 11
+    ds3 = embed_driver.Feature_Dataset(root, MODEL, 4, shuffle_filenames=False, num_workers=0, device="cuda", force_reencode=True,
+                                       gpu_decode=True, decode_chunk=5)
+    assert ds3.process() == (11, 0, 0)
+    for f, old in before.items():
+        new = torch.load(os.path.join(root, f), weights_only=True)
+        assert all(torch.equal(new[MODEL][c], old[MODEL][c]) for c in CROP_NAMES), f
+    for f in ("b_prog.jpg", "b_prog.pt", "b_png.png", "b_png.pt"):
+        os.remove(os.path.join(root, f))
+
     # regressor checkpoint in the reference's pickle format, then the predict driver
     sizes = [2 * cfg.embed_dim, 32, 16, 8, 1]
     Ws, bs = np_fc_weights(sizes, 5)
