@@ -243,54 +243,61 @@ JPG_HD int decode_scan(const ScanGeom g, const uint8_t* arena_data, int16_t* con
 }
 
 // ------------------------------------------------------------------------------------------------ inverse DCT ("islow")
-// Dequantise + 8 x 8 inverse DCT, LL&M with CONST_BITS = 13, PASS1_BITS = 2: columns first into a 32-bit workspace scaled
-// by 4, then rows; the result goes through libjpeg's range-limit table (centre + clamp, index taken modulo 1024).
-JPG_HD uint8_t idct_range_limit(int x) {
-  const int i = x & 1023;
-  return (uint8_t)(i < 128 ? i + 128 : i < 512 ? 255 : i < 896 ? 0 : i - 896);
-}
+// Dequantise + 8 x 8 inverse DCT, LL&M with CONST_BITS = 13, PASS1_BITS = 2: columns first into a workspace scaled by 4, then
+// rows, then centre and clamp.  Written the way libjpeg-turbo's SIMD routine computes it (that is what Pillow executes): the
+// dequantised coefficient is a 16-bit product (wraps), sums and products are 32-bit (wrap), the workspace saturates to 16 bits,
+// the result saturates to a signed byte before the centre is added.  On valid data none of this ever triggers and the result is
+// the textbook islow transform; on damaged data it keeps the pixels equal to Pillow's, and all of it is defined arithmetic
+// (unsigned wrap-around, no signed overflow).
+JPG_HD int32_t wadd(int32_t a, int32_t b) { return (int32_t)((uint32_t)a + (uint32_t)b); }
+JPG_HD int32_t wsub(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); }
+JPG_HD int32_t wmul(int32_t a, int32_t b) { return (int32_t)((uint32_t)a * (uint32_t)b); }
+JPG_HD int32_t sat16(int32_t x) { return x < -32768 ? -32768 : x > 32767 ? 32767 : x; }
 
-JPG_HD void idct_1d(const int in[8], int out[8]) {             // outputs NOT descaled: out[0..7] = the eight sums
+JPG_HD void idct_1d(const int32_t in[8], int32_t out[8]) {     // outputs NOT descaled: out[0..7] = the eight sums
   constexpr int F_0_298631336 = 2446, F_0_390180644 = 3196, F_0_541196100 = 4433, F_0_765366865 = 6270, F_0_899976223 = 7373,
                 F_1_175875602 = 9633, F_1_501321110 = 12299, F_1_847759065 = 15137, F_1_961570560 = 16069, F_2_053119869 = 16819,
                 F_2_562915447 = 20995, F_3_072711026 = 25172;
-  int z2 = in[2], z3 = in[6];
-  int z1 = (z2 + z3) * F_0_541196100;
-  int tmp2 = z1 + z3 * (-F_1_847759065);
-  int tmp3 = z1 + z2 * F_0_765366865;
+  int32_t z2 = in[2], z3 = in[6];
+  int32_t z1 = wmul(wadd(z2, z3), F_0_541196100);
+  int32_t tmp2 = wadd(z1, wmul(z3, -F_1_847759065));
+  int32_t tmp3 = wadd(z1, wmul(z2, F_0_765366865));
   z2 = in[0]; z3 = in[4];
-  int tmp0 = (int)((unsigned)(z2 + z3) << 13);
-  int tmp1 = (int)((unsigned)(z2 - z3) << 13);
-  const int tmp10 = tmp0 + tmp3, tmp13 = tmp0 - tmp3, tmp11 = tmp1 + tmp2, tmp12 = tmp1 - tmp2;
+  int32_t tmp0 = (int32_t)((uint32_t)wadd(z2, z3) << 13);
+  int32_t tmp1 = (int32_t)((uint32_t)wsub(z2, z3) << 13);
+  const int32_t tmp10 = wadd(tmp0, tmp3), tmp13 = wsub(tmp0, tmp3), tmp11 = wadd(tmp1, tmp2), tmp12 = wsub(tmp1, tmp2);
   tmp0 = in[7]; tmp1 = in[5]; tmp2 = in[3]; tmp3 = in[1];
-  z1 = tmp0 + tmp3; z2 = tmp1 + tmp2; z3 = tmp0 + tmp2;
-  int z4 = tmp1 + tmp3;
-  const int z5 = (z3 + z4) * F_1_175875602;
-  tmp0 *= F_0_298631336; tmp1 *= F_2_053119869; tmp2 *= F_3_072711026; tmp3 *= F_1_501321110;
-  z1 *= -F_0_899976223; z2 *= -F_2_562915447; z3 *= -F_1_961570560; z4 *= -F_0_390180644;
-  z3 += z5; z4 += z5;
-  tmp0 += z1 + z3; tmp1 += z2 + z4; tmp2 += z2 + z3; tmp3 += z1 + z4;
-  out[0] = tmp10 + tmp3; out[7] = tmp10 - tmp3;
-  out[1] = tmp11 + tmp2; out[6] = tmp11 - tmp2;
-  out[2] = tmp12 + tmp1; out[5] = tmp12 - tmp1;
-  out[3] = tmp13 + tmp0; out[4] = tmp13 - tmp0;
+  z1 = wadd(tmp0, tmp3); z2 = wadd(tmp1, tmp2); z3 = wadd(tmp0, tmp2);
+  int32_t z4 = wadd(tmp1, tmp3);
+  const int32_t z5 = wmul(wadd(z3, z4), F_1_175875602);
+  tmp0 = wmul(tmp0, F_0_298631336); tmp1 = wmul(tmp1, F_2_053119869); tmp2 = wmul(tmp2, F_3_072711026); tmp3 = wmul(tmp3, F_1_501321110);
+  z1 = wmul(z1, -F_0_899976223); z2 = wmul(z2, -F_2_562915447); z3 = wmul(z3, -F_1_961570560); z4 = wmul(z4, -F_0_390180644);
+  z3 = wadd(z3, z5); z4 = wadd(z4, z5);
+  tmp0 = wadd(tmp0, wadd(z1, z3)); tmp1 = wadd(tmp1, wadd(z2, z4)); tmp2 = wadd(tmp2, wadd(z2, z3)); tmp3 = wadd(tmp3, wadd(z1, z4));
+  out[0] = wadd(tmp10, tmp3); out[7] = wsub(tmp10, tmp3);
+  out[1] = wadd(tmp11, tmp2); out[6] = wsub(tmp11, tmp2);
+  out[2] = wadd(tmp12, tmp1); out[5] = wsub(tmp12, tmp1);
+  out[3] = wadd(tmp13, tmp0); out[4] = wsub(tmp13, tmp0);
 }
 
-JPG_HD int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+JPG_HD int32_t descale(int32_t x, int n) { return wadd(x, 1 << (n - 1)) >> n; }
 
 // coef: 64 int16 (natural order), quant: 64 uint16 (natural order); out: 8 rows, `pitch` bytes apart
 JPG_HD void idct_block(const int16_t* coef, const uint16_t* quant, uint8_t* out, int pitch) {
-  int ws[64];
+  int32_t ws[64];
   for (int c = 0; c < 8; ++c) {
-    int in[8], o[8];
-    for (int r = 0; r < 8; ++r) in[r] = (int)coef[r * 8 + c] * (int)quant[r * 8 + c];
+    int32_t in[8], o[8];
+    for (int r = 0; r < 8; ++r) in[r] = (int16_t)(uint16_t)((uint32_t)(int32_t)coef[r * 8 + c] * (uint32_t)quant[r * 8 + c]);
     idct_1d(in, o);
-    for (int r = 0; r < 8; ++r) ws[r * 8 + c] = descale(o[r], 13 - 2);
+    for (int r = 0; r < 8; ++r) ws[r * 8 + c] = sat16(descale(o[r], 13 - 2));
   }
   for (int r = 0; r < 8; ++r) {
-    int o[8];
+    int32_t o[8];
     idct_1d(ws + r * 8, o);
-    for (int c = 0; c < 8; ++c) out[r * pitch + c] = idct_range_limit(descale(o[c], 13 + 2 + 3));
+    for (int c = 0; c < 8; ++c) {
+      const int32_t v = sat16(descale(o[c], 13 + 2 + 3));
+      out[r * pitch + c] = (uint8_t)((v < -128 ? -128 : v > 127 ? 127 : v) + 128);
+    }
   }
 }
 

@@ -49,7 +49,7 @@ inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
 int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, size_t* scan_len) {
   memset(d, 0, sizeof *d);
-  if (len < 4 || data[0] != 0xFF || data[1] != 0xD8) return JPG_NOT_JPEG;
+  if (len < 4 || data[0] != 0xFF || data[1] != 0xD8 || data[2] != 0xFF) return JPG_NOT_JPEG;   // (Pillow identifies JPEG by these three bytes)
   uint16_t qt[4][64];
   bool have_qt[4] = {false, false, false, false}, have_ht[4] = {false, false, false, false};
   int comp_id[MAX_COMPS] = {0, 0, 0}, comp_tq[MAX_COMPS] = {0, 0, 0};
@@ -92,36 +92,41 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
         for (int l = 0; l < 16; ++l) total += s[i + 1 + l];
         if (tc > 1 || i + 17 + total > n) return JPG_CORRUPT;
         if (th > 1) return JPG_TABLES;                            // (ids 2, 3: extended sequential only; not met in practice)
+        if (tc == 0)
+          for (int k = 0; k < total; ++k)
+            if (s[i + 17 + k] > 15) return JPG_CORRUPT;          // a DC table codes categories 0 .. 15
         if (!build_huff(s + i + 1, s + i + 17, total, &d->huff[tc * 2 + th])) return JPG_CORRUPT;
         have_ht[tc * 2 + th] = true;
         i += 17 + total;
       }
     } else if (m == 0xDD) {                                       // DRI
-      if (n < 2) return JPG_CORRUPT;
+      if (n != 2) return JPG_CORRUPT;
       d->restart_interval = be16(s);
     } else if (m == 0xC0 || m == 0xC1) {                          // SOF0 / SOF1: sequential Huffman
-      if (n < 6) return JPG_CORRUPT;
+      if (n < 6 || have_sof) return JPG_CORRUPT;
       if (s[0] != 8) return JPG_PRECISION;
       d->height = be16(s + 1); d->width = be16(s + 3); d->ncomp = s[5];
       if (d->width < 1 || d->height < 1) return JPG_CORRUPT;     // (height 0 = DNL marker: not supported)
       if (d->width > 16384 || d->height > 16384) return JPG_TOO_LARGE;
       if (d->ncomp != 1 && d->ncomp != 3) return JPG_COMPONENTS;
-      if (n < 6 + 3 * d->ncomp) return JPG_CORRUPT;
+      if (n != 6 + 3 * d->ncomp) return JPG_CORRUPT;
       for (int c = 0; c < d->ncomp; ++c) {
         comp_id[c] = s[6 + 3 * c];
         d->hs[c] = s[7 + 3 * c] >> 4; d->vs[c] = s[7 + 3 * c] & 15;
         comp_tq[c] = s[8 + 3 * c];
-        if (comp_tq[c] > 3 || d->hs[c] < 1 || d->vs[c] < 1) return JPG_CORRUPT;
+        if (comp_tq[c] > 3 || d->hs[c] < 1 || d->vs[c] < 1 || d->hs[c] > 4 || d->vs[c] > 4) return JPG_CORRUPT;
       }
       have_sof = true;
     } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
       return (m == 0xC9 || m == 0xCA || m == 0xCB || m == 0xCD || m == 0xCE || m == 0xCF) ? JPG_ARITHMETIC : JPG_PROGRESSIVE;
     } else if (m == 0xCC) {
       return JPG_ARITHMETIC;
+    } else if (!((m >= 0xE0 && m <= 0xEF) || m == 0xFE) && m != 0xDA) {
+      return JPG_CORRUPT;                                         // not a segment libjpeg skips: Pillow decides what the file is
     } else if (m == 0xDA) {                                       // SOS
       if (!have_sof) return JPG_CORRUPT;
       if (n < 1 || s[0] != d->ncomp) return JPG_MULTI_SCAN;
-      if (n < 1 + 2 * d->ncomp + 3) return JPG_CORRUPT;
+      if (n != 1 + 2 * d->ncomp + 3) return JPG_CORRUPT;
       for (int c = 0; c < d->ncomp; ++c) {
         if (s[1 + 2 * c] != comp_id[c]) return JPG_MULTI_SCAN;   // (components in frame order)
         const int td = s[2 + 2 * c] >> 4, ta = s[2 + 2 * c] & 15;

@@ -69,3 +69,37 @@ def test_parser_reasons_and_truncation_like_pillow():
             _pil(good[:cut])
     tail = good + b"abc\xff\x00xyz" * 5
     assert np.array_equal(jpeg_oracle.decode(tail), _pil(tail))
+
+
+def test_damaged_files_are_refused_or_decoded_like_pillow():
+    """600 mutated files (random bytes in headers / entropy data, 0xFF insertions, truncations).  The parser is stricter than
+    libjpeg on purpose -- what it refuses goes to Pillow in the driver -- so the property to hold is one-sided: a file the
+    decoder accepts is a file Pillow accepts too, and then (bar single blocks of saturated garbage) with the same pixels."""
+    import warnings
+    rs = np.random.RandomState(5)
+    seeds = [_jpeg(rs.randint(0, 256, (h, w, 3), dtype=np.uint8), quality=85, subsampling=ss, **kw)
+             for (h, w, ss, kw) in [(64, 80, 2, {}), (33, 47, 1, {"optimize": True}), (40, 40, 0, {"restart_marker_blocks": 3}), (24, 24, 2, {})]]
+    accepted = same = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for s in seeds:
+            for t in range(150):
+                a = bytearray(s)
+                for _ in range(rs.randint(1, 6)):
+                    mode = t % 4
+                    pos = rs.randint(0, min(700, len(a))) if mode == 1 else rs.randint(min(600, len(a) - 1), len(a)) if mode == 2 else rs.randint(0, len(a))
+                    a[pos] = 0xFF if mode == 3 else rs.randint(0, 256)
+                if t % 7 == 0:
+                    a = a[: rs.randint(2, len(a))]
+                data = bytes(a)
+                try:
+                    got = jpeg_oracle.decode(data)
+                except ValueError:
+                    continue
+                accepted += 1
+                ref = _pil(data)                                      # must not raise: accepted here => accepted by Pillow
+                assert ref.shape == got.shape
+                bad_blocks = {(y // 8, x // 8) for y, x in zip(*np.nonzero((ref != got).any(-1)))}
+                same += not bad_blocks
+                assert len(bad_blocks) <= 2, (len(data), bad_blocks)
+    assert accepted >= 50 and same >= 0.9 * accepted, (accepted, same)

@@ -94,3 +94,41 @@ def test_decoded_images_feed_the_gpu_front_end_like_pillow_decoded_ones(gpu):
     b, names_b = cropper.batch([torch.from_numpy(_pil(f).copy()) for f in files])
     assert names_a == names_b and torch.equal(a, b)
     cropper.close(); dec.close()
+
+
+def test_damaged_files_on_the_device_equal_the_cpu_run_of_the_same_arithmetic(gpu):
+    """Mutated files (random bytes, 0xFF insertions, truncations): the device must survive every one of them, refuse the same
+    files as the CPU run of the same sources (oracle/jpeg_ref.cpp) and produce the same pixels for the rest."""
+    from oracle import jpeg_oracle
+    rs = np.random.RandomState(11)
+    seeds = [_jpeg(rs.randint(0, 256, (h, w, 3), dtype=np.uint8), quality=85, subsampling=ss, **kw)
+             for (h, w, ss, kw) in [(64, 80, 2, {}), (33, 47, 1, {"optimize": True}), (40, 40, 0, {"restart_marker_blocks": 3}), (24, 24, 2, {})]]
+    files = []
+    for s in seeds:
+        for t in range(100):
+            a = bytearray(s)
+            for _ in range(rs.randint(1, 6)):
+                mode = t % 4
+                pos = rs.randint(0, min(700, len(a))) if mode == 1 else rs.randint(min(600, len(a) - 1), len(a)) if mode == 2 else rs.randint(0, len(a))
+                a[pos] = 0xFF if mode == 3 else rs.randint(0, 256)
+            if t % 7 == 0:
+                a = a[: rs.randint(2, len(a))]
+            files.append(bytes(a))
+    dec = GpuJpegDecoder(gpu)
+    images, status = dec.decode(files)
+    n_ok = 0
+    for data, img, st in zip(files, images, status):
+        try:
+            ref = jpeg_oracle.decode(data)
+        except ValueError:
+            ref = None
+        assert (ref is None) == (st != 0), (st, len(data))
+        if ref is not None:
+            n_ok += 1
+            assert np.array_equal(img.cpu().numpy(), ref)
+    assert n_ok >= 30
+    # the handle is still good
+    good = _jpeg(rs.randint(0, 256, (50, 60, 3), dtype=np.uint8), quality=90)
+    images, status = dec.decode([good])
+    assert status == [0] and np.array_equal(images[0].cpu().numpy(), _pil(good))
+    dec.close()
