@@ -117,6 +117,7 @@ class Feature_Dataset:
         # Files the decoder does not take (progressive, CMYK, PNG, ...) are decoded by Pillow here, as the reference does.
         self.gpu_decode = bool(gpu_decode)
         self.decode_chunk = max(int(decode_chunk), 1)
+        self.gpu_decode_max_bytes = 1 << 20                 # larger files: Pillow in the reader threads (see gpu_decoded_batches)
         gpu_preprocess = gpu_preprocess or self.gpu_decode
         self.packed_store = packed_store
         self.shard_images = int(shard_images)     # images per sealed shard = the most a killed rank can lose
@@ -240,9 +241,16 @@ class Feature_Dataset:
             from concurrent.futures import ThreadPoolExecutor
 
             def read(path):
+                """file bytes; files over `gpu_decode_max_bytes` are decoded right here with Pillow (the pool's threads run in
+                parallel: Pillow releases the GIL while it decodes) -- a file is ONE serial stream for the device's entropy
+                decoder, at about a third of a host core's speed, so a multi-megabyte photo would hold its whole batch up"""
                 try:
                     with open(path, "rb") as f:
-                        return f.read()
+                        blob = f.read()
+                    if len(blob) > self.gpu_decode_max_bytes:
+                        import io
+                        return torch.from_numpy(np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"), dtype=np.uint8).copy())
+                    return blob
                 except Exception as e:
                     print(f"Error loading or processing image {path}: {e}")
                     return None
@@ -254,9 +262,11 @@ class Feature_Dataset:
                     if ci + 1 < len(chunks):
                         ahead.append(pool.submit(lambda c=chunks[ci + 1]: [read(p) for p in c]))
                     blobs = ahead.pop(0).result()
-                    images, status = self.jpeg.decode([b if b is not None else b"" for b in blobs])
+                    images, status = self.jpeg.decode([b if isinstance(b, bytes) else b"" for b in blobs])
                     acc = []
                     for path, blob, img, st in zip(chunk, blobs, images, status):
+                        if isinstance(blob, torch.Tensor):          # decoded by Pillow in the reader thread (large file)
+                            img, blob = blob, None
                         if img is None and blob is not None:      # not a baseline JPEG the device takes: Pillow, as the reference
                             try:
                                 import io

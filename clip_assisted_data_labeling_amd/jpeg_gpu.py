@@ -29,12 +29,12 @@ class GpuJpegDecoder:
         return self.lib.jpegdec_reason(int(code)).decode()
 
     @torch.no_grad()
-    def decode(self, files: Sequence[bytes], max_batch_pixels: int = 400_000_000) -> Tuple[List[Optional[torch.Tensor]], List[int]]:
+    def decode(self, files: Sequence[bytes], max_batch_pixels: int = 2_000_000_000) -> Tuple[List[Optional[torch.Tensor]], List[int]]:
         """files: the bytes of each file -> (images, status): images[i] a uint8 [H, W, 3] tensor on the GPU (a view into a
         batch buffer) or None when status[i] != 0 (1..12: not decodable here, see `reason`; >= 100: corrupt or truncated entropy
         data).  The device works on all files of a call at once -- the entropy decoder is one serial stream per file, so its
         throughput IS the number of files in flight -- except that a call is split into groups of at most `max_batch_pixels`
-        pixels (7.5 bytes of device scratch + output per pixel: 3 GB at the default)."""
+        pixels (7.5 bytes of device scratch + output per pixel: 15 GB at the default)."""
         n = len(files)
         if n == 0:
             return [], []

@@ -54,7 +54,7 @@ def test_decoder_matches_pillow_bit_for_bit_over_sizes_samplings_qualities(gpu):
     # a second batch through the same handle (buffers are reused, the arena may grow); then the same files under a pixel budget that
     # splits the call into several device batches
     big = [_jpeg(rs.randint(0, 256, (512, 512, 3), dtype=np.uint8), quality=90) for _ in range(5)] + [_jpeg(_smooth(rs, 1200, 1600), quality=92)]
-    for budget in (400_000_000, 600_000):
+    for budget in (2_000_000_000, 600_000):
         images, status = dec.decode(big, max_batch_pixels=budget)
         assert status == [0] * len(big)
         for img, data in zip(images, big):
