@@ -48,6 +48,14 @@ struct ImageDesc {
   uint64_t block_base;                   // index of the image's first 8 x 8 block in the batch-wide block numbering
   uint32_t n_blocks;
   uint32_t data_real;                    // bytes of data_len that come from the file (the rest is the host's padding)
+  // parallel entropy decoding (below): the unstuffed stream, its restart intervals, per-subsequence scratch
+  uint64_t clean_off;                    // 4-byte aligned, 16 bytes of 0xFF behind clean_len
+  uint32_t clean_len;
+  int32_t n_iv;                          // restart intervals (1 without DRI)
+  uint64_t iv_off;                       // uint32 iv_byte[n_iv + 1], then uint32 iv_sub[n_iv + 1]
+  uint32_t n_sub;                        // subsequences of the image
+  int32_t sub_bytes;
+  uint64_t sub_off;                      // scratch: n_sub x { u64 entry, u64 exit, u32 blocks, u32 du_base, i32 dc[3], i32 dc_base[3] }
   HuffTable huff[4];
 };
 
@@ -240,6 +248,157 @@ JPG_HD int decode_scan(const ScanGeom g, const uint8_t* arena_data, int16_t* con
     br.marker = b;
   }
   return (br.marker == 0xD9 && br.consumed <= g.data_real) ? 0 : 3;
+}
+
+// ------------------------------------------------------------------------------------------------ parallel entropy decoding
+// A Huffman-coded scan is serial as written -- every code's position depends on all codes before it -- but it re-synchronises:
+// a decoder started at a wrong bit or in a wrong state (which block of the MCU, which coefficient index) falls back into step
+// with the true symbol sequence after a few symbols.  That makes the scan decodable in parallel (Klein & Wiseman 2003;
+// Weissenberger & Schmidt 2018/2021 for JPEG on GPUs): the unstuffed stream (jpeg_host.cpp: unstuff_scan) is cut into
+// subsequences of `sub_bytes` bytes; each keeps an ENTRY state (bit position, block-in-MCU u, coefficient index k), a guess at
+// first except for the first subsequence of every restart interval, whose state is known; every pass decodes each subsequence
+// from its entry state up to the first symbol boundary at or behind its end and hands that EXIT state to the next one as its new
+// entry state; when a pass changes nothing, entry(i + 1) = exit(i) holds for all i and entry(0) is true, so by induction every
+// state is true.  Counting the blocks completed and summing the DC differences per component in that last pass gives, by a prefix
+// sum, the block index and DC predictors each subsequence starts with; a final pass decodes every subsequence once more and
+// writes the coefficients -- the same values, in the same places, as the serial walk.
+struct SubState { uint32_t bit; int u, k; };
+JPG_HD uint64_t pack_state(const SubState& s) { return (uint64_t)s.bit | (uint64_t)(uint32_t)s.u << 32 | (uint64_t)(uint32_t)s.k << 40; }
+JPG_HD SubState unpack_state(uint64_t v) { SubState s; s.bit = (uint32_t)v; s.u = (int)((v >> 32) & 0xff); s.k = (int)((v >> 40) & 0xff); return s; }
+
+struct ParGeom {
+  int ncomp, B, mcus_x;                    // B: blocks ("data units") per MCU
+  int comp_of_u[6], bx_of_u[6], by_of_u[6];
+  int h[MAX_COMPS], v[MAX_COMPS], bw[MAX_COMPS], dc[MAX_COMPS], ac[MAX_COMPS];
+  uint32_t total_du, du_per_interval;      // du_per_interval: restart_interval * B, 0 = one interval
+};
+
+JPG_HD ParGeom par_geom(const ImageDesc& d) {
+  ParGeom g;
+  g.ncomp = d.ncomp; g.mcus_x = d.mcus_x;
+  int u = 0;
+  for (int c = 0; c < MAX_COMPS; ++c) {
+    g.h[c] = d.ncomp == 1 ? 1 : d.hs[c]; g.v[c] = d.ncomp == 1 ? 1 : d.vs[c];
+    g.bw[c] = d.bw[c]; g.dc[c] = d.dc_tab[c]; g.ac[c] = d.ac_tab[c];
+    if (c < d.ncomp)
+      for (int by = 0; by < g.v[c]; ++by)
+        for (int bx = 0; bx < g.h[c]; ++bx)
+          if (u < 6) { g.comp_of_u[u] = c; g.bx_of_u[u] = bx; g.by_of_u[u] = by; ++u; }
+  }
+  g.B = u;
+  for (; u < 6; ++u) { g.comp_of_u[u] = 0; g.bx_of_u[u] = 0; g.by_of_u[u] = 0; }
+  g.total_du = (uint32_t)d.mcus_x * (uint32_t)d.mcus_y * (uint32_t)g.B;
+  g.du_per_interval = (uint32_t)d.restart_interval * (uint32_t)g.B;
+  return g;
+}
+
+JPG_HD uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xff00u) | ((v << 8) & 0xff0000u) | (v << 24); }
+
+// the 32 bits at bit position `bit` of the unstuffed stream (4-byte aligned, 16 bytes of 0xFF behind its end)
+JPG_HD uint32_t peek32(const uint8_t* clean, uint32_t bit) {
+  const uint32_t* w = (const uint32_t*)clean + (bit >> 5);
+  const uint32_t a = bswap32(w[0]), b = bswap32(w[1]);
+  const int sh = (int)(bit & 31);
+  return sh ? (a << sh) | (b >> (32 - sh)) : a;
+}
+
+// where subsequence i lies: restart intervals start at clean-stream bytes iv_byte[j] (iv_byte[n_iv] = length of the stream) and
+// hold the subsequences iv_sub[j] .. iv_sub[j + 1] - 1, each sub_bytes long except the last of an interval
+struct SubSeq { uint32_t start_bit, end_bit, iv_end_bit; int interval; bool first, last; };
+JPG_HD SubSeq subseq_of(const uint32_t* iv_byte, const uint32_t* iv_sub, int n_iv, int sub_bytes, uint32_t i) {
+  int lo = 0, hi = n_iv - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (iv_sub[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  SubSeq q;
+  q.interval = lo;
+  const uint32_t local = i - iv_sub[lo];
+  const uint32_t b0 = iv_byte[lo] + local * (uint32_t)sub_bytes;
+  q.first = local == 0;
+  q.last = i + 1 == iv_sub[lo + 1];
+  q.iv_end_bit = iv_byte[lo + 1] * 8u;
+  q.start_bit = b0 * 8u;
+  q.end_bit = q.last ? q.iv_end_bit : (b0 + (uint32_t)sub_bytes) * 8u;
+  return q;
+}
+
+// Decodes symbols from state s until the first symbol boundary at or behind end_bit (WRITE: or until block index du_stop is
+// reached).  du: index of the block in progress at entry; pred: WRITE = the running DC predictors, else accumulators of the DC
+// differences met; *blocks_done: blocks completed.  Returns 0, or (WRITE only; a speculative pass skips a bit instead) 1 for an
+// invalid code / category / coefficient index or more blocks than the interval holds.
+template <bool WRITE>
+JPG_HD int decode_span(const ParGeom& g, const uint8_t* clean, const HuffTable* huff, const uint8_t* zz, SubState& s, uint32_t end_bit,
+                       uint32_t du, uint32_t du_stop, int pred[MAX_COMPS], int16_t* const coef[MAX_COMPS], uint32_t* blocks_done) {
+  uint32_t done = 0;
+  int16_t* blk = nullptr;
+  int mx = 0, my = 0;
+  if (WRITE) {
+    const uint32_t mcu = du / (uint32_t)g.B;
+    my = (int)(mcu / (uint32_t)g.mcus_x); mx = (int)(mcu - (uint32_t)my * (uint32_t)g.mcus_x);
+    if (du < g.total_du) {
+      const int c = g.comp_of_u[s.u];
+      blk = coef[c] + ((size_t)(my * g.v[c] + g.by_of_u[s.u]) * g.bw[c] + (mx * g.h[c] + g.bx_of_u[s.u])) * 64;
+    }
+  }
+  for (;;) {
+    if (WRITE && du + done >= du_stop) break;
+    if (s.bit >= end_bit) break;
+    const int c = g.comp_of_u[s.u];
+    const uint32_t win = peek32(clean, s.bit);
+    const HuffTable& t = huff[s.k == 0 ? g.dc[c] : g.ac[c]];
+    const int c16 = (int)(win >> 16);
+    int len, sym;
+    const int e = t.look[c16 >> 7];
+    if (e) { len = e >> 8; sym = e & 0xff; }
+    else {
+      len = 10;
+      while (len <= 16 && (c16 >> (16 - len)) > t.maxcode[len]) ++len;
+      if (len > 16) {
+        if (WRITE) return 1;
+        s.bit += 1;                                              // a speculative start inside garbage: slide on
+        continue;
+      }
+      sym = t.huffval[((c16 >> (16 - len)) + t.valoffset[len]) & 0xff];
+    }
+    if (s.k == 0) {
+      int sz = sym;
+      if (sz > 11) { if (WRITE) return 1; sz &= 15; }
+      int v = 0;
+      if (sz) v = extend((int)((win << len) >> (32 - sz)), sz);
+      s.bit += (uint32_t)(len + sz);
+      pred[c] += v;
+      if (WRITE) blk[0] = (int16_t)pred[c];
+      s.k = 1;
+    } else {
+      const int r = sym >> 4, sz = sym & 15;
+      if (sz == 0) {
+        s.bit += (uint32_t)len;
+        s.k = r == 15 ? s.k + 16 : 64;
+      } else {
+        s.k += r;
+        const int v = extend((int)((win << len) >> (32 - sz)), sz);
+        s.bit += (uint32_t)(len + sz);
+        if (s.k > 63) { if (WRITE) return 1; }
+        else if (WRITE) blk[zz[s.k]] = (int16_t)v;
+        s.k++;
+      }
+    }
+    if (s.k >= 64) {                                             // block complete
+      s.k = 0;
+      ++done;
+      if (++s.u == g.B) {
+        s.u = 0;
+        if (WRITE && ++mx == g.mcus_x) { mx = 0; ++my; }
+      }
+      if (WRITE && du + done < g.total_du) {
+        const int cn = g.comp_of_u[s.u];
+        blk = coef[cn] + ((size_t)(my * g.v[cn] + g.by_of_u[s.u]) * g.bw[cn] + (mx * g.h[cn] + g.bx_of_u[s.u])) * 64;
+      }
+    }
+  }
+  *blocks_done = done;
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ inverse DCT ("islow")

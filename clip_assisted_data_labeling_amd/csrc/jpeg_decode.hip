@@ -2,17 +2,20 @@
 // (/root/reference/utils/embedder.py:167, PIL.Image.open(...).convert('RGB')) and is bound by that on real data; here the host
 // only walks the markers (jpeg_host.cpp) and the device does the rest with the arithmetic of jpeg_core.h, which is Pillow's
 // (libjpeg-turbo defaults) bit for bit:
-//   jpeg_entropy_kernel   one workgroup per image: its four Huffman tables go to LDS, lane 0 walks the scan (inherently
-//                         serial: every code's position depends on all codes before it) and writes the nonzero coefficients;
-//                         the parallelism is across the images of the batch, which is what the embed driver has plenty of
+//   jpeg_entropy_kernel   one workgroup per image, PARALLEL inside the image: the unstuffed scan is cut into subsequences of 2 KiB,
+//                         one thread each, decoded speculatively and re-decoded until every subsequence's entry state is the
+//                         exit state of the one before (jpeg_core.h, "parallel entropy decoding": Huffman streams
+//                         re-synchronise, typically 2-3 passes); then a prefix sum of block counts and DC differences and one
+//                         writing pass.  Worst case (periodic content) it degenerates to the serial walk, never to a wrong result
 //   jpeg_idct_kernel      one thread per 8 x 8 block of any image: dequantise, integer inverse DCT, samples into the plane
 //   jpeg_colour_kernel    one thread per output pixel: chroma upsampling (triangle filters) + YCbCr -> RGB, interleaved uint8
-// A batch is planned on the host in one pass (per image: padded entropy segment, coefficient planes, sample planes) into one
-// device arena that grows to the largest batch seen; descriptors and entropy segments travel in ONE host-to-device copy from
-// page-locked memory.  The RGB output goes to memory the caller owns.
+// A batch is planned on the host in one pass (per image: the entropy segment with its byte stuffing and restart markers
+// removed -- host threads, memchr-paced --, restart-interval table, coefficient planes, sample planes) into one device arena that
+// grows to the largest batch seen; descriptors and segments travel in ONE host-to-device copy from page-locked memory.  The RGB output goes to memory the caller owns.
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -23,22 +26,111 @@ using jpg::ImageDesc;
 
 namespace {
 
-__global__ __launch_bounds__(64) void jpeg_entropy_kernel(const ImageDesc* __restrict__ descs, int* __restrict__ status,
-                                                          uint8_t* __restrict__ arena) {
+constexpr int SUB_BYTES = 2048;              // subsequence length: 2-3 synchronisation passes on photographic and on noise content
+constexpr int ENT_THREADS = 256;
+
+// per-subsequence scratch (global memory, jpg::ImageDesc::sub_off)
+struct SubScratch {
+  uint64_t entry;                            // state the subsequence is decoded from
+  uint64_t exit;                             // state its last decode ended in
+  uint32_t blocks, du_base;                  // blocks completed in it / index of the block in progress at its entry
+  int32_t dc[3], dc_base[3];                 // DC differences met in it / DC predictors at its entry
+  uint32_t dirty, pad;                       // entry changed since the last decode
+};
+
+__global__ __launch_bounds__(ENT_THREADS) void jpeg_entropy_kernel(const ImageDesc* __restrict__ descs, int* __restrict__ status,
+                                                                   uint8_t* __restrict__ arena) {
   __shared__ jpg::HuffTable tabs[4];
   __shared__ uint8_t zz[64];
+  __shared__ int s_err;
+  __shared__ jpg::ParGeom g;                                   // (its small tables are indexed by the decoding state: LDS, not registers)
   const ImageDesc& d = descs[blockIdx.x];
+  const int tid = threadIdx.x;
   {
+    if (tid == 0) g = jpg::par_geom(d);
     const uint32_t* src = (const uint32_t*)d.huff;
     uint32_t* dst = (uint32_t*)tabs;
-    for (int i = threadIdx.x; i < (int)(sizeof(tabs) / 4); i += 64) dst[i] = src[i];
-    zz[threadIdx.x] = (uint8_t)jpg::zigzag_to_natural(threadIdx.x);
+    for (int i = tid; i < (int)(sizeof(tabs) / 4); i += ENT_THREADS) dst[i] = src[i];
+    if (tid < 64) zz[tid] = (uint8_t)jpg::zigzag_to_natural(tid);
+    if (tid == 0) s_err = 0;
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
+  const uint32_t N = d.n_sub;
+  if (N == 0) {                                                // the host could not unstuff the scan (no EOI, stray marker)
+    if (tid == 0) status[blockIdx.x] = 3;
+    return;
+  }
+  const uint8_t* clean = arena + d.clean_off;
+  const uint32_t* iv_byte = (const uint32_t*)(arena + d.iv_off);
+  const uint32_t* iv_sub = iv_byte + (d.n_iv + 1);
+  const int n_iv = d.n_iv, L = d.sub_bytes;
+  SubScratch* sc = (SubScratch*)(arena + d.sub_off);
   int16_t* coef[jpg::MAX_COMPS];
   for (int c = 0; c < jpg::MAX_COMPS; ++c) coef[c] = (int16_t*)(arena + d.coef_off[c]);
-  status[blockIdx.x] = jpg::decode_scan(jpg::scan_geom(d), arena + d.data_off, coef, tabs, zz);
+
+  for (uint32_t i = tid; i < N; i += ENT_THREADS) {
+    const jpg::SubSeq q = jpg::subseq_of(iv_byte, iv_sub, n_iv, L, i);
+    sc[i].entry = jpg::pack_state(jpg::SubState{q.start_bit, 0, 0});
+    sc[i].dirty = 1;
+  }
+  __syncthreads();
+  // ---- synchronisation passes: at most N (after pass t the entries 0 .. t are the true ones); typically 2-3
+  for (uint32_t pass = 0; pass <= N; ++pass) {
+    for (uint32_t i = tid; i < N; i += ENT_THREADS) {
+      if (!sc[i].dirty) continue;
+      sc[i].dirty = 0;
+      const jpg::SubSeq q = jpg::subseq_of(iv_byte, iv_sub, n_iv, L, i);
+      if (q.last) continue;                                      // nobody reads its exit; its block count follows from the interval's
+      jpg::SubState st = jpg::unpack_state(sc[i].entry);
+      int acc[3] = {0, 0, 0};
+      uint32_t done = 0;
+      jpg::decode_span<false>(g, clean, tabs, zz, st, q.end_bit, 0, 0, acc, coef, &done);
+      sc[i].exit = jpg::pack_state(st);
+      sc[i].blocks = done;
+      sc[i].dc[0] = acc[0]; sc[i].dc[1] = acc[1]; sc[i].dc[2] = acc[2];
+    }
+    __syncthreads();
+    int changed = 0;
+    for (uint32_t i = tid; i + 1 < N; i += ENT_THREADS) {
+      const jpg::SubSeq q = jpg::subseq_of(iv_byte, iv_sub, n_iv, L, i);
+      if (q.last) continue;                                      // the next subsequence starts an interval: its entry is known
+      if (sc[i + 1].entry != sc[i].exit) { sc[i + 1].entry = sc[i].exit; sc[i + 1].dirty = 1; changed = 1; }
+    }
+    if (!__syncthreads_or(changed)) break;
+  }
+  // ---- block index and DC predictors at every entry: prefix sums inside each restart interval
+  for (int j = tid; j < n_iv; j += ENT_THREADS) {
+    uint32_t du = g.du_per_interval ? (uint32_t)j * g.du_per_interval : 0u;
+    int b0 = 0, b1 = 0, b2 = 0;
+    for (uint32_t i = iv_sub[j]; i < iv_sub[j + 1]; ++i) {
+      sc[i].du_base = du;
+      sc[i].dc_base[0] = b0; sc[i].dc_base[1] = b1; sc[i].dc_base[2] = b2;
+      du += sc[i].blocks; b0 += sc[i].dc[0]; b1 += sc[i].dc[1]; b2 += sc[i].dc[2];
+    }
+  }
+  __syncthreads();
+  // ---- the writing pass
+  int err = 0;
+  for (uint32_t i = tid; i < N; i += ENT_THREADS) {
+    const jpg::SubSeq q = jpg::subseq_of(iv_byte, iv_sub, n_iv, L, i);
+    const uint32_t iv_first = g.du_per_interval ? (uint32_t)q.interval * g.du_per_interval : 0u;
+    const uint32_t iv_stop = g.du_per_interval ? min(iv_first + g.du_per_interval, g.total_du) : g.total_du;
+    jpg::SubState st = jpg::unpack_state(sc[i].entry);
+    int pred[3] = {sc[i].dc_base[0], sc[i].dc_base[1], sc[i].dc_base[2]};
+    uint32_t done = 0;
+    const uint32_t du0 = sc[i].du_base;
+    if (du0 > iv_stop || iv_first > g.total_du) { err = 1; continue; }
+    if (jpg::decode_span<true>(g, clean, tabs, zz, st, q.last ? 0xffffffffu : q.end_bit, du0, iv_stop, pred, coef, &done)) { err = 1; continue; }
+    if (q.last) {
+      if (du0 + done != iv_stop || st.u != 0 || st.k != 0) err = 1;     // the interval does not hold the blocks it must
+      else if (st.bit > q.iv_end_bit) err = 2;                   // bits consumed that are not in the file
+    } else if (jpg::pack_state(st) != sc[i + 1].entry) {
+      err = 1;                                                   // stopped early at the interval's block limit
+    }
+  }
+  if (err) atomicMax(&s_err, err);
+  __syncthreads();
+  if (tid == 0) status[blockIdx.x] = s_err;
 }
 
 // image of a batch-wide index: descs[i].base <= idx < descs[i + 1].base
@@ -96,6 +188,8 @@ struct JpegDecState {
   std::vector<ImageDesc> descs;            // decodable images only, in input order
   std::vector<int> input_index;            // descs[i] = input file input_index[i]
   std::vector<std::pair<const uint8_t*, size_t>> scans;
+  std::vector<uint32_t> max_iv;            // per image: upper bound of its restart intervals
+  std::vector<int> host_status;            // per image: 0, or why the host could not prepare its scan
   size_t stage_bytes = 0, arena_bytes = 0, desc_begin = 0, coef_begin = 0, coef_bytes = 0, max_pixels = 0;
   uint64_t total_blocks = 0, rgb_bytes = 0;
   // buffers (grow only)
@@ -139,19 +233,35 @@ void ce_jpegdec_plan(JpegDecState* s, const void* const* files, const size_t* si
     s->input_index.push_back(i);
     s->scans.emplace_back((const uint8_t*)files[i] + so, sl);
   }
-  // arena: [status words][descs][entropy segments][coefficients][sample planes]; the first three are what the staging buffer holds
+  // arena: [status words][descs][per image: unstuffed scan + restart-interval table][subsequence scratch][coefficients]
+  // [sample planes]; the first three are what the staging buffer holds.  Sizes here are upper bounds (the scan is unstuffed in
+  // ce_jpegdec_run): clean bytes <= scan bytes, intervals <= MCUs / restart interval + 1, subsequences <= bytes / SUB_BYTES + intervals
   const size_t m = s->descs.size();
   s->desc_begin = up(m * sizeof(int), 256);
   size_t off = s->desc_begin + up(m * sizeof(ImageDesc), 256);
+  s->max_iv.assign(m, 1);
   for (size_t i = 0; i < m; ++i) {
     ImageDesc& d = s->descs[i];
-    d.data_off = off;
-    d.data_len = (uint32_t)(up(s->scans[i].second, 16) + 32);
-    d.data_real = (uint32_t)s->scans[i].second;
-    off += d.data_len;
+    const size_t scan_len = s->scans[i].second;
+    const size_t mcus = (size_t)d.mcus_x * d.mcus_y;
+    const size_t max_iv = d.restart_interval ? (mcus + d.restart_interval - 1) / d.restart_interval : 1;
+    s->max_iv[i] = (uint32_t)max_iv;
+    d.clean_off = off;
+    off += up(scan_len + 16, 16);
+    d.iv_off = off;
+    off += up((max_iv + 1) * 2 * sizeof(uint32_t), 16);
+    d.sub_bytes = SUB_BYTES;
+    d.data_off = 0; d.data_len = 0; d.data_real = 0;             // (the stuffed segment does not travel to the device)
   }
   off = up(off, 256);
   s->stage_bytes = off;
+  for (size_t i = 0; i < m; ++i) {
+    ImageDesc& d = s->descs[i];
+    const size_t max_sub = s->scans[i].second / SUB_BYTES + s->max_iv[i] + 1;
+    d.sub_off = off;
+    off += up(max_sub * sizeof(SubScratch), 16);
+  }
+  off = up(off, 256);
   s->coef_begin = off;
   for (auto& d : s->descs)
     for (int c = 0; c < d.ncomp; ++c) { d.coef_off[c] = off; off += (size_t)d.bw[c] * d.bh[c] * 128; }
@@ -186,18 +296,44 @@ hipError_t ce_jpegdec_run(JpegDecState* s, void* rgb_dev, int* status, hipStream
   }
   uint8_t* st = (uint8_t*)s->stage;
   memset(st, 0xff, m * sizeof(int));                          // status words: -1 until the entropy kernel has written them
+  // unstuff every scan into the staging buffer (host threads: memchr-paced, ~1 GB/s each) and fill in what depends on it
+  s->host_status.assign(m, 0);
+  {
+    const int nt = (int)std::min<size_t>(std::max(1u, std::thread::hardware_concurrency()), std::min<size_t>(16, m));
+    auto work = [&](int t) {
+      for (size_t i = (size_t)t; i < m; i += (size_t)nt) {
+        ImageDesc& d = s->descs[i];
+        uint32_t* iv_byte = (uint32_t*)(st + d.iv_off);
+        int n_iv = 0;
+        const long clen = jpg::unstuff_scan(s->scans[i].first, s->scans[i].second, st + d.clean_off, iv_byte, (int)s->max_iv[i], &n_iv);
+        const uint32_t mcus = (uint32_t)d.mcus_x * (uint32_t)d.mcus_y;
+        const uint32_t want_iv = d.restart_interval ? (mcus + d.restart_interval - 1) / d.restart_interval : 1u;
+        d.n_sub = 0; d.n_iv = 0; d.clean_len = 0;
+        if (clen < 0) { s->host_status[i] = 3; continue; }       // no EOI / a marker that does not belong into a scan
+        if ((uint32_t)n_iv != want_iv) { s->host_status[i] = 1; continue; }
+        iv_byte[n_iv] = (uint32_t)clen;
+        uint32_t* iv_sub = iv_byte + (n_iv + 1);
+        uint32_t nsub = 0;
+        for (int j = 0; j < n_iv; ++j) {
+          iv_sub[j] = nsub;
+          const uint32_t bytes = iv_byte[j + 1] - iv_byte[j];
+          nsub += bytes ? (bytes + SUB_BYTES - 1) / SUB_BYTES : 1u;
+        }
+        iv_sub[n_iv] = nsub;
+        d.n_iv = n_iv; d.n_sub = nsub; d.clean_len = (uint32_t)clen;
+      }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+  }
   memcpy(st + s->desc_begin, s->descs.data(), m * sizeof(ImageDesc));
-  for (size_t i = 0; i < m; ++i) {
-    const ImageDesc& d = s->descs[i];
-    uint8_t* dst = st + d.data_off;
-    memcpy(dst, s->scans[i].first, s->scans[i].second);
-    for (size_t k = s->scans[i].second; k < d.data_len; ++k) dst[k] = ((k - s->scans[i].second) & 1) ? 0xD9 : 0xFF;   // EOI markers: a scan
-  }                                                                                                                    // that runs long ends in them
   uint8_t* arena = (uint8_t*)s->arena;
   if (hipError_t e = hipMemcpyAsync(arena, st, s->stage_bytes, hipMemcpyHostToDevice, stream); e != hipSuccess) return e;
   if (hipError_t e = hipMemsetAsync(arena + s->coef_begin, 0, s->coef_bytes, stream); e != hipSuccess) return e;
   const ImageDesc* descs = (const ImageDesc*)(arena + s->desc_begin);
-  hipLaunchKernelGGL(jpeg_entropy_kernel, dim3((unsigned)m), dim3(64), 0, stream, descs, (int*)arena, arena);
+  hipLaunchKernelGGL(jpeg_entropy_kernel, dim3((unsigned)m), dim3(ENT_THREADS), 0, stream, descs, (int*)arena, arena);
   hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((s->total_blocks + 255) / 256)), dim3(256), 0, stream, descs, (int)m,
                      s->total_blocks, arena);
   hipLaunchKernelGGL(jpeg_colour_kernel, dim3((unsigned)((s->max_pixels + 255) / 256), (unsigned)m), dim3(256), 0, stream, descs, arena,
@@ -207,7 +343,7 @@ hipError_t ce_jpegdec_run(JpegDecState* s, void* rgb_dev, int* status, hipStream
   if (hipError_t e = hipMemcpyAsync(st, arena, m * sizeof(int), hipMemcpyDeviceToHost, stream); e != hipSuccess) return e;
   if (hipError_t e = hipStreamSynchronize(stream); e != hipSuccess) return e;
   for (size_t i = 0; i < m; ++i) {
-    const int ds = ((const int*)st)[i];
+    const int ds = s->host_status[i] ? s->host_status[i] : ((const int*)st)[i];
     status[s->input_index[i]] = ds ? 100 + ds : 0;
   }
   return hipSuccess;

@@ -47,6 +47,44 @@ namespace {
 inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 }
 
+long unstuff_scan(const uint8_t* scan, size_t len, uint8_t* clean, uint32_t* interval_start, int max_intervals, int* n_intervals) {
+  size_t i = 0, o = 0;
+  int niv = 1, next_rst = 0;
+  interval_start[0] = 0;
+  bool eoi = false;
+  while (i < len) {
+    const uint8_t* f = (const uint8_t*)memchr(scan + i, 0xFF, len - i);
+    const size_t run = f ? (size_t)(f - (scan + i)) : len - i;
+    memcpy(clean + o, scan + i, run);
+    o += run; i += run;
+    if (!f) break;
+    // scan[i] == 0xFF
+    size_t j = i + 1;
+    while (j < len && scan[j] == 0xFF) ++j;                       // fill bytes
+    if (j >= len) { i = len; break; }                             // the file ends inside a marker
+    const int m = scan[j];
+    if (m == 0x00) {
+      if (j != i + 1) return -1;                                  // 0xFF 0xFF 0x00: not valid entropy data
+      clean[o++] = 0xFF; i = j + 1;
+    } else if (m >= 0xD0 && m <= 0xD7) {
+      if (m != 0xD0 + next_rst) return -1;                        // restart markers count 0 .. 7 cyclically
+      next_rst = (next_rst + 1) & 7;
+      if (niv >= max_intervals) return -1;
+      interval_start[niv++] = (uint32_t)o;
+      i = j + 1;
+    } else if (m == 0xD9) {
+      eoi = true;
+      break;
+    } else {
+      return -1;                                                  // another marker inside the scan (DNL, a second scan, ...)
+    }
+  }
+  if (!eoi) return -1;
+  memset(clean + o, 0xFF, 16);
+  *n_intervals = niv;
+  return (long)o;
+}
+
 int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, size_t* scan_len) {
   memset(d, 0, sizeof *d);
   if (len < 4 || data[0] != 0xFF || data[1] != 0xD8 || data[2] != 0xFF) return JPG_NOT_JPEG;   // (Pillow identifies JPEG by these three bytes)

@@ -22,4 +22,11 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
 bool build_huff(const uint8_t counts[16], const uint8_t* vals, int nvals, HuffTable* t);
 const char* reason_text(int code);
 
+// The entropy-coded segment without its byte stuffing and markers, for the parallel decoder: `clean` receives the data bytes
+// (0xFF 0x00 -> 0xFF, fill bytes and RSTn markers dropped), `interval_start` the byte offset in `clean` at which each restart
+// interval begins (first entry 0).  Returns the number of clean bytes, or -1 if the data does not end in an EOI marker (a
+// truncated file) or holds a marker that is neither RSTn in sequence nor EOI.  `clean` must have room for len + 16 bytes; the 16
+// bytes behind the data are set to 0xFF (what the encoder pads with).
+long unstuff_scan(const uint8_t* scan, size_t len, uint8_t* clean, uint32_t* interval_start, int max_intervals, int* n_intervals);
+
 }  // namespace jpg

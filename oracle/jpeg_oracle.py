@@ -22,6 +22,7 @@ def _lib():
         _LIB = ctypes.CDLL(path)
         _LIB.jpeg_ref_info.restype = ctypes.c_int
         _LIB.jpeg_ref_decode.restype = ctypes.c_int
+        _LIB.jpeg_ref_decode_parallel.restype = ctypes.c_int
     return _LIB
 
 
@@ -42,3 +43,17 @@ def decode(data: bytes):
     if rc:
         raise ValueError(f"decode failed: {rc}")
     return out
+
+
+def decode_parallel(data: bytes, sub_bytes: int = 128, max_passes: int = 64):
+    """(uint8 [H, W, 3], synchronisation passes) through the PARALLEL entropy decoder, its threads run one after the other"""
+    rc, w, h, _ = info(data)
+    if rc:
+        raise ValueError(REASONS[rc] if rc < len(REASONS) else str(rc))
+    out = np.empty((h, w, 3), dtype=np.uint8)
+    passes = ctypes.c_int()
+    rc = _lib().jpeg_ref_decode_parallel(data, ctypes.c_size_t(len(data)), out.ctypes.data_as(ctypes.c_void_p), int(sub_bytes), int(max_passes),
+                                         ctypes.byref(passes))
+    if rc:
+        raise ValueError(f"decode failed: {rc}")
+    return out, passes.value

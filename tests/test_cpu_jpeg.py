@@ -93,9 +93,13 @@ def test_damaged_files_are_refused_or_decoded_like_pillow():
                     a = a[: rs.randint(2, len(a))]
                 data = bytes(a)
                 try:
-                    got = jpeg_oracle.decode(data)
+                    got = jpeg_oracle.decode_parallel(data, 2048, 1 << 20)[0]      # the decoder the device runs
                 except ValueError:
                     continue
+                try:
+                    assert np.array_equal(jpeg_oracle.decode(data), got)           # the serial walk, where it accepts the file too
+                except ValueError:
+                    pass
                 accepted += 1
                 ref = _pil(data)                                      # must not raise: accepted here => accepted by Pillow
                 assert ref.shape == got.shape
@@ -103,3 +107,34 @@ def test_damaged_files_are_refused_or_decoded_like_pillow():
                 same += not bad_blocks
                 assert len(bad_blocks) <= 2, (len(data), bad_blocks)
     assert accepted >= 50 and same >= 0.9 * accepted, (accepted, same)
+
+
+@pytest.mark.parametrize("sub_bytes", [2048, 128, 16])
+def test_parallel_entropy_decoder_equals_pillow(sub_bytes):
+    """The subsequence-parallel entropy decoder (jpeg_core.h; its threads run one after the other in the checker): whatever the
+    subsequence length, however many synchronisation passes it takes, the pixels are Pillow's.  Includes streams that never
+    re-synchronise by themselves (flat / periodic content: as many passes as subsequences) and restart intervals."""
+    rs = np.random.RandomState(sub_bytes)
+    yy, xx = np.mgrid[0:256, 0:384]
+    cases = [(_smooth(rs, h, w), dict(quality=q, subsampling=ss)) for (h, w) in [(8, 8), (37, 53), (1, 1), (100, 133), (241, 319)]
+             for ss in (0, 1, 2) for q in (30, 100)]
+    noise = rs.randint(0, 256, (123, 211, 3), dtype=np.uint8)
+    cases += [(noise, dict(quality=85, subsampling=ss, **kw)) for ss in (0, 2)
+              for kw in ({}, {"restart_marker_blocks": 1}, {"restart_marker_blocks": 5}, {"restart_marker_rows": 3})]
+    cases += [(rs.randint(0, 256, (77, 91), dtype=np.uint8), dict(quality=80)),
+              (np.zeros((256, 384, 3), np.uint8) + 120, dict(quality=75, optimize=True)),                       # flat
+              (np.stack([xx // 8] * 3, -1).astype(np.uint8), dict(quality=90, subsampling=0)),                   # a staircase: periodic blocks
+              ((((xx // 8 + yy // 8) & 1) * 255).astype(np.uint8)[..., None].repeat(3, -1), dict(quality=75, optimize=True))]
+    worst = 0
+    for img, kw in cases:
+        data = _jpeg(img, **kw)
+        got, passes = jpeg_oracle.decode_parallel(data, sub_bytes, max_passes=1 << 20)
+        assert np.array_equal(got, _pil(data)), (img.shape, kw)
+        assert np.array_equal(got, jpeg_oracle.decode(data))                  # ... and the serial walk's
+        worst = max(worst, passes)
+    assert worst >= 2
+    # damaged data is refused by both walks alike
+    good = _jpeg(noise, quality=80)
+    for cut in (len(good) // 2, len(good) - 2):
+        with pytest.raises(ValueError):
+            jpeg_oracle.decode_parallel(good[:cut], sub_bytes)

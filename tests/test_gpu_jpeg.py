@@ -98,7 +98,8 @@ def test_decoded_images_feed_the_gpu_front_end_like_pillow_decoded_ones(gpu):
 
 def test_damaged_files_on_the_device_equal_the_cpu_run_of_the_same_arithmetic(gpu):
     """Mutated files (random bytes, 0xFF insertions, truncations): the device must survive every one of them, refuse the same
-    files as the CPU run of the same sources (oracle/jpeg_ref.cpp) and produce the same pixels for the rest."""
+    files as the CPU run of the same sources (oracle/jpeg_ref.cpp: the parallel entropy decoder with its threads in sequence)
+    and produce the same pixels for the rest."""
     from oracle import jpeg_oracle
     rs = np.random.RandomState(11)
     seeds = [_jpeg(rs.randint(0, 256, (h, w, 3), dtype=np.uint8), quality=85, subsampling=ss, **kw)
@@ -119,7 +120,7 @@ def test_damaged_files_on_the_device_equal_the_cpu_run_of_the_same_arithmetic(gp
     n_ok = 0
     for data, img, st in zip(files, images, status):
         try:
-            ref = jpeg_oracle.decode(data)
+            ref = jpeg_oracle.decode_parallel(data, 2048, 1 << 20)[0]
         except ValueError:
             ref = None
         assert (ref is None) == (st != 0), (st, len(data))
