@@ -333,12 +333,13 @@ JPG_HD int decode_span(const ParGeom& g, const uint8_t* clean, const HuffTable* 
   uint32_t done = 0;
   int16_t* blk = nullptr;
   int mx = 0, my = 0;
+  int p0 = pred[0], p1 = pred[1], p2 = pred[2];                 // (scalars: an array indexed by the component lives in scratch memory on the device)
   if (WRITE) {
     const uint32_t mcu = du / (uint32_t)g.B;
     my = (int)(mcu / (uint32_t)g.mcus_x); mx = (int)(mcu - (uint32_t)my * (uint32_t)g.mcus_x);
     if (du < g.total_du) {
       const int c = g.comp_of_u[s.u];
-      blk = coef[c] + ((size_t)(my * g.v[c] + g.by_of_u[s.u]) * g.bw[c] + (mx * g.h[c] + g.bx_of_u[s.u])) * 64;
+      blk = (c == 0 ? coef[0] : c == 1 ? coef[1] : coef[2]) + ((size_t)(my * g.v[c] + g.by_of_u[s.u]) * g.bw[c] + (mx * g.h[c] + g.bx_of_u[s.u])) * 64;
     }
   }
   for (;;) {
@@ -367,8 +368,9 @@ JPG_HD int decode_span(const ParGeom& g, const uint8_t* clean, const HuffTable* 
       int v = 0;
       if (sz) v = extend((int)((win << len) >> (32 - sz)), sz);
       s.bit += (uint32_t)(len + sz);
-      pred[c] += v;
-      if (WRITE) blk[0] = (int16_t)pred[c];
+      const int pv = (c == 0 ? p0 : c == 1 ? p1 : p2) + v;
+      if (c == 0) p0 = pv; else if (c == 1) p1 = pv; else p2 = pv;
+      if (WRITE) blk[0] = (int16_t)pv;
       s.k = 1;
     } else {
       const int r = sym >> 4, sz = sym & 15;
@@ -393,11 +395,12 @@ JPG_HD int decode_span(const ParGeom& g, const uint8_t* clean, const HuffTable* 
       }
       if (WRITE && du + done < g.total_du) {
         const int cn = g.comp_of_u[s.u];
-        blk = coef[cn] + ((size_t)(my * g.v[cn] + g.by_of_u[s.u]) * g.bw[cn] + (mx * g.h[cn] + g.bx_of_u[s.u])) * 64;
+        blk = (cn == 0 ? coef[0] : cn == 1 ? coef[1] : coef[2]) + ((size_t)(my * g.v[cn] + g.by_of_u[s.u]) * g.bw[cn] + (mx * g.h[cn] + g.bx_of_u[s.u])) * 64;
       }
     }
   }
   *blocks_done = done;
+  pred[0] = p0; pred[1] = p1; pred[2] = p2;
   return 0;
 }
 

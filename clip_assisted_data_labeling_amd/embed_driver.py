@@ -117,7 +117,7 @@ class Feature_Dataset:
         # Files the decoder does not take (progressive, CMYK, PNG, ...) are decoded by Pillow here, as the reference does.
         self.gpu_decode = bool(gpu_decode)
         self.decode_chunk = max(int(decode_chunk), 1)
-        self.gpu_decode_max_bytes = 1 << 20                 # larger files: Pillow in the reader threads (see gpu_decoded_batches)
+        self.gpu_decode_max_bytes = 64 << 20                # larger files: Pillow in the reader threads (see gpu_decoded_batches)
         gpu_preprocess = gpu_preprocess or self.gpu_decode
         self.packed_store = packed_store
         self.shard_images = int(shard_images)     # images per sealed shard = the most a killed rank can lose
@@ -241,9 +241,9 @@ class Feature_Dataset:
             from concurrent.futures import ThreadPoolExecutor
 
             def read(path):
-                """file bytes; files over `gpu_decode_max_bytes` are decoded right here with Pillow (the pool's threads run in
-                parallel: Pillow releases the GIL while it decodes) -- a file is ONE serial stream for the device's entropy
-                decoder, at about a third of a host core's speed, so a multi-megabyte photo would hold its whole batch up"""
+                """file bytes; files over `gpu_decode_max_bytes` (64 MiB: a guard, not a tuning knob -- the device decodes
+                inside a file in parallel) are decoded right here with Pillow (the pool's threads run in parallel: Pillow
+                releases the GIL while it decodes)"""
                 try:
                     with open(path, "rb") as f:
                         blob = f.read()
