@@ -1184,6 +1184,16 @@ int jpegdec_run(jpegdec_t d, void* rgb_dev, int* status, void* stream) {
   return 0;
 }
 
+int jpegdec_probe(const void* file, size_t size, int* width, int* height) {
+  if (!file) return jpg::JPG_NOT_JPEG;
+  static thread_local jpg::ImageDesc d;                       // (7 KiB of tables: not on the caller's stack)
+  size_t so = 0, sl = 0;
+  const int rc = jpg::parse_jpeg((const uint8_t*)file, size, &d, &so, &sl);
+  if (width) *width = d.width;
+  if (height) *height = d.height;
+  return rc;
+}
+
 const char* jpegdec_reason(int code) {
   if (code >= 100) return "invalid or truncated entropy-coded data";
   return jpg::reason_text(code);

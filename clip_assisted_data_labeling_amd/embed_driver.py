@@ -241,13 +241,15 @@ class Feature_Dataset:
             from concurrent.futures import ThreadPoolExecutor
 
             def read(path):
-                """file bytes; files over `gpu_decode_max_bytes` (64 MiB: a guard, not a tuning knob -- the device decodes
-                inside a file in parallel) are decoded right here with Pillow (the pool's threads run in parallel: Pillow
-                releases the GIL while it decodes)"""
+                """file bytes -- or, for a file the device decoder does not take (a header check, microseconds) or one over
+                `gpu_decode_max_bytes` (64 MiB: a guard, not a tuning knob), the image decoded right here with Pillow: the
+                pool's threads run in parallel, Pillow and the check release the GIL"""
                 try:
                     with open(path, "rb") as f:
                         blob = f.read()
-                    if len(blob) > self.gpu_decode_max_bytes:
+                    if len(blob) > self.gpu_decode_max_bytes or not self.jpeg.takes(blob):
+                        # progressive / CMYK / PNG / ...: Pillow, as the reference -- here, in the pool, so that such files
+                        # are decoded in parallel and not one after the other in the main process
                         import io
                         return torch.from_numpy(np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"), dtype=np.uint8).copy())
                     return blob

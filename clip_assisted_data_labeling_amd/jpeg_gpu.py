@@ -25,6 +25,10 @@ class GpuJpegDecoder:
         _lib.check(self.lib.jpegdec_create(self.device.index, ctypes.byref(h)), "jpegdec_create")
         self.handle = h
 
+    def takes(self, data: bytes) -> bool:
+        """host only, thread-safe: would `decode` take this file (baseline JPEG of a supported layout)?"""
+        return self.lib.jpegdec_probe(data, len(data), None, None) == 0
+
     def reason(self, code: int) -> str:
         return self.lib.jpegdec_reason(int(code)).decode()
 

@@ -264,6 +264,10 @@ int jpegdec_plan(jpegdec_t d, const void* const* files, const size_t* sizes, int
  * (their pixels are then undefined). */
 int jpegdec_run(jpegdec_t d, void* rgb_dev, int* status, void* stream);
 const char* jpegdec_reason(int code);
+/* Host only, no handle, thread-safe: would jpegdec_plan take this file?  Returns 0 or the reason code; *width / *height (may be
+ * NULL) whenever the header could be read.  (The embed driver's reader threads use it to decode the other files with Pillow right
+ * there, in parallel, instead of in the main process.) */
+int jpegdec_probe(const void* file, size_t size, int* width, int* height);
 
 /* Operator-level entry points (used by the parity tests to pin each kernel on its own). */
 #define CLIPENC_DT_BF16 0
