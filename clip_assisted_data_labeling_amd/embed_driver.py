@@ -258,18 +258,30 @@ class Feature_Dataset:
                     return None
 
             chunks = [todo[i:i + self.decode_chunk] for i in range(0, len(todo), self.decode_chunk)]
-            with ThreadPoolExecutor(max(2, min(16, self.num_workers or 8))) as pool:
-                ahead = [pool.submit(lambda c=c: [read(p) for p in c]) for c in chunks[:1]]
+            side = torch.cuda.Stream(device=self.device)            # the decode of chunk i + 1 runs beside the encode of chunk i
+
+            def stage(chunk):
+                """one chunk, in the staging thread: its files read by the reader pool (in parallel), its JPEGs decoded on
+                the side stream (host part -- parsing, unstuffing, the copy -- and kernels; the call returns when they are done)"""
+                blobs = list(readers.map(read, chunk))
+                with torch.cuda.stream(side):
+                    images, status = self.jpeg.decode([b if isinstance(b, bytes) else b"" for b in blobs])
+                return blobs, images, status
+
+            with ThreadPoolExecutor(max(2, min(16, self.num_workers or 8))) as readers, ThreadPoolExecutor(1) as stager:
+                ahead = [stager.submit(stage, c) for c in chunks[:1]]
                 for ci, chunk in enumerate(chunks):
                     if ci + 1 < len(chunks):
-                        ahead.append(pool.submit(lambda c=chunks[ci + 1]: [read(p) for p in c]))
-                    blobs = ahead.pop(0).result()
-                    images, status = self.jpeg.decode([b if isinstance(b, bytes) else b"" for b in blobs])
+                        ahead.append(stager.submit(stage, chunks[ci + 1]))
+                    blobs, images, status = ahead.pop(0).result()
+                    for im in images:                               # decoded on the side stream, consumed on this one
+                        if im is not None:
+                            im.record_stream(torch.cuda.current_stream(self.device))
                     acc = []
                     for path, blob, img, st in zip(chunk, blobs, images, status):
-                        if isinstance(blob, torch.Tensor):          # decoded by Pillow in the reader thread (large file)
+                        if isinstance(blob, torch.Tensor):          # decoded by Pillow in a reader thread
                             img, blob = blob, None
-                        if img is None and blob is not None:      # not a baseline JPEG the device takes: Pillow, as the reference
+                        if img is None and blob is not None:      # the device flagged its entropy data: Pillow decides, as the reference
                             try:
                                 import io
                                 arr = np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"), dtype=np.uint8)
