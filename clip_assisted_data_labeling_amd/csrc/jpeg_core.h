@@ -324,7 +324,8 @@ JPG_HD SubSeq subseq_of(const uint32_t* iv_byte, const uint32_t* iv_sub, int n_i
 }
 
 // Decodes symbols from state s until the first symbol boundary at or behind end_bit (WRITE: or until block index du_stop is
-// reached).  du: index of the block in progress at entry; pred: WRITE = the running DC predictors, else accumulators of the DC
+// reached -- the last subsequence of an interval ends by that count; running into end_bit = the interval's end first means the
+// data ran out, and it is also what keeps a damaged stream from being read past its buffer).  du: index of the block in progress at entry; pred: WRITE = the running DC predictors, else accumulators of the DC
 // differences met; *blocks_done: blocks completed.  Returns 0, or (WRITE only; a speculative pass skips a bit instead) 1 for an
 // invalid code / category / coefficient index or more blocks than the interval holds.
 template <bool WRITE>

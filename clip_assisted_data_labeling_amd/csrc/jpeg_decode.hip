@@ -120,7 +120,7 @@ __global__ __launch_bounds__(ENT_THREADS) void jpeg_entropy_kernel(const ImageDe
     uint32_t done = 0;
     const uint32_t du0 = sc[i].du_base;
     if (du0 > iv_stop || iv_first > g.total_du) { err = 1; continue; }
-    if (jpg::decode_span<true>(g, clean, tabs, zz, st, q.last ? 0xffffffffu : q.end_bit, du0, iv_stop, pred, coef, &done)) { err = 1; continue; }
+    if (jpg::decode_span<true>(g, clean, tabs, zz, st, q.end_bit, du0, iv_stop, pred, coef, &done)) { err = 1; continue; }
     if (q.last) {
       if (du0 + done != iv_stop || st.u != 0 || st.k != 0) err = 1;     // the interval does not hold the blocks it must
       else if (st.bit > q.iv_end_bit) err = 2;                   // bits consumed that are not in the file

@@ -144,7 +144,7 @@ int jpeg_ref_decode_parallel(const uint8_t* data, size_t len, uint8_t* rgb, int 
     int pred[3] = {dcb[3 * (size_t)i], dcb[3 * (size_t)i + 1], dcb[3 * (size_t)i + 2]};
     uint32_t done = 0;
     if (du_base[i] > iv_stop) return 101;
-    if (jpg::decode_span<true>(g, clean, d.huff, zz, s, q.last ? 0xffffffffu : q.end_bit, du_base[i], iv_stop, pred, cp, &done)) return 101;
+    if (jpg::decode_span<true>(g, clean, d.huff, zz, s, q.end_bit, du_base[i], iv_stop, pred, cp, &done)) return 101;
     if (q.last) {
       if (du_base[i] + done != iv_stop || s.u != 0 || s.k != 0) return 101;
       if (s.bit > q.iv_end_bit) return 102;                     // consumed bits that are not in the file

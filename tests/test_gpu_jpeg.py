@@ -115,6 +115,25 @@ def test_damaged_files_on_the_device_equal_the_cpu_run_of_the_same_arithmetic(gp
             if t % 7 == 0:
                 a = a[: rs.randint(2, len(a))]
             files.append(bytes(a))
+    # restart intervals that come out too short / too long / renumbered / missing: the writing pass must stop at the interval's end
+    for kw in ({"restart_marker_blocks": 1}, {"restart_marker_rows": 1}, {"restart_marker_blocks": 7}):
+        s = _jpeg(rs.randint(0, 256, (64, 80, 3), dtype=np.uint8), quality=85, **kw)
+        sos = s.index(b"\xff\xda")
+        for t in range(60):
+            a = bytearray(s)
+            p = rs.randint(sos + 14, len(a) - 4)
+            if t % 3 == 0:
+                del a[p:p + rs.randint(1, 200)]
+            elif t % 3 == 1:
+                a[p:p] = a[p:p + rs.randint(1, 200)]
+            else:
+                idx = [i for i in range(sos, len(a) - 1) if a[i] == 0xFF and 0xD0 <= a[i + 1] <= 0xD7]
+                q = idx[rs.randint(0, len(idx))]
+                if t % 2:
+                    del a[q:q + 2]
+                else:
+                    a[q + 1] = 0xD0 + rs.randint(0, 8)
+            files.append(bytes(a))
     dec = GpuJpegDecoder(gpu)
     images, status = dec.decode(files)
     n_ok = 0
