@@ -102,7 +102,7 @@ SIGNATURES = {
     "jpegdec_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jpegdec_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "jpegdec_reason": (ctypes.c_char_p, [c_int]),
-    "jpegdec_probe": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "jpegdec_probe": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
 }
 
 # include/clipenc_diag.h: only in libclipenc_hip_diag.so (`make diag`), bound when present (developer tools)

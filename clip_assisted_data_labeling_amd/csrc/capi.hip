@@ -1184,13 +1184,15 @@ int jpegdec_run(jpegdec_t d, void* rgb_dev, int* status, void* stream) {
   return 0;
 }
 
-int jpegdec_probe(const void* file, size_t size, int* width, int* height) {
+int jpegdec_probe(const void* file, size_t size, int* width, int* height, int* n_scans) {
   if (!file) return jpg::JPG_NOT_JPEG;
   static thread_local jpg::ImageDesc d;                       // (7 KiB of tables: not on the caller's stack)
   size_t so = 0, sl = 0;
-  const int rc = jpg::parse_jpeg((const uint8_t*)file, size, &d, &so, &sl);
+  jpg::ProgInfo prog;
+  const int rc = jpg::parse_jpeg((const uint8_t*)file, size, &d, &so, &sl, &prog);
   if (width) *width = d.width;
   if (height) *height = d.height;
+  if (n_scans) *n_scans = prog.scans.empty() ? 1 : (int)prog.scans.size();
   return rc;
 }
 

@@ -56,6 +56,7 @@ struct ImageDesc {
   uint32_t n_sub;                        // subsequences of the image
   int32_t sub_bytes;
   uint64_t sub_off;                      // scratch: n_sub x { u64 entry, u64 exit, u32 blocks, u32 du_base, i32 dc[3], i32 dc_base[3] }
+  uint64_t prog_off;                     // 0 = a sequential file; else its ProgDesc (progressive: several scans, decoded serially)
   HuffTable huff[4];
 };
 
@@ -403,6 +404,171 @@ JPG_HD int decode_span(const ParGeom& g, const uint8_t* clean, const HuffTable* 
   *blocks_done = done;
   pred[0] = p0; pred[1] = p1; pred[2] = p2;
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ progressive scans
+// T.81 Annex G: the coefficients arrive in several scans -- spectral selection (a band Ss .. Se of the zigzag sequence per scan) and
+// successive approximation (high bits first, then one refining bit per scan: Ah -> Al) -- into the same coefficient planes the
+// baseline decoder fills; after the last scan the planes hold exactly the coefficients of the equivalent baseline file, and
+// everything behind (inverse DCT, upsampling, colour) is shared.  A scan is walked serially by one lane (end-of-band runs and
+// correction bits make the position of every code depend on the coefficients decoded before it); the parallelism is across the
+// images of a batch.  All four procedures follow G.1.2 / G.2 (decoding side: Figures G.3 - G.7 mirrored).
+enum { MAX_SCANS = 24 };
+struct ProgScan {
+  int32_t ncomp, comp[MAX_COMPS];
+  int32_t ss, se, ah, al;
+  int32_t dc_tab[MAX_COMPS], ac_tab;     // indices into the image's table array (ProgDesc::tabs_off)
+  int32_t restart_interval;              // MCUs of THIS scan between restart markers, 0 = none
+  int32_t n_iv;
+  uint64_t clean_off;                    // the scan's unstuffed data (4-byte aligned, 16 bytes of 0xFF behind it)
+  uint32_t clean_len, pad;
+  uint64_t iv_off;                       // uint32 iv_byte[n_iv + 1]
+};
+struct ProgDesc {
+  int32_t n_scans, n_tabs;
+  uint64_t tabs_off;                     // HuffTable[n_tabs]
+  ProgScan scans[MAX_SCANS];
+};
+
+// (reads stop at `limit` = a few bytes behind the scan's end, inside its padding: behind it every bit reads as 1, so a damaged scan
+// can run on -- it is refused at the end of the block -- but never leaves its buffer)
+struct PBits { const uint8_t* clean; uint32_t bit, limit; };
+JPG_HD uint32_t pb_peek(const PBits& b) { return b.bit < b.limit ? peek32(b.clean, b.bit) : 0xffffffffu; }
+JPG_HD int pb_get(PBits& b, int n) {                          // n = 0 .. 16
+  if (n == 0) return 0;
+  const uint32_t w = pb_peek(b);
+  b.bit += (uint32_t)n;
+  return (int)(w >> (32 - n));
+}
+JPG_HD int pb_huff(PBits& b, const HuffTable& t) {            // one symbol, -1 = no such code
+  const int c16 = (int)(pb_peek(b) >> 16);
+  const int e = t.look[c16 >> 7];
+  if (e) { b.bit += (uint32_t)(e >> 8); return e & 0xff; }
+  int len = 10;
+  while (len <= 16 && (c16 >> (16 - len)) > t.maxcode[len]) ++len;
+  if (len > 16) return -1;
+  b.bit += (uint32_t)len;
+  return t.huffval[((c16 >> (16 - len)) + t.valoffset[len]) & 0xff];
+}
+
+JPG_HD bool prog_dc_first(PBits& b, const HuffTable& t, int& pred, int16_t* blk, int al) {
+  const int s = pb_huff(b, t);
+  if (s < 0 || s > 11) return false;
+  if (s) pred += extend(pb_get(b, s), s);
+  blk[0] = (int16_t)((uint32_t)pred << al);
+  return true;
+}
+JPG_HD void prog_dc_refine(PBits& b, int16_t* blk, int al) {
+  if (pb_get(b, 1)) blk[0] = (int16_t)(blk[0] | (1 << al));
+}
+JPG_HD bool prog_ac_first(PBits& b, const HuffTable& t, const uint8_t* zz, int16_t* blk, int ss, int se, int al, int& eobrun) {
+  if (eobrun > 0) { --eobrun; return true; }
+  for (int k = ss; k <= se; ++k) {
+    const int rs = pb_huff(b, t);
+    if (rs < 0) return false;
+    const int r = rs >> 4, s = rs & 15;
+    if (s) {
+      k += r;
+      if (k > se) return false;
+      blk[zz[k]] = (int16_t)((uint32_t)extend(pb_get(b, s), s) << al);
+    } else if (r == 15) {
+      k += 15;                                                   // ZRL
+    } else {
+      eobrun = 1 << r;                                           // EOBn: this band and the bands of the next eobrun - 1 blocks are done
+      if (r) eobrun += pb_get(b, r);
+      --eobrun;
+      break;
+    }
+  }
+  return true;
+}
+JPG_HD bool prog_ac_refine(PBits& b, const HuffTable& t, const uint8_t* zz, int16_t* blk, int ss, int se, int al, int& eobrun) {
+  const int p1 = 1 << al, m1 = -(1 << al);
+  int k = ss;
+  if (eobrun == 0) {
+    for (; k <= se; ++k) {
+      const int rs = pb_huff(b, t);
+      if (rs < 0) return false;
+      int r = rs >> 4, s = rs & 15;
+      if (s) {
+        if (s != 1) return false;                                // a newly nonzero coefficient is +-1 at this bit
+        s = pb_get(b, 1) ? p1 : m1;
+      } else if (r != 15) {
+        eobrun = 1 << r;
+        if (r) eobrun += pb_get(b, r);
+        break;                                                   // the rest of the band: correction bits only (below)
+      }
+      // pass the coefficients that are already nonzero (each takes a correction bit) and r zero-history ones
+      do {
+        int16_t& c = blk[zz[k]];
+        if (c != 0) {
+          if (pb_get(b, 1) && (c & p1) == 0) c = (int16_t)(c + (c >= 0 ? p1 : m1));
+        } else if (--r < 0) {
+          break;
+        }
+        ++k;
+      } while (k <= se);
+      if (s) {
+        if (k > se) return false;
+        blk[zz[k]] = (int16_t)s;
+      }
+    }
+  }
+  if (eobrun > 0) {
+    for (; k <= se; ++k) {
+      int16_t& c = blk[zz[k]];
+      if (c != 0 && pb_get(b, 1) && (c & p1) == 0) c = (int16_t)(c + (c >= 0 ? p1 : m1));
+    }
+    --eobrun;
+  }
+  return true;
+}
+
+// one scan, serially.  0 = ok, 1 = invalid code / index, 2 = the data ran out
+JPG_HD int prog_decode_scan(const ImageDesc& d, const ProgScan& sc, const uint8_t* clean, const uint32_t* iv_byte, const HuffTable* tabs,
+                            const uint8_t* zz, int16_t* const coef[MAX_COMPS]) {
+  PBits b{clean, 0, sc.clean_len * 8u + 64u};
+  int pred[MAX_COMPS] = {0, 0, 0};
+  int eobrun = 0;
+  const bool single = sc.ncomp == 1;
+  const int c0 = sc.comp[0];
+  // a single-component scan walks the component's REAL blocks in raster order; an interleaved one walks MCUs
+  const int nx = single ? (d.dw[c0] + 7) / 8 : d.mcus_x, ny = single ? (d.dh[c0] + 7) / 8 : d.mcus_y;
+  int to_restart = sc.restart_interval, iv = 0;
+  for (int my = 0; my < ny; ++my)
+    for (int mx = 0; mx < nx; ++mx) {
+      if (sc.restart_interval) {
+        if (to_restart == 0) {
+          if (b.bit > iv_byte[iv + 1] * 8u) return 2;
+          ++iv;
+          if (iv >= sc.n_iv) return 1;
+          b.bit = iv_byte[iv] * 8u;
+          pred[0] = pred[1] = pred[2] = 0; eobrun = 0;
+          to_restart = sc.restart_interval;
+        }
+        --to_restart;
+      }
+      for (int ci = 0; ci < sc.ncomp; ++ci) {
+        const int c = sc.comp[ci];
+        const int h = single ? 1 : d.hs[c], v = single ? 1 : d.vs[c];
+        for (int by = 0; by < v; ++by)
+          for (int bx = 0; bx < h; ++bx) {
+            int16_t* blk = coef[c] + ((size_t)(my * v + by) * d.bw[c] + (mx * h + bx)) * 64;
+            bool ok = true;
+            if (sc.ss == 0) {
+              if (sc.ah == 0) ok = prog_dc_first(b, tabs[sc.dc_tab[ci]], pred[ci], blk, sc.al);
+              else prog_dc_refine(b, blk, sc.al);
+            } else if (sc.ah == 0) {
+              ok = prog_ac_first(b, tabs[sc.ac_tab], zz, blk, sc.ss, sc.se, sc.al, eobrun);
+            } else {
+              ok = prog_ac_refine(b, tabs[sc.ac_tab], zz, blk, sc.ss, sc.se, sc.al, eobrun);
+            }
+            if (!ok) return 1;
+            if (b.bit > b.limit) return 2;                        // (behind the end: refused here, see PBits)
+          }
+      }
+    }
+  return b.bit > sc.clean_len * 8u ? 2 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ inverse DCT ("islow")

@@ -55,6 +55,7 @@ __global__ __launch_bounds__(ENT_THREADS) void jpeg_entropy_kernel(const ImageDe
     if (tid == 0) s_err = 0;
   }
   __syncthreads();
+  if (d.prog_off) return;                                      // a progressive file: jpeg_entropy_prog_kernel
   const uint32_t N = d.n_sub;
   if (N == 0) {                                                // the host could not unstuff the scan (no EOI, stray marker)
     if (tid == 0) status[blockIdx.x] = 3;
@@ -133,6 +134,44 @@ __global__ __launch_bounds__(ENT_THREADS) void jpeg_entropy_kernel(const ImageDe
   if (tid == 0) status[blockIdx.x] = s_err;
 }
 
+// Progressive files: one workgroup per image, lane 0 walks the scans one after the other (jpeg_core.h: end-of-band runs and
+// correction bits make a scan serial); the tables of the current scan are in LDS.  The parallelism is across the images of the batch.
+__global__ __launch_bounds__(64) void jpeg_entropy_prog_kernel(const ImageDesc* __restrict__ descs, int* __restrict__ status,
+                                                               uint8_t* __restrict__ arena) {
+  __shared__ jpg::HuffTable tabs[4];                           // DC tables of the scan's components, [3] = its AC table
+  __shared__ uint8_t zz[64];
+  const ImageDesc& d = descs[blockIdx.x];
+  if (!d.prog_off) return;
+  const jpg::ProgDesc& pd = *(const jpg::ProgDesc*)(arena + d.prog_off);
+  const jpg::HuffTable* all = (const jpg::HuffTable*)(arena + pd.tabs_off);
+  const int tid = threadIdx.x;
+  zz[tid] = (uint8_t)jpg::zigzag_to_natural(tid);
+  int16_t* coef[jpg::MAX_COMPS];
+  for (int c = 0; c < jpg::MAX_COMPS; ++c) coef[c] = (int16_t*)(arena + d.coef_off[c]);
+  int st = 0;
+  for (int si = 0; si < pd.n_scans; ++si) {
+    const jpg::ProgScan& ps = pd.scans[si];
+    __syncthreads();                                             // lane 0 is done with the previous scan's tables
+    for (int slot = 0; slot < 4; ++slot) {
+      const int src_i = slot < 3 ? (slot < ps.ncomp && ps.ss == 0 && ps.ah == 0 ? ps.dc_tab[slot] : -1) : (ps.ss > 0 ? ps.ac_tab : -1);
+      if (src_i < 0) continue;
+      const uint32_t* src = (const uint32_t*)(all + src_i);
+      uint32_t* dst = (uint32_t*)(tabs + slot);
+      for (int i = tid; i < (int)(sizeof(jpg::HuffTable) / 4); i += 64) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (tid == 0 && st == 0) {
+      if (ps.n_iv <= 0) st = 3;                                  // the host could not prepare this scan
+      else {
+        jpg::ProgScan local = ps;
+        local.dc_tab[0] = 0; local.dc_tab[1] = 1; local.dc_tab[2] = 2; local.ac_tab = 3;
+        st = jpg::prog_decode_scan(d, local, arena + ps.clean_off, (const uint32_t*)(arena + ps.iv_off), tabs, zz, coef);
+      }
+    }
+  }
+  if (tid == 0) status[blockIdx.x] = st;
+}
+
 // image of a batch-wide index: descs[i].base <= idx < descs[i + 1].base
 template <typename F>
 __device__ __forceinline__ int find_image(const ImageDesc* descs, int n, uint64_t idx, F base_of) {
@@ -189,6 +228,9 @@ struct JpegDecState {
   std::vector<int> input_index;            // descs[i] = input file input_index[i]
   std::vector<std::pair<const uint8_t*, size_t>> scans;
   std::vector<uint32_t> max_iv;            // per image: upper bound of its restart intervals
+  std::vector<jpg::ProgInfo> prog;         // per image: its scans, if it is a progressive file (else empty)
+  bool any_prog = false;
+  std::vector<size_t> prog_tabs_off;       // per image: arena offset of its table array (progressive)
   std::vector<int> host_status;            // per image: 0, or why the host could not prepare its scan
   size_t stage_bytes = 0, arena_bytes = 0, desc_begin = 0, coef_begin = 0, coef_bytes = 0, max_pixels = 0;
   uint64_t total_blocks = 0, rgb_bytes = 0;
@@ -211,7 +253,8 @@ void ce_jpegdec_destroy(JpegDecState* s) {
 // *rgb_bytes bytes (256-byte aligned images).
 void ce_jpegdec_plan(JpegDecState* s, const void* const* files, const size_t* sizes, int n, int* status, int* widths, int* heights,
                      unsigned long long* rgb_offsets, unsigned long long* rgb_bytes) {
-  s->descs.clear(); s->input_index.clear(); s->scans.clear();
+  s->descs.clear(); s->input_index.clear(); s->scans.clear(); s->prog.clear();
+  s->any_prog = false;
   s->descs.reserve((size_t)n);
   size_t rgb = 0;
   uint64_t blocks = 0;
@@ -219,7 +262,8 @@ void ce_jpegdec_plan(JpegDecState* s, const void* const* files, const size_t* si
   for (int i = 0; i < n; ++i) {
     ImageDesc d;
     size_t so = 0, sl = 0;
-    const int rc = files[i] ? jpg::parse_jpeg((const uint8_t*)files[i], sizes[i], &d, &so, &sl) : jpg::JPG_NOT_JPEG;
+    jpg::ProgInfo pi;
+    const int rc = files[i] ? jpg::parse_jpeg((const uint8_t*)files[i], sizes[i], &d, &so, &sl, &pi) : jpg::JPG_NOT_JPEG;
     status[i] = rc; widths[i] = d.width; heights[i] = d.height; rgb_offsets[i] = 0;
     if (rc) continue;
     d.rgb_off = rgb; rgb_offsets[i] = rgb;
@@ -231,7 +275,9 @@ void ce_jpegdec_plan(JpegDecState* s, const void* const* files, const size_t* si
     s->max_pixels = std::max(s->max_pixels, (size_t)d.width * d.height);
     s->descs.push_back(d);
     s->input_index.push_back(i);
-    s->scans.emplace_back((const uint8_t*)files[i] + so, sl);
+    s->scans.emplace_back((const uint8_t*)files[i] + so, sl);   // (progressive: the file start, its scans carry their own ranges)
+    if (!pi.scans.empty()) s->any_prog = true;
+    s->prog.push_back(std::move(pi));
   }
   // arena: [status words][descs][per image: unstuffed scan + restart-interval table][subsequence scratch][coefficients]
   // [sample planes]; the first three are what the staging buffer holds.  Sizes here are upper bounds (the scan is unstuffed in
@@ -240,24 +286,48 @@ void ce_jpegdec_plan(JpegDecState* s, const void* const* files, const size_t* si
   s->desc_begin = up(m * sizeof(int), 256);
   size_t off = s->desc_begin + up(m * sizeof(ImageDesc), 256);
   s->max_iv.assign(m, 1);
+  s->prog_tabs_off.clear();
   for (size_t i = 0; i < m; ++i) {
     ImageDesc& d = s->descs[i];
     const size_t scan_len = s->scans[i].second;
     const size_t mcus = (size_t)d.mcus_x * d.mcus_y;
     const size_t max_iv = d.restart_interval ? (mcus + d.restart_interval - 1) / d.restart_interval : 1;
     s->max_iv[i] = (uint32_t)max_iv;
+    d.sub_bytes = SUB_BYTES;
+    d.data_off = 0; d.data_len = 0; d.data_real = 0;             // (the stuffed segment does not travel to the device)
+    d.prog_off = 0;
+    jpg::ProgInfo& pi = s->prog[i];
+    if (!pi.scans.empty()) {
+      // progressive: [ProgDesc][tables][per scan: unstuffed data, interval starts]
+      d.prog_off = off;
+      off += up(sizeof(jpg::ProgDesc), 16);
+      const size_t tabs_off = off;
+      off += up(pi.tabs.size() * sizeof(jpg::HuffTable), 16);
+      for (auto& si : pi.scans) {
+        const bool single = si.s.ncomp == 1;
+        const size_t smcus = single ? (size_t)((d.dw[si.s.comp[0]] + 7) / 8) * ((d.dh[si.s.comp[0]] + 7) / 8) : mcus;
+        const size_t siv = si.s.restart_interval ? (smcus + si.s.restart_interval - 1) / si.s.restart_interval : 1;
+        si.s.clean_off = off;
+        off += up(si.end - si.begin + 32, 16);
+        si.s.iv_off = off;
+        off += up((siv + 1) * sizeof(uint32_t), 16);
+        si.s.n_iv = (int32_t)siv;                                // (expected count; verified when the scan is unstuffed)
+      }
+      s->prog_tabs_off.push_back(tabs_off);
+      d.clean_off = 0; d.iv_off = 0;
+      continue;
+    }
+    s->prog_tabs_off.push_back(0);
     d.clean_off = off;
     off += up(scan_len + 16, 16);
     d.iv_off = off;
     off += up((max_iv + 1) * 2 * sizeof(uint32_t), 16);
-    d.sub_bytes = SUB_BYTES;
-    d.data_off = 0; d.data_len = 0; d.data_real = 0;             // (the stuffed segment does not travel to the device)
   }
   off = up(off, 256);
   s->stage_bytes = off;
   for (size_t i = 0; i < m; ++i) {
     ImageDesc& d = s->descs[i];
-    const size_t max_sub = s->scans[i].second / SUB_BYTES + s->max_iv[i] + 1;
+    const size_t max_sub = d.prog_off ? 0 : s->scans[i].second / SUB_BYTES + s->max_iv[i] + 1;
     d.sub_off = off;
     off += up(max_sub * sizeof(SubScratch), 16);
   }
@@ -303,6 +373,25 @@ hipError_t ce_jpegdec_run(JpegDecState* s, void* rgb_dev, int* status, hipStream
     auto work = [&](int t) {
       for (size_t i = (size_t)t; i < m; i += (size_t)nt) {
         ImageDesc& d = s->descs[i];
+        if (d.prog_off) {
+          jpg::ProgInfo& pi = s->prog[i];
+          jpg::ProgDesc* pd = (jpg::ProgDesc*)(st + d.prog_off);
+          memset(pd, 0, sizeof *pd);
+          pd->n_scans = (int32_t)pi.scans.size(); pd->n_tabs = (int32_t)pi.tabs.size(); pd->tabs_off = s->prog_tabs_off[i];
+          memcpy(st + pd->tabs_off, pi.tabs.data(), pi.tabs.size() * sizeof(jpg::HuffTable));
+          d.n_sub = 0; d.n_iv = 0; d.clean_len = 0;
+          for (size_t k = 0; k < pi.scans.size(); ++k) {
+            jpg::ProgScan ps = pi.scans[k].s;
+            uint32_t* ivb = (uint32_t*)(st + ps.iv_off);
+            int got_iv = 0;
+            const long cl = jpg::unstuff_scan(s->scans[i].first + pi.scans[k].begin, pi.scans[k].end - pi.scans[k].begin, st + ps.clean_off, ivb,
+                                              ps.n_iv, &got_iv, false);
+            if (cl < 0 || got_iv != ps.n_iv) { ps.n_iv = 0; ps.clean_len = 0; s->host_status[i] = cl < 0 ? 3 : 1; }
+            else { ivb[got_iv] = (uint32_t)cl; ps.clean_len = (uint32_t)cl; memset(st + ps.clean_off + cl, 0xFF, 32); }
+            pd->scans[k] = ps;
+          }
+          continue;
+        }
         uint32_t* iv_byte = (uint32_t*)(st + d.iv_off);
         int n_iv = 0;
         const long clen = jpg::unstuff_scan(s->scans[i].first, s->scans[i].second, st + d.clean_off, iv_byte, (int)s->max_iv[i], &n_iv);
@@ -334,6 +423,7 @@ hipError_t ce_jpegdec_run(JpegDecState* s, void* rgb_dev, int* status, hipStream
   if (hipError_t e = hipMemsetAsync(arena + s->coef_begin, 0, s->coef_bytes, stream); e != hipSuccess) return e;
   const ImageDesc* descs = (const ImageDesc*)(arena + s->desc_begin);
   hipLaunchKernelGGL(jpeg_entropy_kernel, dim3((unsigned)m), dim3(ENT_THREADS), 0, stream, descs, (int*)arena, arena);
+  if (s->any_prog) hipLaunchKernelGGL(jpeg_entropy_prog_kernel, dim3((unsigned)m), dim3(64), 0, stream, descs, (int*)arena, arena);
   hipLaunchKernelGGL(jpeg_idct_kernel, dim3((unsigned)((s->total_blocks + 255) / 256)), dim3(256), 0, stream, descs, (int)m,
                      s->total_blocks, arena);
   hipLaunchKernelGGL(jpeg_colour_kernel, dim3((unsigned)((s->max_pixels + 255) / 256), (unsigned)m), dim3(256), 0, stream, descs, arena,

@@ -47,7 +47,8 @@ namespace {
 inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 }
 
-long unstuff_scan(const uint8_t* scan, size_t len, uint8_t* clean, uint32_t* interval_start, int max_intervals, int* n_intervals) {
+long unstuff_scan(const uint8_t* scan, size_t len, uint8_t* clean, uint32_t* interval_start, int max_intervals, int* n_intervals,
+                  bool require_eoi) {
   size_t i = 0, o = 0;
   int niv = 1, next_rst = 0;
   interval_start[0] = 0;
@@ -61,7 +62,7 @@ long unstuff_scan(const uint8_t* scan, size_t len, uint8_t* clean, uint32_t* int
     // scan[i] == 0xFF
     size_t j = i + 1;
     while (j < len && scan[j] == 0xFF) ++j;                       // fill bytes
-    if (j >= len) { i = len; break; }                             // the file ends inside a marker
+    if (j >= len) { i = len; break; }                             // the data ends inside a marker
     const int m = scan[j];
     if (m == 0x00) {
       if (j != i + 1) return -1;                                  // 0xFF 0xFF 0x00: not valid entropy data
@@ -79,20 +80,74 @@ long unstuff_scan(const uint8_t* scan, size_t len, uint8_t* clean, uint32_t* int
       return -1;                                                  // another marker inside the scan (DNL, a second scan, ...)
     }
   }
-  if (!eoi) return -1;
+  if (!eoi && require_eoi) return -1;
   memset(clean + o, 0xFF, 16);
   *n_intervals = niv;
   return (long)o;
 }
 
-int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, size_t* scan_len) {
+namespace {
+
+// end of the entropy-coded data that starts at `pos`: the position of the next marker that is not RSTn (stuffed zeros and fill
+// bytes skipped); len if the file ends first
+size_t find_scan_end(const uint8_t* data, size_t len, size_t pos) {
+  while (pos < len) {
+    const uint8_t* f = (const uint8_t*)memchr(data + pos, 0xFF, len - pos);
+    if (!f) return len;
+    size_t i = (size_t)(f - data), j = i + 1;
+    while (j < len && data[j] == 0xFF) ++j;
+    if (j >= len) return len;
+    const int m = data[j];
+    if (m == 0x00 || (m >= 0xD0 && m <= 0xD7)) { pos = j + 1; continue; }
+    return i;
+  }
+  return len;
+}
+
+}  // namespace
+
+int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, size_t* scan_len, ProgInfo* prog) {
   memset(d, 0, sizeof *d);
+  *scan_off = 0; *scan_len = 0;
   if (len < 4 || data[0] != 0xFF || data[1] != 0xD8 || data[2] != 0xFF) return JPG_NOT_JPEG;   // (Pillow identifies JPEG by these three bytes)
   uint16_t qt[4][64];
   bool have_qt[4] = {false, false, false, false}, have_ht[4] = {false, false, false, false};
   int comp_id[MAX_COMPS] = {0, 0, 0}, comp_tq[MAX_COMPS] = {0, 0, 0};
-  bool have_sof = false, jfif = false, adobe = false;
+  bool have_sof = false, jfif = false, adobe = false, progressive = false, frame_done = false;
   int adobe_transform = -1;
+  int cur_tab[4] = {-1, -1, -1, -1};                              // progressive: index in prog->tabs of DC 0, DC 1, AC 0, AC 1
+  int last_al[MAX_COMPS][64];                                     // progressive: -1 = coefficient not coded yet, else the bit it is refined down to
+  for (auto& row : last_al) for (int& v : row) v = -1;
+
+  // colour space, sampling, geometry, quantisation tables: at the first SOS
+  auto finish_frame = [&]() -> int {
+    if (d->ncomp == 3) {
+      // (libjpeg's rules): JFIF = YCbCr, Adobe transform 0 = RGB, 1 = YCbCr, otherwise by the component ids
+      bool ycc = true;
+      if (jfif) ycc = true;
+      else if (adobe) ycc = adobe_transform == 1;
+      else if (comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') ycc = false;
+      if (!ycc) return JPG_COLORSPACE;
+      if (d->hs[1] != 1 || d->vs[1] != 1 || d->hs[2] != 1 || d->vs[2] != 1) return JPG_SAMPLING;
+      if (!((d->hs[0] == 1 && d->vs[0] == 1) || (d->hs[0] == 2 && d->vs[0] == 1) || (d->hs[0] == 2 && d->vs[0] == 2))) return JPG_SAMPLING;
+      d->hmax = d->hs[0]; d->vmax = d->vs[0];
+    } else {
+      d->hs[0] = d->vs[0] = 1;                                    // a single-component scan is never interleaved: 8 x 8 "MCUs"
+      d->hmax = d->vmax = 1;
+    }
+    d->mcus_x = (d->width + 8 * d->hmax - 1) / (8 * d->hmax);
+    d->mcus_y = (d->height + 8 * d->vmax - 1) / (8 * d->vmax);
+    for (int c = 0; c < d->ncomp; ++c) {
+      if (!have_qt[comp_tq[c]]) return JPG_TABLES;
+      memcpy(d->quant[c], qt[comp_tq[c]], sizeof d->quant[c]);
+      d->bw[c] = d->mcus_x * d->hs[c]; d->bh[c] = d->mcus_y * d->vs[c];
+      d->dw[c] = (d->width * d->hs[c] + d->hmax - 1) / d->hmax;
+      d->dh[c] = (d->height * d->vs[c] + d->vmax - 1) / d->vmax;
+    }
+    frame_done = true;
+    return JPG_OK;
+  };
+
   size_t pos = 2;
   for (;;) {
     while (pos < len && data[pos] != 0xFF) ++pos;                // (garbage between segments is skipped, as libjpeg does)
@@ -100,7 +155,13 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
     if (pos >= len) return JPG_TRUNCATED;
     const int m = data[pos++];
     if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
-    if (m == 0xD9) return JPG_TRUNCATED;                          // EOI before any scan
+    if (m == 0xD9) {                                              // EOI
+      if (!progressive || !prog || prog->scans.empty()) return JPG_TRUNCATED;     // before any scan
+      for (int c = 0; c < d->ncomp; ++c)
+        for (int k = 0; k < 64; ++k)
+          if (last_al[c][k] != 0) return JPG_PROGRESSIVE;         // an unfinished progression (Pillow would smooth it)
+      return JPG_OK;
+    }
     if (pos + 2 > len) return JPG_TRUNCATED;
     const int seg = be16(data + pos);
     if (seg < 2 || pos + (size_t)seg > len) return JPG_TRUNCATED;
@@ -109,6 +170,7 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
     if (m == 0xE0 && n >= 5 && !memcmp(s, "JFIF\0", 5)) jfif = true;
     else if (m == 0xEE && n >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_transform = s[11]; }
     else if (m == 0xDB) {                                         // DQT
+      if (frame_done) return JPG_TABLES;                          // (redefined between scans: not met in practice)
       int i = 0;
       while (i < n) {
         const int pq = s[i] >> 4, tq = s[i] & 15;
@@ -129,19 +191,24 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
         int total = 0;
         for (int l = 0; l < 16; ++l) total += s[i + 1 + l];
         if (tc > 1 || i + 17 + total > n) return JPG_CORRUPT;
-        if (th > 1) return JPG_TABLES;                            // (ids 2, 3: extended sequential only; not met in practice)
+        if (th > 1) return JPG_TABLES;                            // (ids 2, 3: extended sequential / progressive only; not met in practice)
         if (tc == 0)
           for (int k = 0; k < total; ++k)
             if (s[i + 17 + k] > 15) return JPG_CORRUPT;          // a DC table codes categories 0 .. 15
         if (!build_huff(s + i + 1, s + i + 17, total, &d->huff[tc * 2 + th])) return JPG_CORRUPT;
         have_ht[tc * 2 + th] = true;
+        if (prog) { prog->tabs.push_back(d->huff[tc * 2 + th]); cur_tab[tc * 2 + th] = (int)prog->tabs.size() - 1; }
         i += 17 + total;
       }
     } else if (m == 0xDD) {                                       // DRI
       if (n != 2) return JPG_CORRUPT;
       d->restart_interval = be16(s);
-    } else if (m == 0xC0 || m == 0xC1) {                          // SOF0 / SOF1: sequential Huffman
+    } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {             // SOF0 / SOF1: sequential Huffman; SOF2: progressive Huffman
       if (n < 6 || have_sof) return JPG_CORRUPT;
+      if (m == 0xC2) {
+        if (!prog) return JPG_PROGRESSIVE;
+        progressive = true;
+      }
       if (s[0] != 8) return JPG_PRECISION;
       d->height = be16(s + 1); d->width = be16(s + 3); d->ncomp = s[5];
       if (d->width < 1 || d->height < 1) return JPG_CORRUPT;     // (height 0 = DNL marker: not supported)
@@ -155,7 +222,7 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
         if (comp_tq[c] > 3 || d->hs[c] < 1 || d->vs[c] < 1 || d->hs[c] > 4 || d->vs[c] > 4) return JPG_CORRUPT;
       }
       have_sof = true;
-    } else if ((m >= 0xC2 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+    } else if ((m >= 0xC3 && m <= 0xCF) && m != 0xC4 && m != 0xC8 && m != 0xCC) {
       return (m == 0xC9 || m == 0xCA || m == 0xCB || m == 0xCD || m == 0xCE || m == 0xCF) ? JPG_ARITHMETIC : JPG_PROGRESSIVE;
     } else if (m == 0xCC) {
       return JPG_ARITHMETIC;
@@ -163,44 +230,63 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
       return JPG_CORRUPT;                                         // not a segment libjpeg skips: Pillow decides what the file is
     } else if (m == 0xDA) {                                       // SOS
       if (!have_sof) return JPG_CORRUPT;
-      if (n < 1 || s[0] != d->ncomp) return JPG_MULTI_SCAN;
-      if (n != 1 + 2 * d->ncomp + 3) return JPG_CORRUPT;
-      for (int c = 0; c < d->ncomp; ++c) {
-        if (s[1 + 2 * c] != comp_id[c]) return JPG_MULTI_SCAN;   // (components in frame order)
-        const int td = s[2 + 2 * c] >> 4, ta = s[2 + 2 * c] & 15;
+      const int ns = n >= 1 ? s[0] : 0;
+      if (ns < 1 || ns > d->ncomp) return JPG_CORRUPT;
+      if (n != 1 + 2 * ns + 3) return JPG_CORRUPT;
+      if (!frame_done)
+        if (const int rc = finish_frame()) return rc;
+      const uint8_t* e = s + 1 + 2 * ns;
+      if (!progressive) {
+        if (ns != d->ncomp) return JPG_MULTI_SCAN;
+        for (int c = 0; c < d->ncomp; ++c) {
+          if (s[1 + 2 * c] != comp_id[c]) return JPG_MULTI_SCAN;   // (components in frame order)
+          const int td = s[2 + 2 * c] >> 4, ta = s[2 + 2 * c] & 15;
+          if (td > 1 || ta > 1) return JPG_TABLES;
+          if (!have_ht[td] || !have_ht[2 + ta]) return JPG_TABLES;
+          d->dc_tab[c] = td; d->ac_tab[c] = 2 + ta;
+        }
+        if (e[0] != 0 || e[1] != 63 || e[2] != 0) return JPG_CORRUPT;
+        *scan_off = pos + (size_t)seg;
+        *scan_len = len - *scan_off;
+        return JPG_OK;
+      }
+      // ---- a scan of a progressive file
+      if (prog->scans.size() >= MAX_SCANS) return JPG_PROGRESSIVE;
+      ProgScanInfo si;
+      memset(&si, 0, sizeof si);
+      ProgScan& ps = si.s;
+      ps.ncomp = ns;
+      ps.ss = e[0]; ps.se = e[1]; ps.ah = e[2] >> 4; ps.al = e[2] & 15;
+      ps.restart_interval = d->restart_interval;
+      int prev = -1;
+      for (int i = 0; i < ns; ++i) {
+        int c = -1;
+        for (int q = 0; q < d->ncomp; ++q) if (comp_id[q] == s[1 + 2 * i]) c = q;
+        if (c <= prev) return JPG_CORRUPT;                        // unknown component / not in frame order
+        prev = c;
+        ps.comp[i] = c;
+        const int td = s[2 + 2 * i] >> 4, ta = s[2 + 2 * i] & 15;
         if (td > 1 || ta > 1) return JPG_TABLES;
-        if (!have_ht[td] || !have_ht[2 + ta]) return JPG_TABLES;
-        d->dc_tab[c] = td; d->ac_tab[c] = 2 + ta;
+        if (ps.ss == 0 && ps.ah == 0) { if (cur_tab[td] < 0) return JPG_TABLES; ps.dc_tab[i] = cur_tab[td]; }
+        if (ps.ss > 0) { if (cur_tab[2 + ta] < 0) return JPG_TABLES; ps.ac_tab = cur_tab[2 + ta]; }
       }
-      const uint8_t* e = s + 1 + 2 * d->ncomp;
-      if (e[0] != 0 || e[1] != 63 || e[2] != 0) return JPG_PROGRESSIVE;
-      // colour space (libjpeg's rules): 1 component = grey; 3 components: JFIF = YCbCr, Adobe transform 0 = RGB, 1 = YCbCr,
-      // otherwise by the component ids (1 2 3 = YCbCr, 'R' 'G' 'B' = RGB, anything else YCbCr)
-      if (d->ncomp == 3) {
-        bool ycc = true;
-        if (jfif) ycc = true;
-        else if (adobe) ycc = adobe_transform == 1;
-        else if (comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') ycc = false;
-        if (!ycc) return JPG_COLORSPACE;
-        if (d->hs[1] != 1 || d->vs[1] != 1 || d->hs[2] != 1 || d->vs[2] != 1) return JPG_SAMPLING;
-        if (!((d->hs[0] == 1 && d->vs[0] == 1) || (d->hs[0] == 2 && d->vs[0] == 1) || (d->hs[0] == 2 && d->vs[0] == 2))) return JPG_SAMPLING;
-        d->hmax = d->hs[0]; d->vmax = d->vs[0];
-      } else {
-        d->hs[0] = d->vs[0] = 1;                                  // a single-component scan is never interleaved: 8 x 8 "MCUs"
-        d->hmax = d->vmax = 1;
-      }
-      d->mcus_x = (d->width + 8 * d->hmax - 1) / (8 * d->hmax);
-      d->mcus_y = (d->height + 8 * d->vmax - 1) / (8 * d->vmax);
-      for (int c = 0; c < d->ncomp; ++c) {
-        if (!have_qt[comp_tq[c]]) return JPG_TABLES;
-        memcpy(d->quant[c], qt[comp_tq[c]], sizeof d->quant[c]);
-        d->bw[c] = d->mcus_x * d->hs[c]; d->bh[c] = d->mcus_y * d->vs[c];
-        d->dw[c] = (d->width * d->hs[c] + d->hmax - 1) / d->hmax;
-        d->dh[c] = (d->height * d->vs[c] + d->vmax - 1) / d->vmax;
-      }
-      *scan_off = pos + (size_t)seg;
-      *scan_len = len - *scan_off;
-      return JPG_OK;
+      // the scan must be a legal step of an orderly progression (T.81 G.1.1.1.1): DC scans cover coefficient 0 only and may
+      // interleave components, AC scans cover one component; first pass Ah = 0, every later pass refines exactly the next bit
+      if (ps.ss > ps.se || ps.se > 63 || ps.al > 13 || (ps.ss == 0 && ps.se != 0) || (ps.ss > 0 && ns != 1)) return JPG_CORRUPT;
+      if (ps.ah != 0 && ps.al != ps.ah - 1) return JPG_CORRUPT;
+      for (int i = 0; i < ns; ++i)
+        for (int k = ps.ss; k <= ps.se; ++k) {
+          int& la = last_al[ps.comp[i]][k];
+          if (ps.ah == 0 ? la != -1 : la != ps.ah) return JPG_PROGRESSIVE;   // (out of order: libjpeg only warns; Pillow decodes it)
+          la = ps.al;
+        }
+      if (ps.ss > 0 && last_al[ps.comp[0]][0] < 0) return JPG_PROGRESSIVE;   // AC before the component's DC
+      si.begin = pos + (size_t)seg;
+      si.end = find_scan_end(data, len, si.begin);
+      if (si.end >= len) return JPG_TRUNCATED;
+      prog->scans.push_back(si);
+      pos = si.end;
+      continue;
     }
     pos += (size_t)seg;
   }

@@ -118,6 +118,10 @@ class Feature_Dataset:
         self.gpu_decode = bool(gpu_decode)
         self.decode_chunk = max(int(decode_chunk), 1)
         self.gpu_decode_max_bytes = 64 << 20                # larger files: Pillow in the reader threads (see gpu_decoded_batches)
+        # Progressive files: the device takes them, but walks each with ONE lane (scans are serial), 0.25 - 0.5 s for a chunk
+        # during which its small workgroups sit on every CU and the encoder's persistent kernels cannot be placed -- with host
+        # cores to spare Pillow in the reader threads is the better deal; set True on a box without them.
+        self.gpu_decode_progressive = False
         gpu_preprocess = gpu_preprocess or self.gpu_decode
         self.packed_store = packed_store
         self.shard_images = int(shard_images)     # images per sealed shard = the most a killed rank can lose
@@ -247,9 +251,9 @@ class Feature_Dataset:
                 try:
                     with open(path, "rb") as f:
                         blob = f.read()
-                    if len(blob) > self.gpu_decode_max_bytes or not self.jpeg.takes(blob):
-                        # progressive / CMYK / PNG / ...: Pillow, as the reference -- here, in the pool, so that such files
-                        # are decoded in parallel and not one after the other in the main process
+                    if len(blob) > self.gpu_decode_max_bytes or not self.jpeg.takes(blob, progressive=self.gpu_decode_progressive):
+                        # CMYK / PNG / ... and, unless asked for, progressive JPEG: Pillow, as the reference -- here, in the
+                        # pool, so that such files are decoded in parallel and not one after the other in the main process
                         import io
                         return torch.from_numpy(np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"), dtype=np.uint8).copy())
                     return blob

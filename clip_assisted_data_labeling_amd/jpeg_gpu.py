@@ -3,8 +3,9 @@
 /root/reference/utils/embedder.py:167 opens every image with `PIL.Image.open(path).convert('RGB')` inside DataLoader workers;
 on real data that host-side decode is what bounds the embed driver.  `GpuJpegDecoder.decode` takes the file BYTES of a batch,
 parses the headers on the host and decodes on the device with Pillow's (libjpeg-turbo's default) integer arithmetic, so the
-pixels are identical to Pillow's.  Files it does not take (progressive, CMYK, 4:4:0, ... — `reason`) come back as None and
-the caller decodes them with Pillow.  No CPU fallback inside: without the HIP library this module raises.
+pixels are identical to Pillow's.  Files it does not take (CMYK, 4:4:0, arithmetic coding, ... — `reason`) come back as None
+and the caller decodes them with Pillow.  Sequential files are decoded in parallel inside each file; progressive files are taken
+too, one lane per image (serial scans).  No CPU fallback inside: without the HIP library this module raises.
 """
 from __future__ import annotations
 
@@ -25,9 +26,13 @@ class GpuJpegDecoder:
         _lib.check(self.lib.jpegdec_create(self.device.index, ctypes.byref(h)), "jpegdec_create")
         self.handle = h
 
-    def takes(self, data: bytes) -> bool:
-        """host only, thread-safe: would `decode` take this file (baseline JPEG of a supported layout)?"""
-        return self.lib.jpegdec_probe(data, len(data), None, None) == 0
+    def takes(self, data: bytes, progressive: bool = True) -> bool:
+        """host only, thread-safe: would `decode` take this file?  progressive=False: only sequential files (the parallel
+        entropy kernel); a progressive file is walked by one lane per image, scan after scan."""
+        n = ctypes.c_int(0)
+        if self.lib.jpegdec_probe(data, len(data), None, None, ctypes.byref(n)) != 0:
+            return False
+        return progressive or n.value == 1
 
     def reason(self, code: int) -> str:
         return self.lib.jpegdec_reason(int(code)).decode()

@@ -248,9 +248,9 @@ int clipenc_mfma_stream_probe(int device, int fp8, const void* operands_dev, flo
 /* ---- JPEG files -> RGB on the device: the decode step of the reference's image loader
  * (/root/reference/utils/embedder.py:167, PIL.Image.open(path).convert('RGB')), bit-identical to Pillow's libjpeg-turbo defaults
  * (integer "islow" inverse DCT, triangle-filter chroma upsampling, JFIF colour conversion).  Decodable here: baseline and
- * extended-sequential Huffman JPEG, 8 bits, one interleaved scan, greyscale or YCbCr 4:4:4 / 4:2:2 (2x1) / 4:2:0 (2x2), restart
- * intervals.  Anything else gets a reason code from jpegdec_plan and is left to the caller (the embed driver gives such files to
- * Pillow).  One batch at a time per handle: plan (host only), then run. */
+ * extended-sequential Huffman JPEG with one interleaved scan, and progressive Huffman JPEG whose scans form a complete, orderly
+ * progression; 8 bits, greyscale or YCbCr 4:4:4 / 4:2:2 (2x1) / 4:2:0 (2x2), restart intervals.  Anything else gets a reason code
+ * from jpegdec_plan and is left to the caller (the embed driver gives such files to Pillow).  One batch at a time per handle: plan (host only), then run. */
 typedef struct jpegdec_s* jpegdec_t;
 int jpegdec_create(int device, jpegdec_t* out);
 int jpegdec_destroy(jpegdec_t d);
@@ -265,9 +265,11 @@ int jpegdec_plan(jpegdec_t d, const void* const* files, const size_t* sizes, int
 int jpegdec_run(jpegdec_t d, void* rgb_dev, int* status, void* stream);
 const char* jpegdec_reason(int code);
 /* Host only, no handle, thread-safe: would jpegdec_plan take this file?  Returns 0 or the reason code; *width / *height (may be
- * NULL) whenever the header could be read.  (The embed driver's reader threads use it to decode the other files with Pillow right
- * there, in parallel, instead of in the main process.) */
-int jpegdec_probe(const void* file, size_t size, int* width, int* height);
+ * NULL) whenever the header could be read; *n_scans (may be NULL): 1 for a sequential file, the number of scans of a progressive
+ * one.  (The embed driver's reader threads use it: files the device does not take, and by default progressive files -- whose
+ * scans one lane per image walks serially, long enough to keep the encoder's persistent kernels off the CUs meanwhile -- are
+ * decoded with Pillow right there, in parallel.) */
+int jpegdec_probe(const void* file, size_t size, int* width, int* height, int* n_scans);
 
 /* Operator-level entry points (used by the parity tests to pin each kernel on its own). */
 #define CLIPENC_DT_BF16 0

@@ -13,9 +13,10 @@ extern "C" {
 
 // returns a jpg:: reason code (0 = decodable); width / height are filled whenever the header could be read
 int jpeg_ref_info(const uint8_t* data, size_t len, int* width, int* height, int* ncomp) {
-  jpg::ImageDesc d;
+  static jpg::ImageDesc d;
   size_t so = 0, sl = 0;
-  const int rc = jpg::parse_jpeg(data, len, &d, &so, &sl);
+  jpg::ProgInfo prog;
+  const int rc = jpg::parse_jpeg(data, len, &d, &so, &sl, &prog);
   *width = d.width; *height = d.height; *ncomp = d.ncomp;
   return rc;
 }
@@ -45,12 +46,49 @@ void finish_image(const jpg::ImageDesc& d, int16_t* const cp[jpg::MAX_COMPS], ui
 
 }  // namespace
 
+namespace {
+
+// a progressive file: its scans one after the other (jpeg_core.h: prog_decode_scan), exactly what the device's lane does
+int decode_progressive(const uint8_t* data, const jpg::ImageDesc& d, jpg::ProgInfo& prog, uint8_t* rgb) {
+  std::vector<std::vector<int16_t>> coef(d.ncomp);
+  int16_t* cp[jpg::MAX_COMPS] = {nullptr, nullptr, nullptr};
+  for (int c = 0; c < d.ncomp; ++c) { coef[c].assign((size_t)d.bw[c] * d.bh[c] * 64, 0); cp[c] = coef[c].data(); }
+  uint8_t zz[64];
+  for (int k = 0; k < 64; ++k) zz[k] = (uint8_t)jpg::zigzag_to_natural(k);
+  for (auto& si : prog.scans) {
+    const size_t sl = si.end - si.begin;
+    std::vector<uint32_t> clean_words((sl + 32) / 4 + 8);
+    uint8_t* clean = (uint8_t*)clean_words.data();
+    std::vector<uint32_t> iv_byte(sl / 2 + 4);
+    int n_iv = 0;
+    const long clen = jpg::unstuff_scan(data + si.begin, sl, clean, iv_byte.data(), (int)iv_byte.size() - 1, &n_iv, false);
+    if (clen < 0) return 103;
+    memset(clean + clen, 0xFF, 32);
+    jpg::ProgScan& ps = si.s;
+    const bool single = ps.ncomp == 1;
+    const uint32_t mcus = single ? (uint32_t)((d.dw[ps.comp[0]] + 7) / 8) * (uint32_t)((d.dh[ps.comp[0]] + 7) / 8)
+                                 : (uint32_t)d.mcus_x * (uint32_t)d.mcus_y;
+    const uint32_t want_iv = ps.restart_interval ? (mcus + ps.restart_interval - 1) / ps.restart_interval : 1;
+    if ((uint32_t)n_iv != want_iv) return 105;
+    iv_byte[n_iv] = (uint32_t)clen;
+    ps.n_iv = n_iv; ps.clean_len = (uint32_t)clen;
+    const int st = jpg::prog_decode_scan(d, ps, clean, iv_byte.data(), prog.tabs.data(), zz, cp);
+    if (st) return 100 + st;
+  }
+  finish_image(d, cp, rgb);
+  return 0;
+}
+
+}  // namespace
+
 // rgb: [height][width][3]; returns 0, a parse reason code, or 100 + the entropy decoder's status.  The SERIAL walk of the scan.
 int jpeg_ref_decode(const uint8_t* data, size_t len, uint8_t* rgb) {
   static jpg::ImageDesc d;                                     // (6 KiB of tables)
   size_t so = 0, sl = 0;
-  const int rc = jpg::parse_jpeg(data, len, &d, &so, &sl);
+  jpg::ProgInfo prog;
+  const int rc = jpg::parse_jpeg(data, len, &d, &so, &sl, &prog);
   if (rc) return rc;
+  if (!prog.scans.empty()) return decode_progressive(data, d, prog, rgb);
   // the entropy-coded segment, 16-byte aligned and padded the way the product's host side pads it
   const size_t padded = (sl + 15) / 16 * 16 + 32;
   std::vector<uint64_t> seg(padded / 8 + 1);
@@ -76,8 +114,10 @@ int jpeg_ref_decode(const uint8_t* data, size_t len, uint8_t* rgb) {
 int jpeg_ref_decode_parallel(const uint8_t* data, size_t len, uint8_t* rgb, int sub_bytes, int max_passes, int* passes) {
   static jpg::ImageDesc d;
   size_t so = 0, sl = 0;
-  const int rc = jpg::parse_jpeg(data, len, &d, &so, &sl);
+  jpg::ProgInfo prog;
+  const int rc = jpg::parse_jpeg(data, len, &d, &so, &sl, &prog);
   if (rc) return rc;
+  if (!prog.scans.empty()) { if (passes) *passes = 0; return decode_progressive(data, d, prog, rgb); }
   std::vector<uint32_t> clean_words((sl + 16) / 4 + 8);
   uint8_t* clean = (uint8_t*)clean_words.data();
   std::vector<uint32_t> iv_byte(sl / 2 + 4);

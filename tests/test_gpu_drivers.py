@@ -72,6 +72,13 @@ def test_embed_predict_dedup_pipeline(gpu, tmp_path):
     for f, old in before.items():
         new = torch.load(os.path.join(root, f), weights_only=True)
         assert all(torch.equal(new[MODEL][c], old[MODEL][c]) for c in CROP_NAMES), f
+    ds4 = embed_driver.Feature_Dataset(root, MODEL, 4, shuffle_filenames=False, num_workers=0, device="cuda", force_reencode=True,
+                                       gpu_decode=True)
+    ds4.gpu_decode_progressive = True                       # ... and with the progressive file decoded on the device too
+    assert ds4.process() == (11, 0, 0)
+    for f, old in before.items():
+        new = torch.load(os.path.join(root, f), weights_only=True)
+        assert all(torch.equal(new[MODEL][c], old[MODEL][c]) for c in CROP_NAMES), f
     for f in ("b_prog.jpg", "b_prog.pt", "b_png.png", "b_png.pt"):
         os.remove(os.path.join(root, f))
 
