@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Developer: the GPU JPEG decoder against Pillow on a large random corpus (sizes 1 .. 1500, every sampling, qualities 1 .. 100,
-optimised / default tables, restart intervals, grey, content from flat to noise); prints mismatches, exits 1 if any."""
+optimised / default tables, restart intervals, grey, content from flat to noise, 30 % of the files progressive); prints mismatches,
+exits 1 if any."""
 import io, os, sys, time
 import numpy as np, torch
 from PIL import Image, ImageFile
@@ -29,6 +30,7 @@ for i in range(n):
     h = rs.randint(1, 1500 if big else 400); w = rs.randint(1, 1500 if big else 400)
     grey = rs.rand() < 0.1
     kw = dict(quality=int(rs.choice([1, 5, 20, 50, 75, 85, 90, 95, 100])), optimize=bool(rs.rand() < 0.3))
+    if rs.rand() < float(os.environ.get("PROGRESSIVE", "0.3")): kw["progressive"] = True
     if not grey: kw["subsampling"] = int(rs.randint(0, 3))
     r = rs.rand()
     if r < 0.15: kw["restart_marker_blocks"] = int(rs.randint(1, 40))
