@@ -2,6 +2,7 @@
 oracle/jpeg_ref.cpp, against Pillow -- the decoder behind /root/reference/utils/embedder.py:167.  Integer algorithms on both
 sides: every pixel must be equal.  (The device run of the same sources is tests/test_gpu_jpeg.py.)"""
 import io
+import struct
 
 import numpy as np
 import pytest
@@ -163,3 +164,95 @@ def test_progressive_files_equal_pillow(subsampling):
     for cut in (len(good) // 3, len(good) // 2, len(good) - 2):
         with pytest.raises(ValueError):
             jpeg_oracle.decode(good[:cut])
+
+
+# ---------------------------------------------------------------------------------------------- files as other encoders write them
+def _segments(data):
+    """[(marker, payload bytes incl. length)] up to and including SOS header; then the rest (entropy data + following) as raw"""
+    out=[]; pos=2
+    while True:
+        assert data[pos]==0xFF
+        m=data[pos+1]; L=struct.unpack('>H',data[pos+2:pos+4])[0]
+        out.append((m,data[pos+2:pos+2+L])); pos+=2+L
+        if m==0xDA: break
+    return out, data[pos:]
+
+def _rebuild(segs, rest):
+    b=bytearray(b'\xff\xd8')
+    for m,p in segs: b+=bytes([0xFF,m])+p
+    return bytes(b)+rest
+
+def _variants(data):
+    segs,rest=_segments(data)
+    # 1. all DHT tables in ONE segment (what cameras write)
+    dht=[p[2:] for m,p in segs if m==0xC4]
+    if len(dht)>1:
+        merged=b''.join(dht); one=(0xC4, struct.pack('>H',len(merged)+2)+merged)
+        s2=[]; done=False
+        for m,p in segs:
+            if m==0xC4:
+                if not done: s2.append(one); done=True
+            else: s2.append((m,p))
+        yield 'merged DHT', _rebuild(s2,rest)
+    # 2. all DQT tables in one segment, as 16-bit entries
+    dqt=[p[2:] for m,p in segs if m==0xDB]
+    tabs=[]
+    for payload in dqt:
+        i=0
+        while i<len(payload):
+            pq,tq=payload[i]>>4,payload[i]&15; n=64*(pq+1); vals=payload[i+1:i+1+n]; i+=1+n
+            v=[vals[k] for k in range(64)] if pq==0 else [struct.unpack('>H',vals[2*k:2*k+2])[0] for k in range(64)]
+            tabs.append((tq,v))
+    body=b''.join(bytes([0x10|tq])+b''.join(struct.pack('>H',x) for x in v) for tq,v in tabs)
+    one=(0xDB, struct.pack('>H',len(body)+2)+body)
+    s2=[]; done=False
+    for m,p in segs:
+        if m==0xDB:
+            if not done: s2.append(one); done=True
+        else: s2.append((m,p))
+    yield '16-bit DQT', _rebuild(s2,rest)
+    # 3. comment + EXIF-like APP1 + APP13 segments in front of and behind the frame header
+    com=(0xFE, struct.pack('>H',2+11)+b'hello world'); app1=(0xE1, struct.pack('>H',2+300)+b'Exif\0\0'+bytes(294)); app13=(0xED, struct.pack('>H',2+40)+bytes(range(40)))
+    s2=[]
+    for m,p in segs:
+        if m in (0xC0,0xC2): s2+=[com,app1]
+        s2.append((m,p))
+        if m in (0xC0,0xC2): s2+=[app13]
+    yield 'COM/APPn', _rebuild(s2,rest)
+    # 4. tables behind the frame header (DQT, DHT after SOF)
+    s2=[x for x in segs if x[0] not in (0xDB,0xC4,0xDA)]+[x for x in segs if x[0] in (0xDB,0xC4)]+[x for x in segs if x[0]==0xDA]
+    yield 'tables after SOF', _rebuild(s2,rest)
+    # 5. fill bytes in front of every marker inside the entropy data / between scans, and in front of EOI
+    r=bytearray(); i=0
+    while i<len(rest):
+        if rest[i]==0xFF and i+1<len(rest) and rest[i+1] not in (0x00,):
+            r+=b'\xff\xff\xff'
+        r.append(rest[i]); 
+        if rest[i]==0xFF and i+1<len(rest) and rest[i+1]==0x00:
+            r.append(0); i+=2; continue
+        i+=1
+    yield 'fill bytes', _rebuild(segs,bytes(r))
+    # 6. no JFIF marker (component ids 1 2 3 decide), 7. trailing bytes
+    yield 'no JFIF', _rebuild([x for x in segs if x[0]!=0xE0],rest)
+    yield 'trailing bytes', data+b'\x00\x01\xff\x00\xffjunk'*3
+
+
+def test_structural_variants_of_the_same_stream_decode_like_pillow():
+    """Pillow writes one layout; cameras and other encoders write others.  Byte-level rewrites of Pillow's files -- all Huffman
+    tables in one DHT segment, 16-bit quantisation tables in one DQT, COM / EXIF-like APP1 / APP13 segments around the frame
+    header, tables behind the frame header, fill bytes in front of every marker of the entropy data, no JFIF marker, bytes
+    behind EOI -- baseline, restart intervals, optimised tables, progressive, colour and grey."""
+    import struct  # noqa: F401  (used by the helpers above)
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (67, 93, 3), dtype=np.uint8)
+    grey = rs.randint(0, 256, (40, 50), dtype=np.uint8)
+    n = 0
+    for kw in (dict(quality=85), dict(quality=85, subsampling=0, restart_marker_blocks=4), dict(quality=60, subsampling=1, optimize=True),
+               dict(quality=85, progressive=True), dict(quality=85, progressive=True, restart_marker_rows=1, subsampling=1)):
+        for arr in (img, grey):
+            data = _jpeg(arr, **kw)
+            for name, v in _variants(data):
+                ref = _pil(v)
+                assert np.array_equal(jpeg_oracle.decode_parallel(v)[0], ref), (name, kw, arr.shape)
+                n += 1
+    assert n >= 60
