@@ -76,6 +76,18 @@ def test_embed_predict_dedup_pipeline(gpu, tmp_path):
                                        gpu_decode=True)
     ds4.gpu_decode_progressive = True                       # ... and with the progressive file decoded on the device too
     assert ds4.process() == (11, 0, 0)
+    # unreadable files are counted and skipped, like the reference's loader does (utils/embedder.py:176-181): an empty file, half a
+    # file (the device flags its entropy data, Pillow then refuses it too), bytes that are no image at all
+    good = open(os.path.join(root, "a005.jpg"), "rb").read()
+    for name, blob in (("c_empty.jpg", b""), ("c_half.jpg", good[: len(good) // 2]), ("c_text.jpg", b"not an image" * 20)):
+        with open(os.path.join(root, name), "wb") as f:
+            f.write(blob)
+    ds5 = embed_driver.Feature_Dataset(root, MODEL, 4, shuffle_filenames=False, num_workers=0, device="cuda", force_reencode=True,
+                                       gpu_decode=True)
+    assert ds5.process() == (11, 0, 3)
+    for name in ("c_empty", "c_half", "c_text"):
+        assert not os.path.exists(os.path.join(root, name + ".pt"))
+        os.remove(os.path.join(root, name + ".jpg"))
     for f, old in before.items():
         new = torch.load(os.path.join(root, f), weights_only=True)
         assert all(torch.equal(new[MODEL][c], old[MODEL][c]) for c in CROP_NAMES), f
