@@ -269,7 +269,7 @@ JPG_HD SubState unpack_state(uint64_t v) { SubState s; s.bit = (uint32_t)v; s.u 
 
 struct ParGeom {
   int ncomp, B, mcus_x;                    // B: blocks ("data units") per MCU
-  int comp_of_u[6], bx_of_u[6], by_of_u[6];
+  int comp_of_u[10], bx_of_u[10], by_of_u[10];   // (T.81: at most 10 blocks per MCU)
   int h[MAX_COMPS], v[MAX_COMPS], bw[MAX_COMPS], dc[MAX_COMPS], ac[MAX_COMPS];
   uint32_t total_du, du_per_interval;      // du_per_interval: restart_interval * B, 0 = one interval
 };
@@ -284,10 +284,10 @@ JPG_HD ParGeom par_geom(const ImageDesc& d) {
     if (c < d.ncomp)
       for (int by = 0; by < g.v[c]; ++by)
         for (int bx = 0; bx < g.h[c]; ++bx)
-          if (u < 6) { g.comp_of_u[u] = c; g.bx_of_u[u] = bx; g.by_of_u[u] = by; ++u; }
+          if (u < 10) { g.comp_of_u[u] = c; g.bx_of_u[u] = bx; g.by_of_u[u] = by; ++u; }
   }
   g.B = u;
-  for (; u < 6; ++u) { g.comp_of_u[u] = 0; g.bx_of_u[u] = 0; g.by_of_u[u] = 0; }
+  for (; u < 10; ++u) { g.comp_of_u[u] = 0; g.bx_of_u[u] = 0; g.by_of_u[u] = 0; }
   g.total_du = (uint32_t)d.mcus_x * (uint32_t)d.mcus_y * (uint32_t)g.B;
   g.du_per_interval = (uint32_t)d.restart_interval * (uint32_t)g.B;
   return g;
@@ -632,22 +632,20 @@ JPG_HD void idct_block(const int16_t* coef, const uint16_t* quant, uint8_t* out,
 
 // ------------------------------------------------------------------------------------------------ upsampling + colour
 // Sample (x, y) of a component at full resolution.  p: the component's plane (pitch bytes per row), dw x dh its real size,
-// (h, v) = (hmax / hs, vmax / vs) its expansion: 1 x 1 is a copy; 2 x 1 and 2 x 2 use the triangle filters of libjpeg
-// ("fancy upsampling": 3/4 + 1/4 horizontally with alternating rounding, 9/16 + 3/16 + 3/16 + 1/16 for 2 x 2; the rows above the
-// first and below the last real row are those rows again) when the plane is more than 2 samples wide, sample replication
-// otherwise -- as libjpeg chooses.
+// (h, v) = (hmax / hs, vmax / vs) its expansion.  As libjpeg chooses its upsampler per component: 1 x 1 is a copy; 2 x 1, 2 x 2
+// and 1 x 2 use triangle filters ("fancy upsampling": 3/4 + 1/4 in one direction with alternating rounding, 9/16 + 3/16 + 3/16 +
+// 1/16 for 2 x 2; the rows above the first and below the last real row are those rows again) -- the two horizontal ones only when
+// the plane is more than 2 samples wide; every other integral expansion replicates samples.
 JPG_HD int upsampled(const uint8_t* p, int pitch, int dw, int dh, int h, int v, int x, int y) {
   if (h == 1 && v == 1) return p[(size_t)y * pitch + x];
-  if (h == 2 && v == 1) {
+  if (h == 2 && v == 1 && dw > 2) {
     const uint8_t* row = p + (size_t)y * pitch;
     const int i = x >> 1;
-    if (dw <= 2) return row[i];
     if (x & 1) return i == dw - 1 ? row[i] : (row[i] * 3 + row[i + 1] + 2) >> 2;
     return i == 0 ? row[0] : (row[i] * 3 + row[i - 1] + 1) >> 2;
   }
-  if (h == 2 && v == 2) {
+  if (h == 2 && v == 2 && dw > 2) {
     const int i = x >> 1, r = y >> 1;
-    if (dw <= 2) return p[(size_t)r * pitch + i];
     int rn = (y & 1) ? r + 1 : r - 1;                          // the nearer neighbouring row
     rn = rn < 0 ? 0 : rn > dh - 1 ? dh - 1 : rn;
     const uint8_t* r0 = p + (size_t)r * pitch;
@@ -656,7 +654,13 @@ JPG_HD int upsampled(const uint8_t* p, int pitch, int dw, int dh, int h, int v, 
     if (x & 1) return i == dw - 1 ? (cur * 4 + 7) >> 4 : (cur * 3 + (r0[i + 1] * 3 + r1[i + 1]) + 7) >> 4;
     return i == 0 ? (cur * 4 + 8) >> 4 : (cur * 3 + (r0[i - 1] * 3 + r1[i - 1]) + 8) >> 4;
   }
-  return -1;                                                   // (the host refuses every other sampling)
+  if (h == 1 && v == 2) {
+    const int r = y >> 1;
+    int rn = (y & 1) ? r + 1 : r - 1;
+    rn = rn < 0 ? 0 : rn > dh - 1 ? dh - 1 : rn;
+    return (p[(size_t)r * pitch + x] * 3 + p[(size_t)rn * pitch + x] + ((y & 1) ? 2 : 1)) >> 2;
+  }
+  return p[(size_t)(y / v) * pitch + x / h];                   // integral replication
 }
 
 JPG_HD uint8_t clamp255(int v) { return (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v); }

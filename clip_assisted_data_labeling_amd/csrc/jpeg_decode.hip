@@ -208,11 +208,10 @@ __global__ __launch_bounds__(256) void jpeg_colour_kernel(const ImageDesc* __res
   if (pix >= (uint32_t)d.width * (uint32_t)d.height) return;
   const int y = (int)(pix / (uint32_t)d.width), x = (int)(pix - (uint32_t)y * d.width);
   uint8_t* o = rgb + d.rgb_off + (size_t)pix * 3;
-  const int Y = arena[d.plane_off[0] + (size_t)y * d.bw[0] * 8 + x];
-  if (d.ncomp == 1) { o[0] = o[1] = o[2] = (uint8_t)Y; return; }
-  const int h = d.hmax / d.hs[1], v = d.vmax / d.vs[1];
-  const int cb = jpg::upsampled(arena + d.plane_off[1], d.bw[1] * 8, d.dw[1], d.dh[1], h, v, x, y);
-  const int cr = jpg::upsampled(arena + d.plane_off[2], d.bw[2] * 8, d.dw[2], d.dh[2], h, v, x, y);
+  if (d.ncomp == 1) { o[0] = o[1] = o[2] = arena[d.plane_off[0] + (size_t)y * d.bw[0] * 8 + x]; return; }
+  const int Y = jpg::upsampled(arena + d.plane_off[0], d.bw[0] * 8, d.dw[0], d.dh[0], d.hmax / d.hs[0], d.vmax / d.vs[0], x, y);
+  const int cb = jpg::upsampled(arena + d.plane_off[1], d.bw[1] * 8, d.dw[1], d.dh[1], d.hmax / d.hs[1], d.vmax / d.vs[1], x, y);
+  const int cr = jpg::upsampled(arena + d.plane_off[2], d.bw[2] * 8, d.dw[2], d.dh[2], d.hmax / d.hs[2], d.vmax / d.vs[2], x, y);
   uint8_t px[3];
   jpg::ycc_to_rgb(Y, cb, cr, px);
   o[0] = px[0]; o[1] = px[1]; o[2] = px[2];

@@ -8,7 +8,7 @@ namespace jpg {
 
 const char* reason_text(int code) {
   static const char* const t[] = {"ok", "not a JPEG file", "progressive / lossless / hierarchical", "sample precision is not 8 bits",
-                                  "neither 1 nor 3 components", "chroma sampling other than 4:4:4, 4:2:2 (2x1), 4:2:0 (2x2)",
+                                  "neither 1 nor 3 components", "sampling factors that do not divide the largest ones",
                                   "more than one scan / non-interleaved", "colour space other than grey or YCbCr", "missing table",
                                   "arithmetic coding", "larger than 16384 x 16384", "truncated", "corrupt header"};
   return code >= 0 && code <= JPG_CORRUPT ? t[code] : "?";
@@ -128,9 +128,17 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
       else if (adobe) ycc = adobe_transform == 1;
       else if (comp_id[0] == 'R' && comp_id[1] == 'G' && comp_id[2] == 'B') ycc = false;
       if (!ycc) return JPG_COLORSPACE;
-      if (d->hs[1] != 1 || d->vs[1] != 1 || d->hs[2] != 1 || d->vs[2] != 1) return JPG_SAMPLING;
-      if (!((d->hs[0] == 1 && d->vs[0] == 1) || (d->hs[0] == 2 && d->vs[0] == 1) || (d->hs[0] == 2 && d->vs[0] == 2))) return JPG_SAMPLING;
-      d->hmax = d->hs[0]; d->vmax = d->vs[0];
+      // any sampling libjpeg upsamples: every component's factors divide the largest ones, at most 10 blocks per MCU
+      d->hmax = d->vmax = 1;
+      int blocks = 0;
+      for (int c = 0; c < 3; ++c) {
+        if (d->hs[c] > d->hmax) d->hmax = d->hs[c];
+        if (d->vs[c] > d->vmax) d->vmax = d->vs[c];
+        blocks += d->hs[c] * d->vs[c];
+      }
+      if (blocks > 10) return JPG_CORRUPT;
+      for (int c = 0; c < 3; ++c)
+        if (d->hmax % d->hs[c] || d->vmax % d->vs[c]) return JPG_SAMPLING;       // (3 into 2 etc.: libjpeg refuses these too)
     } else {
       d->hs[0] = d->vs[0] = 1;                                    // a single-component scan is never interleaved: 8 x 8 "MCUs"
       d->hmax = d->vmax = 1;

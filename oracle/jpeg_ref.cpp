@@ -35,11 +35,10 @@ void finish_image(const jpg::ImageDesc& d, int16_t* const cp[jpg::MAX_COMPS], ui
   for (int y = 0; y < d.height; ++y)
     for (int x = 0; x < d.width; ++x) {
       uint8_t* o = rgb + ((size_t)y * d.width + x) * 3;
-      const int Y = plane[0][(size_t)y * d.bw[0] * 8 + x];
-      if (d.ncomp == 1) { o[0] = o[1] = o[2] = (uint8_t)Y; continue; }
-      const int h = d.hmax / d.hs[1], v = d.vmax / d.vs[1];
-      const int cb = jpg::upsampled(plane[1].data(), d.bw[1] * 8, d.dw[1], d.dh[1], h, v, x, y);
-      const int cr = jpg::upsampled(plane[2].data(), d.bw[2] * 8, d.dw[2], d.dh[2], h, v, x, y);
+      if (d.ncomp == 1) { o[0] = o[1] = o[2] = plane[0][(size_t)y * d.bw[0] * 8 + x]; continue; }
+      const int Y = jpg::upsampled(plane[0].data(), d.bw[0] * 8, d.dw[0], d.dh[0], d.hmax / d.hs[0], d.vmax / d.vs[0], x, y);
+      const int cb = jpg::upsampled(plane[1].data(), d.bw[1] * 8, d.dw[1], d.dh[1], d.hmax / d.hs[1], d.vmax / d.vs[1], x, y);
+      const int cr = jpg::upsampled(plane[2].data(), d.bw[2] * 8, d.dw[2], d.dh[2], d.hmax / d.hs[2], d.vmax / d.vs[2], x, y);
       jpg::ycc_to_rgb(Y, cb, cr, o);
     }
 }

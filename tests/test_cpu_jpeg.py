@@ -256,3 +256,29 @@ def test_structural_variants_of_the_same_stream_decode_like_pillow():
                 assert np.array_equal(jpeg_oracle.decode_parallel(v)[0], ref), (name, kw, arr.shape)
                 n += 1
     assert n >= 60
+
+
+def test_any_sampling_libjpeg_upsamples_equals_pillow():
+    """Streams Pillow cannot be asked to write (tests/jpeg_writer.py entropy-codes random quantised coefficients): 4:4:0 (what a
+    losslessly rotated 4:2:2 photo is), 4:1:1, 1x4, 4x2 and 2x4 luma (ten blocks per MCU), chroma planes sampled differently from
+    each other, luma sampled below chroma, a grey file that declares 2x2 -- with and without restart intervals, zero runs over 16."""
+    from tests.jpeg_writer import random_coefs, tables_from_pillow, write_baseline
+    dqt, dht = tables_from_pillow(80)
+    rs = np.random.RandomState(0)
+    configs = [[(1, 1)] * 3, [(2, 1), (1, 1), (1, 1)], [(2, 2), (1, 1), (1, 1)], [(1, 2), (1, 1), (1, 1)], [(4, 1), (1, 1), (1, 1)],
+               [(1, 4), (1, 1), (1, 1)], [(4, 2), (1, 1), (1, 1)], [(2, 4), (1, 1), (1, 1)], [(2, 2), (2, 1), (1, 1)], [(2, 2), (1, 2), (2, 1)],
+               [(2, 2), (2, 2), (1, 1)], [(1, 1), (2, 2), (2, 2)], [(2, 1), (1, 2), (1, 1)], [(2, 2)], [(1, 1)]]
+    for samp in configs:
+        for (w, h) in [(8, 8), (17, 9), (33, 47), (100, 37), (3, 2)]:
+            for restart in (0, 1, 5):
+                data = write_baseline(w, h, samp, random_coefs(rs, w, h, samp), dqt, dht, restart=restart)
+                ref = _pil(data)
+                assert np.array_equal(jpeg_oracle.decode_parallel(data, 64)[0], ref), (samp, w, h, restart)
+                assert np.array_equal(jpeg_oracle.decode(data), ref), (samp, w, h, restart)
+    # factors that do not divide the largest ones (3 next to 2): libjpeg refuses them, so does the parser
+    bad = write_baseline(32, 32, [(2, 2), (1, 1), (1, 1)], random_coefs(rs, 32, 32, [(2, 2), (1, 1), (1, 1)]), dqt, dht)
+    i = bad.index(b"\xff\xc0")
+    bad = bad[: i + 11] + bytes([0x31]) + bad[i + 12: i + 14] + bytes([0x21]) + bad[i + 15:]      # luma 3x1 next to a 2x1 chroma plane
+    assert jpeg_oracle.info(bad)[0] == 5
+    with pytest.raises(OSError):
+        _pil(bad)

@@ -177,3 +177,22 @@ def test_progressive_files_on_the_device_equal_pillow(gpu):
     for i, (img, data) in enumerate(zip(images, files)):
         assert np.array_equal(img.cpu().numpy(), _pil(data)), i
     dec.close()
+
+
+def test_any_sampling_on_the_device_equals_pillow(gpu):
+    """4:4:0, 4:1:1, ten-block MCUs, unequal chroma planes, luma below chroma (tests/jpeg_writer.py), restart intervals."""
+    from tests.jpeg_writer import random_coefs, tables_from_pillow, write_baseline
+    dqt, dht = tables_from_pillow(80)
+    rs = np.random.RandomState(1)
+    files = []
+    for samp in ([(1, 2), (1, 1), (1, 1)], [(4, 1), (1, 1), (1, 1)], [(1, 4), (1, 1), (1, 1)], [(4, 2), (1, 1), (1, 1)], [(2, 4), (1, 1), (1, 1)],
+                 [(2, 2), (2, 1), (1, 1)], [(2, 2), (1, 2), (2, 1)], [(1, 1), (2, 2), (2, 2)], [(2, 1), (1, 2), (1, 1)], [(2, 2)]):
+        for (w, h) in [(8, 8), (33, 47), (100, 37), (3, 2), (257, 130)]:
+            for restart in (0, 3):
+                files.append(write_baseline(w, h, samp, random_coefs(rs, w, h, samp), dqt, dht, restart=restart))
+    dec = GpuJpegDecoder(gpu)
+    images, status = dec.decode(files)
+    assert status == [0] * len(files)
+    for i, (img, data) in enumerate(zip(images, files)):
+        assert np.array_equal(img.cpu().numpy(), _pil(data)), i
+    dec.close()
