@@ -139,3 +139,78 @@ def random_coefs(rs, width, height, samp):
         a[..., 40 + c] = rs.randint(-3, 4, a.shape[:2]) * far          # behind a run of 28+ zeros: ZRL
         out.append(a)
     return out
+
+
+def write_progressive(width, height, samp, coefs, dqt, dht, restart=0, comp_tq=(0, 1, 1), comp_tabs=((0, 0), (1, 1), (1, 1)), bands=((1, 5), (6, 63))):
+    """The same coefficients as a PROGRESSIVE file by spectral selection only (no successive approximation): one interleaved DC
+    scan, then per component one AC scan per band (every block's band ends with EOB0 unless it is full) -- single-component scans
+    walk the component's REAL blocks, ceil(dw / 8) x ceil(dh / 8), which is where exotic samplings differ from the MCU walk."""
+    nc = len(samp)
+    hmax, vmax = (max(h for h, _ in samp), max(v for _, v in samp)) if nc > 1 else (1, 1)
+    mx, my = -(-width // (8 * hmax)), -(-height // (8 * vmax))
+    out = bytearray(b"\xff\xd8\xff\xe0\x00\x10JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+    for tq in sorted(set(comp_tq[:nc])):
+        out += b"\xff\xdb" + struct.pack(">H", 67) + bytes([tq]) + bytes(dqt[tq])
+    out += b"\xff\xc2" + struct.pack(">HBHHB", 8 + 3 * nc, 8, height, width, nc)
+    for c in range(nc):
+        out += bytes([c + 1, (samp[c][0] << 4) | samp[c][1], comp_tq[c]])
+    for key in sorted({(0, comp_tabs[c][0]) for c in range(nc)} | {(1, comp_tabs[c][1]) for c in range(nc)}):
+        counts, vals = dht[key]
+        out += b"\xff\xc4" + struct.pack(">H", 19 + len(vals)) + bytes([(key[0] << 4) | key[1]]) + bytes(counts) + bytes(vals)
+    if restart:
+        out += b"\xff\xdd\x00\x04" + struct.pack(">H", restart)
+    dc = [_codes(*dht[(0, comp_tabs[c][0])]) for c in range(nc)]
+    ac = [_codes(*dht[(1, comp_tabs[c][1])]) for c in range(nc)]
+
+    def scan(comps, ss, se, units):
+        """units: iterable of lists of (component, block) = the MCUs of the scan in order"""
+        nonlocal out
+        out += b"\xff\xda" + struct.pack(">HB", 6 + 2 * len(comps), len(comps))
+        for c in comps:
+            out += bytes([c + 1, (comp_tabs[c][0] << 4) | comp_tabs[c][1]])
+        out += bytes([ss, se, 0])
+        bits, pred, n, rst = _Bits(), [0] * nc, 0, 0
+        for mcu in units:
+            if restart and n and n % restart == 0:
+                bits.flush(); out += bits.out + bytes([0xFF, 0xD0 + rst]); rst = (rst + 1) & 7
+                bits, pred = _Bits(), [0] * nc
+            n += 1
+            for c, blk in mcu:
+                if ss == 0:
+                    d = int(blk[0]) - pred[c]; pred[c] = int(blk[0])
+                    s_ = _cat(d)
+                    bits.put(*dc[c][s_])
+                    if s_:
+                        bits.put(d if d > 0 else d + (1 << s_) - 1, s_)
+                    continue
+                run = 0
+                last = max([k for k in range(ss, se + 1) if blk[k]] or [ss - 1])
+                for k in range(ss, last + 1):
+                    if blk[k] == 0:
+                        run += 1
+                        continue
+                    while run > 15:
+                        bits.put(*ac[c][0xF0]); run -= 16
+                    s_ = _cat(blk[k])
+                    bits.put(*ac[c][(run << 4) | s_])
+                    vv = int(blk[k])
+                    bits.put(vv if vv > 0 else vv + (1 << s_) - 1, s_)
+                    run = 0
+                if last < se:
+                    bits.put(*ac[c][0x00])
+        bits.flush()
+        out += bits.out
+
+    def mcus():
+        for y in range(my):
+            for x in range(mx):
+                yield [(c, coefs[c][y * (samp[c][1] if nc > 1 else 1) + by][x * (samp[c][0] if nc > 1 else 1) + bx])
+                       for c in range(nc) for by in range(samp[c][1] if nc > 1 else 1) for bx in range(samp[c][0] if nc > 1 else 1)]
+    scan(list(range(nc)), 0, 0, mcus())
+    for c in range(nc):
+        h, v = samp[c] if nc > 1 else (1, 1)
+        dw, dh = -(-width * h // hmax), -(-height * v // vmax)
+        nbx, nby = -(-dw // 8), -(-dh // 8)
+        for (ss, se) in bands:
+            scan([c], ss, se, ([(c, coefs[c][by][bx])] for by in range(nby) for bx in range(nbx)))
+    return bytes(out + b"\xff\xd9")

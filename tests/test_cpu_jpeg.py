@@ -282,3 +282,17 @@ def test_any_sampling_libjpeg_upsamples_equals_pillow():
     assert jpeg_oracle.info(bad)[0] == 5
     with pytest.raises(OSError):
         _pil(bad)
+
+
+def test_progressive_files_with_any_sampling_equal_pillow():
+    """Spectral-selection progressive files from tests/jpeg_writer.py (what a losslessly rotated progressive photo looks like when
+    its sampling becomes 4:4:0): the single-component AC scans walk each component's REAL blocks, not the MCU grid."""
+    from tests.jpeg_writer import random_coefs, tables_from_pillow, write_progressive
+    dqt, dht = tables_from_pillow(80)
+    rs = np.random.RandomState(3)
+    for samp in ([(1, 1)] * 3, [(2, 2), (1, 1), (1, 1)], [(1, 2), (1, 1), (1, 1)], [(4, 1), (1, 1), (1, 1)], [(1, 4), (1, 1), (1, 1)],
+                 [(4, 2), (1, 1), (1, 1)], [(2, 2), (2, 1), (1, 1)], [(2, 2), (1, 2), (2, 1)], [(1, 1), (2, 2), (2, 2)], [(2, 2)]):
+        for (w, h) in [(8, 8), (17, 9), (33, 47), (100, 37), (3, 2)]:
+            for restart in (0, 2):
+                data = write_progressive(w, h, samp, random_coefs(rs, w, h, samp), dqt, dht, restart=restart)
+                assert np.array_equal(jpeg_oracle.decode(data), _pil(data)), (samp, w, h, restart)

@@ -190,6 +190,10 @@ def test_any_sampling_on_the_device_equals_pillow(gpu):
         for (w, h) in [(8, 8), (33, 47), (100, 37), (3, 2), (257, 130)]:
             for restart in (0, 3):
                 files.append(write_baseline(w, h, samp, random_coefs(rs, w, h, samp), dqt, dht, restart=restart))
+    from tests.jpeg_writer import write_progressive
+    for samp in ([(1, 2), (1, 1), (1, 1)], [(4, 1), (1, 1), (1, 1)], [(2, 2), (1, 2), (2, 1)], [(2, 2)]):          # ... and progressive ones
+        for (w, h) in [(33, 47), (100, 37)]:
+            files.append(write_progressive(w, h, samp, random_coefs(rs, w, h, samp), dqt, dht, restart=2 * (w > 50)))
     dec = GpuJpegDecoder(gpu)
     images, status = dec.decode(files)
     assert status == [0] * len(files)
