@@ -418,6 +418,7 @@ struct ProgScan {
   int32_t ncomp, comp[MAX_COMPS];
   int32_t ss, se, ah, al;
   int32_t dc_tab[MAX_COMPS], ac_tab;     // indices into the image's table array (ProgDesc::tabs_off)
+  int32_t ac_tab3[MAX_COMPS];            // full-band scans of a sequential file: an AC table per component of the scan
   int32_t restart_interval;              // MCUs of THIS scan between restart markers, 0 = none
   int32_t n_iv;
   uint64_t clean_off;                    // the scan's unstuffed data (4-byte aligned, 16 bytes of 0xFF behind it)
@@ -449,6 +450,31 @@ JPG_HD int pb_huff(PBits& b, const HuffTable& t) {            // one symbol, -1 
   if (len > 16) return -1;
   b.bit += (uint32_t)len;
   return t.huffval[((c16 >> (16 - len)) + t.valoffset[len]) & 0xff];
+}
+
+// a whole block of a SEQUENTIAL scan (a sequential file whose components come in several scans): DC difference, then AC run / size
+// pairs up to EOB -- what decode_block does on the stuffed stream
+JPG_HD bool seq_block(PBits& b, const HuffTable& dc, const HuffTable& ac, const uint8_t* zz, int& pred, int16_t* blk) {
+  int s = pb_huff(b, dc);
+  if (s < 0 || s > 11) return false;
+  if (s) pred += extend(pb_get(b, s), s);
+  blk[0] = (int16_t)pred;
+  for (int k = 1; k < 64;) {
+    const int rs = pb_huff(b, ac);
+    if (rs < 0) return false;
+    const int r = rs >> 4;
+    s = rs & 15;
+    if (s == 0) {
+      if (r != 15) break;
+      k += 16;
+      continue;
+    }
+    k += r;
+    if (k > 63) return false;
+    blk[zz[k]] = (int16_t)extend(pb_get(b, s), s);
+    ++k;
+  }
+  return true;
 }
 
 JPG_HD bool prog_dc_first(PBits& b, const HuffTable& t, int& pred, int16_t* blk, int al) {
@@ -555,7 +581,9 @@ JPG_HD int prog_decode_scan(const ImageDesc& d, const ProgScan& sc, const uint8_
           for (int bx = 0; bx < h; ++bx) {
             int16_t* blk = coef[c] + ((size_t)(my * v + by) * d.bw[c] + (mx * h + bx)) * 64;
             bool ok = true;
-            if (sc.ss == 0) {
+            if (sc.ss == 0 && sc.se == 63) {
+              ok = seq_block(b, tabs[sc.dc_tab[ci]], tabs[sc.ac_tab3[ci]], zz, pred[ci], blk);
+            } else if (sc.ss == 0) {
               if (sc.ah == 0) ok = prog_dc_first(b, tabs[sc.dc_tab[ci]], pred[ci], blk, sc.al);
               else prog_dc_refine(b, blk, sc.al);
             } else if (sc.ah == 0) {

@@ -138,8 +138,8 @@ __global__ __launch_bounds__(ENT_THREADS) void jpeg_entropy_kernel(const ImageDe
 // correction bits make a scan serial); the tables of the current scan are in LDS.  The parallelism is across the images of the batch.
 __global__ __launch_bounds__(64) void jpeg_entropy_prog_kernel(const ImageDesc* __restrict__ descs, int* __restrict__ status,
                                                                uint8_t* __restrict__ arena) {
-  __shared__ jpg::HuffTable tabs[4];                           // DC tables of the scan's components, [3] = its AC table
-  __shared__ uint8_t zz[64];
+  __shared__ jpg::HuffTable tabs[7];                           // [0..2] DC tables of the scan's components, [3] its AC table (progressive),
+  __shared__ uint8_t zz[64];                                   // [4..6] AC tables per component (full-band scans of a sequential file)
   const ImageDesc& d = descs[blockIdx.x];
   if (!d.prog_off) return;
   const jpg::ProgDesc& pd = *(const jpg::ProgDesc*)(arena + d.prog_off);
@@ -152,8 +152,12 @@ __global__ __launch_bounds__(64) void jpeg_entropy_prog_kernel(const ImageDesc* 
   for (int si = 0; si < pd.n_scans; ++si) {
     const jpg::ProgScan& ps = pd.scans[si];
     __syncthreads();                                             // lane 0 is done with the previous scan's tables
-    for (int slot = 0; slot < 4; ++slot) {
-      const int src_i = slot < 3 ? (slot < ps.ncomp && ps.ss == 0 && ps.ah == 0 ? ps.dc_tab[slot] : -1) : (ps.ss > 0 ? ps.ac_tab : -1);
+    const bool full_band = ps.ss == 0 && ps.se == 63;            // a scan of a sequential file: DC and AC table per component
+    for (int slot = 0; slot < 7; ++slot) {
+      int src_i = -1;
+      if (slot < 3) { if (slot < ps.ncomp && ps.ss == 0 && ps.ah == 0) src_i = ps.dc_tab[slot]; }
+      else if (slot == 3) { if (ps.ss > 0) src_i = ps.ac_tab; }
+      else if (full_band && slot - 4 < ps.ncomp) src_i = ps.ac_tab3[slot - 4];
       if (src_i < 0) continue;
       const uint32_t* src = (const uint32_t*)(all + src_i);
       uint32_t* dst = (uint32_t*)(tabs + slot);
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(64) void jpeg_entropy_prog_kernel(const ImageDesc* 
       else {
         jpg::ProgScan local = ps;
         local.dc_tab[0] = 0; local.dc_tab[1] = 1; local.dc_tab[2] = 2; local.ac_tab = 3;
+        local.ac_tab3[0] = 4; local.ac_tab3[1] = 5; local.ac_tab3[2] = 6;
         st = jpg::prog_decode_scan(d, local, arena + ps.clean_off, (const uint32_t*)(arena + ps.iv_off), tabs, zz, coef);
       }
     }

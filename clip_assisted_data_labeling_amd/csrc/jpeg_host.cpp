@@ -9,7 +9,7 @@ namespace jpg {
 const char* reason_text(int code) {
   static const char* const t[] = {"ok", "not a JPEG file", "progressive / lossless / hierarchical", "sample precision is not 8 bits",
                                   "neither 1 nor 3 components", "sampling factors that do not divide the largest ones",
-                                  "more than one scan / non-interleaved", "colour space other than grey or YCbCr", "missing table",
+                                  "scan components out of frame order", "colour space other than grey or YCbCr", "missing table",
                                   "arithmetic coding", "larger than 16384 x 16384", "truncated", "corrupt header"};
   return code >= 0 && code <= JPG_CORRUPT ? t[code] : "?";
 }
@@ -113,7 +113,7 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
   uint16_t qt[4][64];
   bool have_qt[4] = {false, false, false, false}, have_ht[4] = {false, false, false, false};
   int comp_id[MAX_COMPS] = {0, 0, 0}, comp_tq[MAX_COMPS] = {0, 0, 0};
-  bool have_sof = false, jfif = false, adobe = false, progressive = false, frame_done = false;
+  bool have_sof = false, jfif = false, adobe = false, progressive = false, multi = false, frame_done = false;
   int adobe_transform = -1;
   int cur_tab[4] = {-1, -1, -1, -1};                              // progressive: index in prog->tabs of DC 0, DC 1, AC 0, AC 1
   int last_al[MAX_COMPS][64];                                     // progressive: -1 = coefficient not coded yet, else the bit it is refined down to
@@ -164,7 +164,7 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
     const int m = data[pos++];
     if (m == 0xD8 || m == 0x01 || (m >= 0xD0 && m <= 0xD7)) continue;
     if (m == 0xD9) {                                              // EOI
-      if (!progressive || !prog || prog->scans.empty()) return JPG_TRUNCATED;     // before any scan
+      if (!(progressive || multi) || !prog || prog->scans.empty()) return JPG_TRUNCATED;     // before any scan
       for (int c = 0; c < d->ncomp; ++c)
         for (int k = 0; k < 64; ++k)
           if (last_al[c][k] != 0) return JPG_PROGRESSIVE;         // an unfinished progression (Pillow would smooth it)
@@ -244,8 +244,7 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
       if (!frame_done)
         if (const int rc = finish_frame()) return rc;
       const uint8_t* e = s + 1 + 2 * ns;
-      if (!progressive) {
-        if (ns != d->ncomp) return JPG_MULTI_SCAN;
+      if (!progressive && ns == d->ncomp) {
         for (int c = 0; c < d->ncomp; ++c) {
           if (s[1 + 2 * c] != comp_id[c]) return JPG_MULTI_SCAN;   // (components in frame order)
           const int td = s[2 + 2 * c] >> 4, ta = s[2 + 2 * c] & 15;
@@ -258,7 +257,9 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
         *scan_len = len - *scan_off;
         return JPG_OK;
       }
-      // ---- a scan of a progressive file
+      // ---- a scan of a progressive file, or of a sequential file whose components come in several scans (full band each)
+      if (!prog) return JPG_MULTI_SCAN;
+      multi = true;
       if (prog->scans.size() >= MAX_SCANS) return JPG_PROGRESSIVE;
       ProgScanInfo si;
       memset(&si, 0, sizeof si);
@@ -276,11 +277,12 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
         const int td = s[2 + 2 * i] >> 4, ta = s[2 + 2 * i] & 15;
         if (td > 1 || ta > 1) return JPG_TABLES;
         if (ps.ss == 0 && ps.ah == 0) { if (cur_tab[td] < 0) return JPG_TABLES; ps.dc_tab[i] = cur_tab[td]; }
-        if (ps.ss > 0) { if (cur_tab[2 + ta] < 0) return JPG_TABLES; ps.ac_tab = cur_tab[2 + ta]; }
+        if (ps.se > 0) { if (cur_tab[2 + ta] < 0) return JPG_TABLES; ps.ac_tab = cur_tab[2 + ta]; ps.ac_tab3[i] = cur_tab[2 + ta]; }
       }
+      if (!progressive && !(ps.ss == 0 && ps.se == 63 && ps.ah == 0 && ps.al == 0)) return JPG_CORRUPT;   // sequential: full band, full precision
       // the scan must be a legal step of an orderly progression (T.81 G.1.1.1.1): DC scans cover coefficient 0 only and may
       // interleave components, AC scans cover one component; first pass Ah = 0, every later pass refines exactly the next bit
-      if (ps.ss > ps.se || ps.se > 63 || ps.al > 13 || (ps.ss == 0 && ps.se != 0) || (ps.ss > 0 && ns != 1)) return JPG_CORRUPT;
+      if (ps.ss > ps.se || ps.se > 63 || ps.al > 13 || (progressive && ps.ss == 0 && ps.se != 0) || (ps.ss > 0 && ns != 1)) return JPG_CORRUPT;
       if (ps.ah != 0 && ps.al != ps.ah - 1) return JPG_CORRUPT;
       for (int i = 0; i < ns; ++i)
         for (int k = ps.ss; k <= ps.se; ++k) {

@@ -1,6 +1,6 @@
 // Host side of the JPEG decoder: marker parsing and table preparation (no device code; also compiled into the CPU checker
-// the tests' jpeg_ref.cpp).  Supported: baseline / extended-sequential Huffman JPEG with one interleaved scan and
-// progressive Huffman JPEG, 8 bits, greyscale or YCbCr with any sampling libjpeg upsamples (4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, ...),
+// the tests' jpeg_ref.cpp).  Supported: baseline / extended-sequential Huffman JPEG (one interleaved scan, or the
+// components in several full-band scans) and progressive Huffman JPEG, 8 bits, greyscale or YCbCr with any sampling libjpeg upsamples (4:4:4, 4:2:2, 4:2:0, 4:4:0, 4:1:1, ...),
 // restart intervals.  Everything else is reported with a reason code and
 // left to the caller (the embed driver hands such files to Pillow).
 #pragma once

@@ -248,8 +248,8 @@ int clipenc_mfma_stream_probe(int device, int fp8, const void* operands_dev, flo
 /* ---- JPEG files -> RGB on the device: the decode step of the reference's image loader
  * (/root/reference/utils/embedder.py:167, PIL.Image.open(path).convert('RGB')), bit-identical to Pillow's libjpeg-turbo defaults
  * (integer "islow" inverse DCT, triangle-filter chroma upsampling, JFIF colour conversion).  Decodable here: baseline and
- * extended-sequential Huffman JPEG with one interleaved scan, and progressive Huffman JPEG whose scans form a complete, orderly
- * progression; 8 bits, greyscale or YCbCr with any sampling whose factors divide the largest ones (4:4:4, 4:2:2, 4:2:0, 4:4:0,
+ * extended-sequential Huffman JPEG (one interleaved scan, or the components in several scans), and progressive Huffman JPEG
+ * whose scans form a complete, orderly progression; 8 bits, greyscale or YCbCr with any sampling whose factors divide the largest ones (4:4:4, 4:2:2, 4:2:0, 4:4:0,
  * 4:1:1, ...), restart intervals.  Anything else gets a reason code
  * from jpegdec_plan and is left to the caller (the embed driver gives such files to Pillow).  One batch at a time per handle: plan (host only), then run. */
 typedef struct jpegdec_s* jpegdec_t;

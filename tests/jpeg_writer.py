@@ -214,3 +214,67 @@ def write_progressive(width, height, samp, coefs, dqt, dht, restart=0, comp_tq=(
         for (ss, se) in bands:
             scan([c], ss, se, ([(c, coefs[c][by][bx])] for by in range(nby) for bx in range(nbx)))
     return bytes(out + b"\xff\xd9")
+
+
+def write_sequential_scans(width, height, samp, coefs, dqt, dht, scans, restart=0, comp_tq=(0, 1, 1), comp_tabs=((0, 0), (1, 1), (1, 1))):
+    """A SEQUENTIAL (SOF0) file whose components come in several scans, e.g. scans = [[0], [1], [2]] or [[0], [1, 2]]: every scan
+    codes the full band of its components; one component alone walks its real blocks, several are interleaved MCU by MCU."""
+    nc = len(samp)
+    hmax, vmax = max(h for h, _ in samp), max(v for _, v in samp)
+    mx, my = -(-width // (8 * hmax)), -(-height // (8 * vmax))
+    out = bytearray(b"\xff\xd8\xff\xe0\x00\x10JFIF\x00\x01\x01\x00\x00\x01\x00\x01\x00\x00")
+    for tq in sorted(set(comp_tq[:nc])):
+        out += b"\xff\xdb" + struct.pack(">H", 67) + bytes([tq]) + bytes(dqt[tq])
+    out += b"\xff\xc0" + struct.pack(">HBHHB", 8 + 3 * nc, 8, height, width, nc)
+    for c in range(nc):
+        out += bytes([c + 1, (samp[c][0] << 4) | samp[c][1], comp_tq[c]])
+    for key in sorted({(0, comp_tabs[c][0]) for c in range(nc)} | {(1, comp_tabs[c][1]) for c in range(nc)}):
+        counts, vals = dht[key]
+        out += b"\xff\xc4" + struct.pack(">H", 19 + len(vals)) + bytes([(key[0] << 4) | key[1]]) + bytes(counts) + bytes(vals)
+    if restart:
+        out += b"\xff\xdd\x00\x04" + struct.pack(">H", restart)
+    dc = [_codes(*dht[(0, comp_tabs[c][0])]) for c in range(nc)]
+    ac = [_codes(*dht[(1, comp_tabs[c][1])]) for c in range(nc)]
+    for comps in scans:
+        out += b"\xff\xda" + struct.pack(">HB", 6 + 2 * len(comps), len(comps))
+        for c in comps:
+            out += bytes([c + 1, (comp_tabs[c][0] << 4) | comp_tabs[c][1]])
+        out += b"\x00\x3f\x00"
+        if len(comps) == 1:
+            c = comps[0]
+            h, v = samp[c]
+            dw, dh = -(-width * h // hmax), -(-height * v // vmax)
+            units = ([(c, coefs[c][by][bx])] for by in range(-(-dh // 8)) for bx in range(-(-dw // 8)))
+        else:
+            units = ([(c, coefs[c][y * samp[c][1] + by][x * samp[c][0] + bx]) for c in comps for by in range(samp[c][1]) for bx in range(samp[c][0])]
+                     for y in range(my) for x in range(mx))
+        bits, pred, n, rst = _Bits(), [0] * nc, 0, 0
+        for mcu in units:
+            if restart and n and n % restart == 0:
+                bits.flush(); out += bits.out + bytes([0xFF, 0xD0 + rst]); rst = (rst + 1) & 7
+                bits, pred = _Bits(), [0] * nc
+            n += 1
+            for c, blk in mcu:
+                d = int(blk[0]) - pred[c]; pred[c] = int(blk[0])
+                s_ = _cat(d)
+                bits.put(*dc[c][s_])
+                if s_:
+                    bits.put(d if d > 0 else d + (1 << s_) - 1, s_)
+                run = 0
+                last = max([k for k in range(1, 64) if blk[k]] or [0])
+                for k in range(1, last + 1):
+                    if blk[k] == 0:
+                        run += 1
+                        continue
+                    while run > 15:
+                        bits.put(*ac[c][0xF0]); run -= 16
+                    s_ = _cat(blk[k])
+                    bits.put(*ac[c][(run << 4) | s_])
+                    vv = int(blk[k])
+                    bits.put(vv if vv > 0 else vv + (1 << s_) - 1, s_)
+                    run = 0
+                if last < 63:
+                    bits.put(*ac[c][0x00])
+        bits.flush()
+        out += bits.out
+    return bytes(out + b"\xff\xd9")

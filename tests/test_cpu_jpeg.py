@@ -296,3 +296,20 @@ def test_progressive_files_with_any_sampling_equal_pillow():
             for restart in (0, 2):
                 data = write_progressive(w, h, samp, random_coefs(rs, w, h, samp), dqt, dht, restart=restart)
                 assert np.array_equal(jpeg_oracle.decode(data), _pil(data)), (samp, w, h, restart)
+
+
+def test_sequential_files_in_several_scans_equal_pillow():
+    """A sequential (SOF0) file may bring its components in several scans -- one each, or one alone and two interleaved; the decoder
+    walks them with the machinery of the progressive files (tests/jpeg_writer.py writes them, Pillow gives the expected pixels)."""
+    from tests.jpeg_writer import random_coefs, tables_from_pillow, write_sequential_scans
+    dqt, dht = tables_from_pillow(80)
+    rs = np.random.RandomState(4)
+    for samp in ([(1, 1)] * 3, [(2, 2), (1, 1), (1, 1)], [(2, 1), (1, 1), (1, 1)], [(1, 2), (1, 1), (1, 1)], [(2, 2), (1, 2), (2, 1)]):
+        for scans in ([[0], [1], [2]], [[0], [1, 2]], [[0, 1], [2]]):
+            for (w, h) in [(8, 8), (17, 9), (33, 47), (100, 37), (3, 2)]:
+                for restart in (0, 3):
+                    data = write_sequential_scans(w, h, samp, random_coefs(rs, w, h, samp), dqt, dht, scans, restart=restart)
+                    assert np.array_equal(jpeg_oracle.decode(data), _pil(data)), (samp, scans, w, h, restart)
+    # a component that never arrives: refused (Pillow decodes what is there and leaves the rest grey)
+    data = write_sequential_scans(33, 47, [(1, 1)] * 3, random_coefs(rs, 33, 47, [(1, 1)] * 3), dqt, dht, [[0], [1]])
+    assert jpeg_oracle.info(data)[0] != 0

@@ -194,6 +194,10 @@ def test_any_sampling_on_the_device_equals_pillow(gpu):
     for samp in ([(1, 2), (1, 1), (1, 1)], [(4, 1), (1, 1), (1, 1)], [(2, 2), (1, 2), (2, 1)], [(2, 2)]):          # ... and progressive ones
         for (w, h) in [(33, 47), (100, 37)]:
             files.append(write_progressive(w, h, samp, random_coefs(rs, w, h, samp), dqt, dht, restart=2 * (w > 50)))
+    from tests.jpeg_writer import write_sequential_scans
+    for samp in ([(2, 2), (1, 1), (1, 1)], [(1, 2), (1, 1), (1, 1)]):                                                # ... sequential files in several scans
+        for scans in ([[0], [1], [2]], [[0], [1, 2]]):
+            files.append(write_sequential_scans(100, 37, samp, random_coefs(rs, 100, 37, samp), dqt, dht, scans, restart=3))
     dec = GpuJpegDecoder(gpu)
     images, status = dec.decode(files)
     assert status == [0] * len(files)
