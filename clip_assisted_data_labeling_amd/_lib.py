@@ -111,6 +111,7 @@ DIAG_SIGNATURES = {
                                        c_void_p, c_void_p, c_void_p]),
     "clipenc_op_gemm_nt_stamps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "clipenc_op_gemm_resid": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "clipenc_diag_fp8_stamps": (c_int, [c_void_p]),
 }
 
 _lib = None

@@ -1084,6 +1084,14 @@ int clipenc_op_quant_rows_fp8(const void* in_dev, int in_f32, int n_rows, int k,
   return 0;
 }
 
+#ifdef CLIPENC_DIAG
+static unsigned long long* g_fp8_stamps = nullptr;   // diagnostic library: [tiles][8] stamps of the next fp8 GEMM ops (tools/gemm_fp8_stamps.py)
+int clipenc_diag_fp8_stamps(unsigned long long* stamps_dev) { g_fp8_stamps = stamps_dev; return 0; }
+#define FP8_DBG(p) (p).dbg = g_fp8_stamps
+#else
+#define FP8_DBG(p) ((void)0)
+#endif
+
 int clipenc_op_gemm_fp8(const void* a8_dev, const void* w8_dev, int m, int n, int k, const float* scale_a_dev,
                         const float* scale_w_dev, const float* bias_dev, int act, const void* resid_dev, void* out_dev,
                         void* stream) {
@@ -1091,6 +1099,7 @@ int clipenc_op_gemm_fp8(const void* a8_dev, const void* w8_dev, int m, int n, in
   GemmParams p{};
   p.A = a8_dev; p.lda = k; p.W = w8_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out_dev; p.ldo = n; p.bias = bias_dev;
   p.scale_a = scale_a_dev; p.scale_w = scale_w_dev; p.act = act; p.resid = resid_dev;
+  FP8_DBG(p);
   hipError_t err = ce_gemm_fp8(p, resid_dev ? EPI_RESID : EPI_STORE_BF16, (hipStream_t)stream);
   if (err != hipSuccess) return fail("gemm_fp8(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
   return 0;
@@ -1102,6 +1111,7 @@ int clipenc_op_gemm_fp8_q(const void* a8_dev, const void* w8_dev, int m, int n, 
   GemmParams p{};
   p.A = a8_dev; p.lda = k; p.W = w8_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out8_dev; p.ldo = n; p.bias = bias_dev;
   p.scale_a = scale_a_dev; p.scale_w = scale_w_dev; p.act = act; p.out_inv_scale = out_inv_scale_dev;
+  FP8_DBG(p);
   hipError_t err = ce_gemm_fp8(p, EPI_STORE_FP8, (hipStream_t)stream);
   if (err != hipSuccess) return fail("gemm_fp8_q(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
   return 0;
@@ -1131,6 +1141,7 @@ int clipenc_op_gemm_fp8_lnf(const void* a8_dev, const void* exp_dev, const void*
   p.A = a8_dev; p.lda = k; p.W = w8_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out_dev; p.ldo = n; p.bias = bias_dev;
   p.scale_w = scale_w_dev; p.colsum = colsum_dev; p.act = act; p.out_inv_scale = out_inv_scale_dev;
   p.a_exp = (const unsigned char*)exp_dev; p.ld_aexp = 4; p.row_r = row_r_dev; p.row_d = row_d_dev; p.ld_row = 1;
+  FP8_DBG(p);
   hipError_t err = ce_gemm_fp8(p, out_inv_scale_dev ? EPI_STORE_FP8 : EPI_STORE_BF16, (hipStream_t)stream);
   if (err != hipSuccess) return fail("gemm_fp8_lnf(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
   return 0;
@@ -1143,6 +1154,7 @@ int clipenc_op_gemm_fp8_resid_q(const void* a8_dev, const void* w8_dev, int m, i
   p.A = a8_dev; p.lda = k; p.W = w8_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = x_inout_dev; p.ldo = n; p.bias = bias_dev;
   p.scale_w = scale_w_dev; p.act = -1; p.resid = x_inout_dev;
   p.out8 = out8_dev; p.ld8 = n; p.out_exp = (unsigned char*)exp_dev; p.ld_oexp = 4; p.stats_out = stats_dev; p.stats_ld = stats_ld;
+  FP8_DBG(p);
   hipError_t err = ce_gemm_fp8(p, EPI_RESID_Q, (hipStream_t)stream);
   if (err != hipSuccess) return fail("gemm_fp8_resid_q(%d,%d,%d) failed: %s", m, n, k, hipGetErrorString(err));
   return 0;

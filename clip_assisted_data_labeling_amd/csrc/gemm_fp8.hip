@@ -299,6 +299,9 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
         }
       }
     }
+#ifdef CLIPENC_DIAG
+    if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 4] = __builtin_amdgcn_s_memtime(); }
+#endif
     if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
 
     constexpr bool ZERO_C = ZERO_C_OK;
@@ -360,6 +363,9 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(acc[i][j]));
     if (wr == 0) BARRIER();                  // re-align the two wave rows for the epilogue
+#ifdef CLIPENC_DIAG
+    if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 2] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 5] = __builtin_amdgcn_s_memtime(); }
+#endif
 
     // ------------------------------- epilogue of tile `cur` -------------------------------
     // lane (r32, h) of m-tile mt holds row mw0 + mt*32 + r32, columns nb + nt*32 + 8g + 4h + (0..3) in acc[mt][nt][4g..4g+3]
@@ -611,11 +617,17 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       }
     }
 
+#ifdef CLIPENC_DIAG
+    if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 3] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 0] = blockIdx.x; }
+#endif
     if (!has_next) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant DMA before the LDS is released
       break;
     }
     relax = (cur.m0 + BM <= p.M) ? 2 : 0;    // all 256 rows valid: every guarded row store above was issued; the first two waits
+#ifdef CLIPENC_DIAG
+    if (p.dbg) relax = 0;                    // (the stamps add stores: no relaxed waits then)
+#endif
     idx = nidx; cur = nxt; Ablk = Anext; Wblk = Wnext;
   }
 }
