@@ -10,7 +10,7 @@ const char* reason_text(int code) {
   static const char* const t[] = {"ok", "not a JPEG file", "progressive / lossless / hierarchical", "sample precision is not 8 bits",
                                   "neither 1 nor 3 components", "sampling factors that do not divide the largest ones",
                                   "scan components out of frame order", "colour space other than grey or YCbCr", "missing table",
-                                  "arithmetic coding", "larger than 16384 x 16384", "truncated", "corrupt header"};
+                                  "arithmetic coding", "larger than 16384 per side or 178 956 970 pixels", "truncated", "corrupt header"};
   return code >= 0 && code <= JPG_CORRUPT ? t[code] : "?";
 }
 
@@ -220,7 +220,9 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
       if (s[0] != 8) return JPG_PRECISION;
       d->height = be16(s + 1); d->width = be16(s + 3); d->ncomp = s[5];
       if (d->width < 1 || d->height < 1) return JPG_CORRUPT;     // (height 0 = DNL marker: not supported)
-      if (d->width > 16384 || d->height > 16384) return JPG_TOO_LARGE;
+      // 16384 per side, and Pillow's decompression-bomb limit (2 x Image.MAX_IMAGE_PIXELS): Pillow raises on such a file, so it is
+      // left to the caller's Pillow path to do so -- and a few header bytes cannot make the planner reserve gigabytes
+      if (d->width > 16384 || d->height > 16384 || (uint64_t)d->width * (uint64_t)d->height > 178956970ull) return JPG_TOO_LARGE;
       if (d->ncomp != 1 && d->ncomp != 3) return JPG_COMPONENTS;
       if (n != 6 + 3 * d->ncomp) return JPG_CORRUPT;
       for (int c = 0; c < d->ncomp; ++c) {

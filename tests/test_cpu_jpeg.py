@@ -313,3 +313,14 @@ def test_sequential_files_in_several_scans_equal_pillow():
     # a component that never arrives: refused (Pillow decodes what is there and leaves the rest grey)
     data = write_sequential_scans(33, 47, [(1, 1)] * 3, random_coefs(rs, 33, 47, [(1, 1)] * 3), dqt, dht, [[0], [1]])
     assert jpeg_oracle.info(data)[0] != 0
+
+
+def test_header_claiming_a_huge_image_is_refused():
+    """Pillow raises DecompressionBombError above 2 x MAX_IMAGE_PIXELS; the decoder hands such files back (reason 10) instead of
+    planning gigabytes of scratch for a few header bytes."""
+    data = bytearray(_jpeg(np.zeros((16, 16, 3), np.uint8), quality=80))
+    i = data.index(b"\xff\xc0")
+    data[i + 5:i + 9] = bytes([0x3c, 0x00, 0x3c, 0x00])            # 15360 x 15360 = 236 M pixels
+    assert jpeg_oracle.info(bytes(data))[0] == 10
+    data[i + 5:i + 9] = bytes([0x30, 0x00, 0x30, 0x00])            # 12288 x 12288 = 151 M pixels: parsed (and then found truncated)
+    assert jpeg_oracle.info(bytes(data))[0] == 0
