@@ -57,6 +57,9 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p]),
     "dedup_find_pairs": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                  c_ulonglong, c_void_p, c_void_p]),
+    "dedup_screen_ws_bytes": (c_size_t, [c_int, c_int, ctypes.c_ulonglong]),
+    "dedup_find_pairs_screened": (c_int, [c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_size_t, ctypes.c_ulonglong, c_void_p,
+                                          c_void_p, ctypes.c_ulonglong, c_void_p, c_void_p]),
     "dedup_tile_order": (c_int, [c_int, c_int, POINTER(ctypes.c_uint), c_long]),
     "preproc_create": (c_int, [c_int, POINTER(c_void_p)]),
     "preproc_destroy": (c_int, [c_void_p]),

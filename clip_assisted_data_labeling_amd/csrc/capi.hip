@@ -968,6 +968,48 @@ int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int
   return 0;
 }
 
+namespace {
+struct ScreenWs { size_t q8, margin, cand, total; int ld8; unsigned long long cand_cap; };
+// layout of the screened search's scratch: [0, 256) the candidate counter | e4m3 rows | margins | candidate slots
+ScreenWs screen_ws_layout(int n, int d, unsigned long long cand_cap) {
+  const size_t n_pad = ((size_t)n + 255) / 256 * 256;
+  const int ld = (d + 127) / 128 * 128, ld8 = std::max(512, (ld + 255) / 256 * 256);   // (the fp8 pipeline wants two stage pairs)
+  ScreenWs w{};
+  w.ld8 = ld8; w.cand_cap = cand_cap;
+  w.q8 = 256;
+  w.margin = w.q8 + n_pad * (size_t)ld8;
+  w.cand = (w.margin + n_pad * sizeof(float) + 255) / 256 * 256;
+  w.total = w.cand + (size_t)cand_cap * 8;
+  return w;
+}
+}  // namespace
+
+size_t dedup_screen_ws_bytes(int n, int d, unsigned long long candidate_capacity) {
+  if (n < 0 || d < 1) return 0;
+  return screen_ws_layout(n, d, candidate_capacity).total;
+}
+
+int dedup_find_pairs_screened(const void* emb_f16_dev, int n, int d, float threshold, int fp16_compare, void* ehat_ws_dev,
+                              void* screen_ws_dev, size_t screen_ws_bytes, unsigned long long candidate_capacity, long long* pairs_dev,
+                              float* vals_dev, unsigned long long capacity, unsigned long long* count_dev, void* stream) {
+  if (n < 0 || d < 1) return fail("dedup_find_pairs_screened: bad shape n=%d d=%d", n, d);
+  if (!count_dev) return fail("dedup_find_pairs_screened: count_dev is NULL");
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), st));
+  if (n < 2) return 0;
+  if (!emb_f16_dev || !ehat_ws_dev || !screen_ws_dev || (capacity && (!pairs_dev || !vals_dev))) return fail("dedup_find_pairs_screened: NULL device pointer");
+  if (candidate_capacity < 1) return fail("dedup_find_pairs_screened: candidate_capacity must be at least 1");
+  const ScreenWs w = screen_ws_layout(n, d, candidate_capacity);
+  if (screen_ws_bytes < w.total) return fail("dedup_find_pairs_screened: screen_ws_bytes %zu < %zu (dedup_screen_ws_bytes)", screen_ws_bytes, w.total);
+  if ((uintptr_t)screen_ws_dev & 255) return fail("dedup_find_pairs_screened: screen_ws_dev must be 256-byte aligned");
+  const int ld = (d + 127) / 128 * 128;
+  char* ws = (char*)screen_ws_dev;
+  HIP_TRY(ce_dedup_normalize_f16(emb_f16_dev, ehat_ws_dev, n, d, ld, st));
+  HIP_TRY(ce_dedup_pairs_screened(ehat_ws_dev, n, ld, threshold, fp16_compare, ws + w.q8, (float*)(ws + w.margin), ws + w.cand,
+                                  candidate_capacity, (unsigned long long*)ws, pairs_dev, vals_dev, capacity, count_dev, st));
+  return 0;
+}
+
 int dedup_tile_order(int tiles_per_side, int grid, unsigned* order_out, long capacity) {
   if (tiles_per_side < 1 || tiles_per_side > 0xffff || grid < 1 || !order_out) return fail("dedup_tile_order: bad argument");
   const std::vector<unsigned> order = tri_tile_order(tiles_per_side, grid);

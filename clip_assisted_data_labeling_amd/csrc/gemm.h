@@ -28,6 +28,8 @@ struct GemmParams {
   unsigned long long cap;
   unsigned long long* count;
   const unsigned* tile_list;     // [tt (tt + 1) / 2] tm | tn << 16: execution order of the upper-triangular tiles (set by ce_gemm_tri_persist)
+  const unsigned long long* run_if_over;   // EPI_THRESH, optional: the launch does nothing unless *run_if_over > run_if_limit (read on the
+  unsigned long long run_if_limit;         // device when the launch starts: the exact search as the fall-back of the screened one, dedup.hip)
   // fp8 path (gemm_fp8.hip): out = acc * scale_a[m] * scale_w[n] + bias[n]
   const float* scale_a;          // [M] per-token activation scale (NULL: 1)
   const float* scale_w;          // [N] per-output-channel weight scale
@@ -55,5 +57,7 @@ hipError_t ce_gemm_nt(const GemmParams& p, int dtype, int epi, hipStream_t strea
 hipError_t ce_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream);           // fp8 e4m3 operands; EPI_STORE_BF16 / EPI_RESID / EPI_STORE_FP8 / EPI_RESID_Q
 hipError_t ce_gemm_nt_persist(const GemmParams& p, int epi, hipStream_t stream);   // bf16; EPI_STORE_BF16 / LNFOLD / RESID
 hipError_t ce_gemm_tri_persist(const GemmParams& p, hipStream_t stream);            // f16 E.E^T, upper triangle, EPI_THRESH (gemm_tri.hip)
+hipError_t ce_gemm_fp8_tri(const GemmParams& p, hipStream_t stream);                // e4m3 Q.Q^T, upper triangle, candidate screen (gemm_fp8_tri.hip)
+hipError_t ce_tri_tile_list(int tt, int grid, const unsigned** dev_list);           // gemm_tri.hip: the device copy of tri_tile_order(tt, grid), cached
 #include <vector>
 std::vector<unsigned> tri_tile_order(int tt, int grid);                            // gemm_tri.hip: execution order of the triangular tile list

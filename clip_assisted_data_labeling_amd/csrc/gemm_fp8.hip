@@ -44,7 +44,7 @@
 #define F8_LNF_DBG 0             // 4 no exponent DMA
 #endif
 // instantiations with the register room for the peeled zero-C first stage pair (the others spill with it)
-#define ZERO_C_SET(EPI, ACT) ((EPI) == 2 && (ACT) <= 0)
+#define ZERO_C_SET(EPI, ACT) (((EPI) == 2 && (ACT) <= 0) || (EPI) == 4)
 
 namespace {
 
@@ -96,9 +96,19 @@ __device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n)
   return TileId{tm * BM, tn * BN};
 }
 
+// EPI 4 (gemm_fp8_tri.hip): the tiles of the upper triangle in the host-made order of gemm_tri.hip, one scalar load per tile
+// (scalar memory counts in lgkmcnt, not in the vmcnt of the DMA pipeline's counted waits)
+__device__ __forceinline__ TileId tri_tile(const unsigned* list, int i) {
+  unsigned v;
+  asm volatile("s_load_dword %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(list), "s"(i * 4) : "memory");
+  return TileId{(int)(v & 0xffffu) * BM, (int)(v >> 16) * BN};
+}
+
 // EPI: 0 = scale + bias (+ activation) -> bf16;  1 = scale + bias + residual (bf16, in place) -> bf16;
 //      2 = scale + bias (+ activation), then * out_inv_scale[n] -> e4m3 (the next GEMM's operand, no bf16 round trip)
 //      3 = as 1, and the e4m3 block-exponent copy of the new rows + their (sum, sum of squares) per 64 columns
+//      4 = near-duplicate SCREEN (A == W == e4m3 rows of unit vectors x 256, upper-triangular tile list): no output matrix; the
+//          (i < j) whose e4m3 product cannot rule them out are appended as candidates (ce_gemm_fp8_tri below)
 // LNF: A rows are block-exponent rows (a_exp) and the epilogue applies the folded LayerNorm (row_r, row_d, colsum)
 template <int EPI, int ACT, bool LNF>
 __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
@@ -117,7 +127,8 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   const int r32 = lane & 31, h = lane >> 5;
 
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = p.N / BN;
-  const int nwg = tiles_m * tiles_n;
+  const int nwg = EPI == 4 ? tiles_n * (tiles_n + 1) / 2 : tiles_m * tiles_n;
+#define DECODE_TILE(i_) (EPI == 4 ? tri_tile(p.tile_list, (i_)) : decode_tile((i_), tiles_m, tiles_n))
   const int G = gridDim.x;
   const size_t lda_b = (size_t)p.lda, ldw_b = (size_t)p.ldw;      // fp8: 1 byte per element
   const int kend = p.K;                      // bytes along K; one stage = 128 B; K % 256 == 0 (stages come in pairs)
@@ -143,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
 #define TW_ADDR(c) (tr + tw_base + ((((c)) ^ tw_sw) << 4))
 
   int idx = blockIdx.x;
-  TileId cur = decode_tile(idx, tiles_m, tiles_n);
+  TileId cur = DECODE_TILE(idx);
   const char* Ablk = (const char*)p.A + (size_t)cur.m0 * lda_b;
   const char* Wblk = (const char*)p.W + (size_t)cur.n0 * ldw_b;
 #define AOFF(m0v, r) ((unsigned)((min((m0v) + (r), p.M - 1) - (m0v)) * lda_b) + dchunk16)
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   // the column constants (weight scales, biases, EPI 2: inverse output scales) of the tile are staged into the wave's image at
   // the top of the tile (below): those pieces sit between the previous tile's stores and the first waits (the per-row
   // scale pieces, issued only with per-token scales, are not counted: the wait is then two pieces stricter than need be)
-  constexpr int CB_PIECES = LNF ? (EPI == 2 ? 8 : 7) : (EPI == 2 ? 3 : 2);
+  constexpr int CB_PIECES = EPI == 4 ? 0 : LNF ? (EPI == 2 ? 8 : 7) : (EPI == 2 ? 3 : 2);
 
   // ---- cold prologue of the first tile ----
   // E_ROWS(m0v, dst): the exponent dwords of the wave's 128 rows of the tile at m0v, two DMA pieces (lane = row)
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     // (EPI 2), [3584, 4096) per-row scales.  As global loads at the head of the epilogue they made the first block wait for
     // every older DMA piece of the next tile (vmcnt retires in order) -- see gemm_persist.hip, same change, same argument:
     // extra pieces only make the counted waits stricter, and they have retired before the epilogue.
-    {
+    if constexpr (EPI != 4) {
       int lane_t;                                              // the lane id from the hardware (not kept across the main loop)
       asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_t));
       const unsigned ti = lds0 + (unsigned)(TR_OFF + w * 4096);
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
     if (has_next) {
-      nxt = decode_tile(nidx, tiles_m, tiles_n);
+      nxt = DECODE_TILE(nidx);
       Anext = (const char*)p.A + (size_t)nxt.m0 * lda_b;
       Wnext = (const char*)p.W + (size_t)nxt.n0 * ldw_b;
     }
@@ -368,6 +379,47 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
 #endif
 
     // ------------------------------- epilogue of tile `cur` -------------------------------
+    if constexpr (EPI == 4) {
+      // Screen (dedup.hip has the derivation): acc = 65536 * (q_i . q_j) with q = e4m3(256 e_hat); the true cosine differs from
+      // acc / 65536 by at most 1.1 (err_i + err_j), err = the rows' own quantisation error norms.  p.scale_a[r] holds row r's
+      // share of that margin in accumulator units, p.thr the smallest cosine the exact rule could still accept.  First one
+      // running maximum against the worst-case margin (2 x 1.1 x 0.0665: rows with a larger error divert the call, dedup.hip), then -- rarely -- the test per pair.
+      int lane_e;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_e));
+      const int r32e = lane_e & 31, he = lane_e >> 5;
+      float vmax = -1e30f;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) asm("v_max3_f32 %0, %0, %1, %2" : "+v"(vmax) : "v"(acc[mt][nt][2 * q]), "v"(acc[mt][nt][2 * q + 1]));
+      const float thr_acc = p.thr * 65536.0f;
+      if (__builtin_amdgcn_ballot_w64(vmax > thr_acc - 0.147f * 65536.0f) != 0ull) {
+        const float* marg = p.scale_a;
+        uint2* cand = (uint2*)p.pairs;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int i = cur.m0 + wr * 128 + mt * 32 + r32e;
+          const float mi = marg[i];
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int j0 = cur.n0 + wc * 64 + nt * 32 + 8 * g + 4 * he;
+              const f32x4_t mj = *(const f32x4_t*)(marg + j0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int j = j0 + e;
+                if (j > i && j < p.n_valid && acc[mt][nt][4 * g + e] + mi + mj[e] > thr_acc) {
+                  const unsigned long long slot = atomicAdd(p.count, 1ull);
+                  if (slot < p.cap) cand[slot] = uint2{(unsigned)i, (unsigned)j};
+                }
+              }
+            }
+        }
+      }
+    } else {
     // lane (r32, h) of m-tile mt holds row mw0 + mt*32 + r32, columns nb + nt*32 + 8g + 4h + (0..3) in acc[mt][nt][4g..4g+3]
     // (every per-lane constant of the epilogue comes from the hardware's lane id HERE: derived at the top of the kernel they are
     // loop invariants that hipcc keeps across the main loop -- in scratch, reloaded below behind a vmcnt(0) that drains the DMA
@@ -616,6 +668,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
         for (int mt = 0; mt < 4; ++mt) *(unsigned*)(tr + E_CUR + (mt * 32 + r32e) * 4) = e_hop[mt];
       }
     }
+    }   // EPI != 4
 
 #ifdef CLIPENC_DIAG
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 3] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 0] = blockIdx.x; }
@@ -624,7 +677,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // drain the redundant DMA before the LDS is released
       break;
     }
-    relax = (cur.m0 + BM <= p.M) ? 2 : 0;    // all 256 rows valid: every guarded row store above was issued; the first two waits
+    relax = (EPI != 4 && cur.m0 + BM <= p.M) ? 2 : 0;    // (EPI 4 issues a data-dependent number of stores: never relaxed)  all 256 rows valid: every guarded row store above was issued; the first two waits
 #ifdef CLIPENC_DIAG
     if (p.dbg) relax = 0;                    // (the stamps add stores: no relaxed waits then)
 #endif
@@ -648,6 +701,30 @@ hipError_t launch_fp8(const GemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
+#ifdef GEMM_FP8_TRI_TU
+// gemm_fp8_tri.hip: the screen instantiation in a translation unit of its own (it cannot perturb the code generation of the
+// tower's instantiations).  A == W: e4m3 [n_pad][lda] bytes (n_pad a multiple of 256, K = lda a multiple of 256, zero padded);
+// scale_a = per-row margins [n_pad]; pairs = candidate slots (8 bytes each), cap, count; tile_list as ce_gemm_tri_persist uses.
+hipError_t ce_gemm_fp8_tri(const GemmParams& p_in, hipStream_t stream) {
+  GemmParams p = p_in;
+  if (p.N < BN || p.N % BN != 0 || p.M != p.N || p.K < 512 || p.K % 256 != 0 || p.lda != p.ldw || p.lda < p.K || p.A != p.W) return hipErrorInvalidValue;
+  if (!p.scale_a || !p.pairs || !p.count || ((uintptr_t)p.A & 15) || ((uintptr_t)p.scale_a & 15) || ((uintptr_t)p.pairs & 7)) return hipErrorInvalidValue;
+  if ((size_t)255 * p.lda + 64 >= 0x7fffffffull) return hipErrorInvalidValue;
+  const int tt = p.N / BN;
+  if (tt > 0xffff) return hipErrorInvalidValue;
+  static DeviceKernelSetup setup;
+  int n_cu = 0;
+  if (hipError_t e = setup.ensure((const void*)gemm_fp8_kernel<4, -1, false>, LDS_BYTES, &n_cu); e != hipSuccess) return e;
+  const int tiles = tt * (tt + 1) / 2;
+  int grid = n_cu > 0 ? n_cu : 256;
+  grid -= grid % 8;
+  if (grid < 8) grid = 8;
+  if (tiles < grid) grid = tiles;
+  if (hipError_t e = ce_tri_tile_list(tt, grid, &p.tile_list); e != hipSuccess) return e;
+  hipLaunchKernelGGL((gemm_fp8_kernel<4, -1, false>), dim3(grid), dim3(512), LDS_BYTES, stream, p);
+  return hipGetLastError();
+}
+#else
 // A: fp8 [M][lda] (bytes), W: fp8 [N][ldw]; out bf16 [M][ldo]; scale_a [M], scale_w [N], bias [N] fp32.
 // epi: EPI_STORE_BF16 (scale + bias + p.act), EPI_RESID (scale + bias + bf16 residual, may alias out) or
 // EPI_STORE_FP8 (as STORE_BF16, then e4m3(value * out_inv_scale[n]) into out [M][ldo] BYTES).  scale_a NULL = 1.
@@ -695,3 +772,4 @@ hipError_t ce_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream) {
   if (p.act == CE_ACT_GELU_ERF) return launch_fp8<0, CE_ACT_GELU_ERF>(p, stream);
   return launch_fp8<0, -1>(p, stream);
 }
+#endif

@@ -102,6 +102,9 @@ template <int EPI, int ACT>
 __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p) {
   typedef typename OperandOf<EPI>::frag frag_t;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if constexpr (EPI == EPI_THRESH) {           // the exact search as a fall-back (gemm.h): nothing to do unless the counter ran over
+    if (p.run_if_over && *(const volatile unsigned long long*)p.run_if_over <= p.run_if_limit) return;
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -658,37 +661,40 @@ std::mutex g_tri_mu;
 std::vector<TriOrderEntry> g_tri_cache;         // a handful of (device, problem size) pairs per process; oldest evicted
 }  // namespace
 
+// The device copy of tri_tile_order(tt, grid) for the current device (made at the first use of a problem size, cached).
+hipError_t ce_tri_tile_list(int tt, int grid, const unsigned** dev_list) {
+  int device = 0;
+  if (hipError_t e = hipGetDevice(&device); e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(g_tri_mu);
+  for (const auto& c : g_tri_cache)
+    if (c.device == device && c.tt == tt && c.grid == grid) { *dev_list = c.dev_list; return hipSuccess; }
+  const std::vector<unsigned> order = tri_tile_order(tt, grid);
+  unsigned* d = nullptr;
+  if (hipError_t e = hipMalloc((void**)&d, order.size() * sizeof(unsigned)); e != hipSuccess) return e;
+  // (first use of a problem size only; a blocking copy, so the list is complete before any launch can read it)
+  if (hipError_t e = hipMemcpy(d, order.data(), order.size() * sizeof(unsigned), hipMemcpyHostToDevice); e != hipSuccess) {
+    (void)hipFree(d);
+    return e;
+  }
+  if (g_tri_cache.size() >= 8) {              // the evicted list may still be read by a launch in flight: wait for the device
+    (void)hipDeviceSynchronize();
+    (void)hipFree(g_tri_cache.front().dev_list);
+    g_tri_cache.erase(g_tri_cache.begin());
+  }
+  g_tri_cache.push_back(TriOrderEntry{device, tt, grid, d});
+  *dev_list = d;
+  return hipSuccess;
+}
+
 hipError_t ce_gemm_tri_persist(const GemmParams& p_in, hipStream_t stream) {
   GemmParams p = p_in;
   const int tt = p.N / BN;
   if (tt > 0xffff) return hipErrorInvalidValue;                              // tile coordinates are packed 16 + 16 bits
   static DeviceKernelSetup setup;
-  int n_cu = 0, device = 0;
+  int n_cu = 0;
   if (hipError_t e = setup.ensure((const void*)gemm_persist_kernel<EPI_THRESH, -1>, LDS_BYTES, &n_cu); e != hipSuccess) return e;
-  if (hipError_t e = hipGetDevice(&device); e != hipSuccess) return e;
   const int grid = persist_grid(n_cu, tt * (tt + 1) / 2);
-  {
-    std::lock_guard<std::mutex> lock(g_tri_mu);
-    for (const auto& c : g_tri_cache)
-      if (c.device == device && c.tt == tt && c.grid == grid) p.tile_list = c.dev_list;
-    if (!p.tile_list) {
-      const std::vector<unsigned> order = tri_tile_order(tt, grid);
-      unsigned* d = nullptr;
-      if (hipError_t e = hipMalloc((void**)&d, order.size() * sizeof(unsigned)); e != hipSuccess) return e;
-      // (first use of a problem size only; a blocking copy, so the list is complete before any launch can read it)
-      if (hipError_t e = hipMemcpy(d, order.data(), order.size() * sizeof(unsigned), hipMemcpyHostToDevice); e != hipSuccess) {
-        (void)hipFree(d);
-        return e;
-      }
-      if (g_tri_cache.size() >= 8) {              // the evicted list may still be read by a launch in flight: wait for the device
-        (void)hipDeviceSynchronize();
-        (void)hipFree(g_tri_cache.front().dev_list);
-        g_tri_cache.erase(g_tri_cache.begin());
-      }
-      g_tri_cache.push_back(TriOrderEntry{device, tt, grid, d});
-      p.tile_list = d;
-    }
-  }
+  if (hipError_t e = ce_tri_tile_list(tt, grid, &p.tile_list); e != hipSuccess) return e;
   return launch_persist<EPI_THRESH, -1>(p, stream);
 }
 #else

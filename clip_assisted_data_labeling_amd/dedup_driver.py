@@ -71,8 +71,11 @@ def get_paths_and_embeddings(args, crop_to_use):
 
 @torch.no_grad()
 def near_duplicate_pairs(emb_fp16: torch.Tensor, threshold: float, device="cuda", fp16_compare: bool = True,
-                         capacity: int = 1 << 20) -> Tuple[np.ndarray, np.ndarray]:
-    """[n, d] float16 -> (pairs int64 [P,2] sorted row-major with i < j, values float32 [P])."""
+                         capacity: int = 1 << 20, screened: bool = True, candidate_capacity: int = 1 << 22) -> Tuple[np.ndarray, np.ndarray]:
+    """[n, d] float16 -> (pairs int64 [P,2] sorted row-major with i < j, values float32 [P]).
+    screened (default): the e4m3 screen + exact recheck of include/clipenc.h (dedup_find_pairs_screened) -- the same pairs and
+    values as the exact float16 search, which it falls back to by itself when there are more than `candidate_capacity` candidates;
+    screened=False: the exact search only (dedup_find_pairs)."""
     lib = _lib.load()
     dev = torch.device(device)
     x = emb_fp16.to(dev, torch.float16).contiguous()
@@ -80,12 +83,22 @@ def near_duplicate_pairs(emb_fp16: torch.Tensor, threshold: float, device="cuda"
     n_pad, d_pad = (n + 255) // 256 * 256, (d + 127) // 128 * 128
     ws = torch.empty(max(n_pad * d_pad, 1), dtype=torch.float16, device=dev)
     count = torch.zeros(1, dtype=torch.int64, device=dev)
+    sws = None
+    if screened and n >= 2:
+        nbytes = int(lib.dedup_screen_ws_bytes(n, d, candidate_capacity))
+        sws = torch.empty(nbytes + 256, dtype=torch.uint8, device=dev)
+        sws_ptr = (sws.data_ptr() + 255) // 256 * 256
     while True:
         pairs = torch.empty((capacity, 2), dtype=torch.int64, device=dev)
         vals = torch.empty(capacity, dtype=torch.float32, device=dev)
-        _lib.check(lib.dedup_find_pairs(x.data_ptr(), n, d, float(threshold), 1 if fp16_compare else 0, ws.data_ptr(),
-                                        pairs.data_ptr(), vals.data_ptr(), capacity, count.data_ptr(),
-                                        _lib.current_stream_ptr(dev)), "dedup_find_pairs")
+        if sws is not None:
+            _lib.check(lib.dedup_find_pairs_screened(x.data_ptr(), n, d, float(threshold), 1 if fp16_compare else 0, ws.data_ptr(), sws_ptr, nbytes,
+                                                     candidate_capacity, pairs.data_ptr(), vals.data_ptr(), capacity, count.data_ptr(),
+                                                     _lib.current_stream_ptr(dev)), "dedup_find_pairs_screened")
+        else:
+            _lib.check(lib.dedup_find_pairs(x.data_ptr(), n, d, float(threshold), 1 if fp16_compare else 0, ws.data_ptr(),
+                                            pairs.data_ptr(), vals.data_ptr(), capacity, count.data_ptr(),
+                                            _lib.current_stream_ptr(dev)), "dedup_find_pairs")
         c = int(count.item())
         if c <= capacity:
             break

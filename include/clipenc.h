@@ -155,6 +155,18 @@ int fctrain_get_params(fctrain_t t, int layer, float* W_host, float* b_host);
 int dedup_find_pairs(const void* emb_f16_dev, int n, int d, float threshold, int fp16_compare,
                      void* ehat_ws_dev, long long* pairs_dev, float* vals_dev, unsigned long long capacity,
                      unsigned long long* count_dev, void* stream);
+/* The same search -- the same pairs with the same values, in whatever order -- at about twice the rate: an e4m3 MFMA pass over the
+ * upper triangle first SCREENS the pairs (unit rows quantised as e4m3(256 x); a pair stays a candidate unless its e4m3 product plus
+ * the two rows' own measured quantisation-error norms, a Cauchy-Schwarz bound, is below what the exact rule could accept), then
+ * only the candidates get their exact float16-MFMA value, accumulated in the order of dedup_find_pairs, and its rule.  No
+ * reported pair can be lost to the screen; when the screen finds more candidates than `candidate_capacity` (a store of near-identical
+ * rows) the exact search of dedup_find_pairs runs instead, decided on the device without a host round trip.
+ *   screen_ws_dev  256-byte aligned scratch of dedup_screen_ws_bytes(n, d, candidate_capacity) bytes (8 bytes per candidate slot
+ *                  + 1 byte per padded element + 4 per row); the other arguments as for dedup_find_pairs */
+size_t dedup_screen_ws_bytes(int n, int d, unsigned long long candidate_capacity);
+int dedup_find_pairs_screened(const void* emb_f16_dev, int n, int d, float threshold, int fp16_compare, void* ehat_ws_dev,
+                              void* screen_ws_dev, size_t screen_ws_bytes, unsigned long long candidate_capacity, long long* pairs_dev,
+                              float* vals_dev, unsigned long long capacity, unsigned long long* count_dev, void* stream);
 /* Host-only view of HOW dedup_find_pairs walks the similarity matrix (no device work; the CPU tests check it): the
  * execution order of the 256 x 256 tiles of the upper triangle (tn >= tm) of a tiles_per_side x tiles_per_side tile grid for a
  * launch of `grid` persistent workgroups.  order_out[i] = tm | tn << 16 is the tile that workgroup i % grid runs in its round

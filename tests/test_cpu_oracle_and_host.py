@@ -293,3 +293,16 @@ def test_simplefc_is_pickle_compatible_with_reference_layout(tmp_path):
     m2 = load_regressor(str(tmp_path / "m.pth"))
     assert m2.clip_models == ["ViT-L-14/openai"] and m2.crop_names == ["centre_crop"]
     assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+
+
+def test_dedup_screen_scratch_size_is_host_arithmetic():
+    """include/clipenc.h: dedup_screen_ws_bytes -- counter block + e4m3 rows (n and d padded) + a margin per row + 8 bytes per
+    candidate slot; no device work."""
+    from clip_assisted_data_labeling_amd import _lib
+    lib = _lib.load()
+    b = lib.dedup_screen_ws_bytes
+    assert b(100_000, 768, 0) == 256 + 100_096 * 768 + 100_096 * 4            # 391 x 256 rows; 768 = 3 x 256 columns
+    assert b(100_000, 768, 1 << 20) - b(100_000, 768, 0) == 8 << 20
+    assert b(1000, 100, 0) == 256 + 1024 * 512 + 1024 * 4                     # d 100 -> 128 -> at least 512 e4m3 columns
+    assert b(10, 1000, 5) == 256 + 256 * 1024 + 256 * 4 + 40
+    assert b(-1, 768, 10) == 0 and b(10, 0, 10) == 0

@@ -43,6 +43,7 @@ def test_single_gpu_line_has_the_contract_keys(gpu):
     assert sec["fp8_step"]["dtype"] == "fp8" and sec["fp8_step"]["value"] > 0 and "fp8" in sec["fp8_step"]["dominant_kernel"]
     assert sec["fp8_step"]["dominant_peak"] == 5033.2 and 0 < sec["fp8_step"]["dominant_frac"] < 1
     assert sec["dedup_100k"]["pairs_found"] == 1000 and sec["dedup_100k"]["ms"] > 0
+    assert sec["dedup_100k"]["candidates"] == 1000 and sec["dedup_100k"]["exact_search"]["pairs_found"] == 1000
     l336 = sec["vit_l14_336"]
     assert l336["value"] > 0 and 0 < l336["attention_share_of_step"] < 1 and any(k.startswith("attn_long") for k in l336["kernels_ms_per_step"])
     assert sec["embed_e2e"].get("images") == 4096 and sec["embed_e2e"]["pt_files_written"] == 4096 and sec["embed_e2e"]["value"] > 0, sec["embed_e2e"]
