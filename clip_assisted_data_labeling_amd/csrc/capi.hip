@@ -1004,7 +1004,8 @@ int dedup_find_pairs_screened(const void* emb_f16_dev, int n, int d, float thres
   if ((uintptr_t)screen_ws_dev & 255) return fail("dedup_find_pairs_screened: screen_ws_dev must be 256-byte aligned");
   const int ld = (d + 127) / 128 * 128;
   char* ws = (char*)screen_ws_dev;
-  HIP_TRY(ce_dedup_normalize_f16(emb_f16_dev, ehat_ws_dev, n, d, ld, st));
+  HIP_TRY(ce_dedup_normalize_quant(emb_f16_dev, ehat_ws_dev, n, d, ld, ws + w.q8, w.ld8, (float*)(ws + w.margin), (unsigned long long*)ws,
+                                   candidate_capacity, st));
   HIP_TRY(ce_dedup_pairs_screened(ehat_ws_dev, n, ld, threshold, fp16_compare, ws + w.q8, (float*)(ws + w.margin), ws + w.cand,
                                   candidate_capacity, (unsigned long long*)ws, pairs_dev, vals_dev, capacity, count_dev, st));
   return 0;

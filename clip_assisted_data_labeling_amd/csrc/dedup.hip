@@ -130,12 +130,114 @@ __global__ __launch_bounds__(256) void dedup_recheck_kernel(const _Float16* __re
   }
 }
 
+// Normalisation (dedup_normalize_kernel's arithmetic) and the screen's quantisation (dedup_quant_fp8_kernel's) in one pass over the
+// rows, 16-byte accesses: one wave per row, a lane takes 8 columns at a time (d % 8 == 0; other widths use the two kernels above).
+// q8 == nullptr: normalise only.
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8_t;
+__global__ __launch_bounds__(256) void dedup_normalize_quant_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out, int n, int d,
+                                                                    int n_pad, int ld, unsigned char* __restrict__ q8, int ld8,
+                                                                    float* __restrict__ margin, unsigned long long* overflow,
+                                                                    unsigned long long over_by) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_pad) return;
+  h16x8_t* o = (h16x8_t*)(out + (size_t)row * ld);
+  uint2* o8 = q8 ? (uint2*)(q8 + (size_t)row * ld8) : nullptr;
+  const h16x8_t zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+  const int dc = d / 8, lc = ld / 8, l8c = ld8 / 8;
+  if (row >= n) {
+    for (int c = lane; c < lc; c += 64) o[c] = zero8;
+    if (q8) {
+      for (int c = lane; c < l8c; c += 64) o8[c] = uint2{0u, 0u};
+      if (lane == 0) margin[row] = 0.f;
+    }
+    return;
+  }
+  const h16x8_t* x = (const h16x8_t*)(in + (size_t)row * d);
+  float ss = 0.f;
+  for (int c = lane; c < dc; c += 64) {
+    const h16x8_t v = x[c];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss += (float)v[e] * (float)v[e];
+  }
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) ss += __shfl_xor(ss, s);
+  const float nrm = (float)(_Float16)sqrtf(ss);
+  float ee = 0.f, qq = 0.f;
+  bool finite = true;
+  for (int c = lane; c < max(lc, l8c); c += 64) {
+    h16x8_t r = zero8;
+    if (c < dc) {
+      const h16x8_t v = x[c];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = (_Float16)((float)v[e] / nrm);
+    }
+    if (c < lc) o[c] = r;
+    if (q8 && c < l8c) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        f[e] = (float)r[e];
+        finite = finite && fabsf(f[e]) <= 65504.f;
+      }
+      int w0 = 0, w1 = 0;
+#define Q_(a) __builtin_amdgcn_fmed3f((a) * 256.f, -448.f, 448.f)
+      w0 = __builtin_amdgcn_cvt_pk_fp8_f32(Q_(f[0]), Q_(f[1]), w0, false); w0 = __builtin_amdgcn_cvt_pk_fp8_f32(Q_(f[2]), Q_(f[3]), w0, true);
+      w1 = __builtin_amdgcn_cvt_pk_fp8_f32(Q_(f[4]), Q_(f[5]), w1, false); w1 = __builtin_amdgcn_cvt_pk_fp8_f32(Q_(f[6]), Q_(f[7]), w1, true);
+#undef Q_
+      o8[c] = uint2{(unsigned)w0, (unsigned)w1};
+      const float q[8] = {__builtin_amdgcn_cvt_f32_fp8(w0, 0), __builtin_amdgcn_cvt_f32_fp8(w0, 1), __builtin_amdgcn_cvt_f32_fp8(w0, 2),
+                          __builtin_amdgcn_cvt_f32_fp8(w0, 3), __builtin_amdgcn_cvt_f32_fp8(w1, 0), __builtin_amdgcn_cvt_f32_fp8(w1, 1),
+                          __builtin_amdgcn_cvt_f32_fp8(w1, 2), __builtin_amdgcn_cvt_f32_fp8(w1, 3)};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float qv = q[e] * (1.f / 256.f), dv = f[e] - qv;
+        ee += dv * dv; qq += qv * qv;
+      }
+    }
+  }
+  if (!q8) return;
+  finite = __builtin_amdgcn_ballot_w64(!finite) == 0ull;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) { ee += __shfl_xor(ee, s); qq += __shfl_xor(qq, s); }
+  if (!finite) {                               // as dedup_quant_fp8_kernel: a zero row in the screen
+    for (int c = lane; c < l8c; c += 64) o8[c] = uint2{0u, 0u};
+    if (lane == 0) margin[row] = 0.f;
+    return;
+  }
+  const float err = sqrtf(ee) * (1.f + 0x1p-10f), nq = sqrtf(qq) * (1.f + 0x1p-10f);
+  if (lane == 0) {
+    margin[row] = 65536.f * (1.1f * err + 1e-4f);
+    if (!(nq <= 1.065f && err <= 0.0665f)) atomicAdd(overflow, over_by);
+  }
+}
+
 }  // namespace
 
 hipError_t ce_dedup_normalize_f16(const void* emb_f16, void* out_f16, int n, int d, int ld_out, hipStream_t stream) {
   const int n_pad = (n + 255) / 256 * 256;
-  hipLaunchKernelGGL(dedup_normalize_kernel, dim3((n_pad + 3) / 4), dim3(256), 0, stream, (const _Float16*)emb_f16,
-                     (_Float16*)out_f16, n, d, n_pad, ld_out);
+  if (d % 8 == 0 && ld_out % 8 == 0 && !(((uintptr_t)emb_f16 | (uintptr_t)out_f16) & 15))
+    hipLaunchKernelGGL(dedup_normalize_quant_kernel, dim3((n_pad + 3) / 4), dim3(256), 0, stream, (const _Float16*)emb_f16, (_Float16*)out_f16, n, d,
+                       n_pad, ld_out, (unsigned char*)nullptr, 0, (float*)nullptr, (unsigned long long*)nullptr, 0ull);
+  else
+    hipLaunchKernelGGL(dedup_normalize_kernel, dim3((n_pad + 3) / 4), dim3(256), 0, stream, (const _Float16*)emb_f16,
+                       (_Float16*)out_f16, n, d, n_pad, ld_out);
+  return hipGetLastError();
+}
+
+// normalise + quantise for the screened search (one pass when the width allows 16-byte accesses); zeroes *cand_count first
+hipError_t ce_dedup_normalize_quant(const void* emb_f16, void* out_f16, int n, int d, int ld, void* q8_ws, int ld8, float* margin_ws,
+                                    unsigned long long* cand_count, unsigned long long cand_cap, hipStream_t stream) {
+  const int n_pad = (n + 255) / 256 * 256;
+  if (hipError_t e = hipMemsetAsync(cand_count, 0, sizeof(unsigned long long), stream); e != hipSuccess) return e;
+  if (d % 8 == 0 && ld % 8 == 0 && ld8 % 8 == 0 && !(((uintptr_t)emb_f16 | (uintptr_t)out_f16 | (uintptr_t)q8_ws) & 15)) {
+    hipLaunchKernelGGL(dedup_normalize_quant_kernel, dim3((n_pad + 3) / 4), dim3(256), 0, stream, (const _Float16*)emb_f16, (_Float16*)out_f16, n, d,
+                       n_pad, ld, (unsigned char*)q8_ws, ld8, margin_ws, cand_count, cand_cap + 1);
+    return hipGetLastError();
+  }
+  hipLaunchKernelGGL(dedup_normalize_kernel, dim3((n_pad + 3) / 4), dim3(256), 0, stream, (const _Float16*)emb_f16, (_Float16*)out_f16, n, d, n_pad, ld);
+  hipLaunchKernelGGL(dedup_quant_fp8_kernel, dim3((n_pad + 3) / 4), dim3(256), 0, stream, (const _Float16*)out_f16, ld, (unsigned char*)q8_ws, ld8,
+                     margin_ws, n_pad, cand_count, cand_cap + 1);
   return hipGetLastError();
 }
 
@@ -151,18 +253,15 @@ hipError_t ce_dedup_pairs(const void* ehat_f16, int n, int d, int ld, float thre
   return ce_gemm_nt(p, CE_DT_F16, EPI_THRESH, stream);
 }
 
-// The same pairs and values as ce_dedup_pairs, found by the e4m3 screen + exact recheck (kernels above).  q8_ws: n_pad * ld8 bytes
-// (ld8 = ld rounded up to 256, at least 512), margin_ws: n_pad floats, cand_ws: cand_cap slots of 8 bytes, cand_count: one counter (zeroed here).
+// The same pairs and values as ce_dedup_pairs, found by the e4m3 screen + exact recheck (kernels above), on rows prepared by
+// ce_dedup_normalize_quant.  q8_ws: n_pad * ld8 bytes
+// (ld8 = ld rounded up to 256, at least 512), margin_ws: n_pad floats, cand_ws: cand_cap slots of 8 bytes, cand_count: the counter ce_dedup_normalize_quant zeroed.
 // When the screen finds more candidates than slots, the exact search runs instead, decided on the device (no host round trip).
 hipError_t ce_dedup_pairs_screened(const void* ehat_f16, int n, int ld, float threshold, int fp16_compare, void* q8_ws, float* margin_ws,
                                    void* cand_ws, unsigned long long cand_cap, unsigned long long* cand_count, long long* pairs,
                                    float* vals, unsigned long long capacity, unsigned long long* count, hipStream_t stream) {
   const int n_pad = (n + 255) / 256 * 256;
   const int ld8 = ld + 255 < 512 ? 512 : (ld + 255) / 256 * 256;    // zero padded; at least two stage pairs of the fp8 pipeline
-  if (hipError_t e = hipMemsetAsync(cand_count, 0, sizeof(unsigned long long), stream); e != hipSuccess) return e;
-  hipLaunchKernelGGL(dedup_quant_fp8_kernel, dim3((n_pad + 3) / 4), dim3(256), 0, stream, (const _Float16*)ehat_f16, ld,
-                     (unsigned char*)q8_ws, ld8, margin_ws, n_pad, cand_count, cand_cap + 1);
-  if (hipError_t e = hipGetLastError(); e != hipSuccess) return e;
   // the smallest true cosine the exact rule can accept: it compares the (fp16-rounded) value with the (fp16-rounded) threshold
   const float thr_x = fp16_compare ? (float)(_Float16)threshold : threshold;
   const float thr_lo = thr_x - 2.0e-3f * fmaxf(1.0f, fabsf(thr_x));

@@ -102,6 +102,8 @@ hipError_t ce_dedup_normalize_f16(const void* emb_f16, void* out_f16, int n, int
 hipError_t ce_dedup_pairs(const void* ehat_f16, int n, int d, int ld, float threshold, int fp16_compare,
                           long long* pairs, float* vals, unsigned long long capacity, unsigned long long* count,
                           hipStream_t stream);
+hipError_t ce_dedup_normalize_quant(const void* emb_f16, void* out_f16, int n, int d, int ld, void* q8_ws, int ld8, float* margin_ws,
+                                    unsigned long long* cand_count, unsigned long long cand_cap, hipStream_t stream);
 hipError_t ce_dedup_pairs_screened(const void* ehat_f16, int n, int ld, float threshold, int fp16_compare, void* q8_ws, float* margin_ws,
                                    void* cand_ws, unsigned long long cand_cap, unsigned long long* cand_count, long long* pairs,
                                    float* vals, unsigned long long capacity, unsigned long long* count, hipStream_t stream);
