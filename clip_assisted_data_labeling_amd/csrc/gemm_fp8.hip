@@ -521,19 +521,36 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     if constexpr (EPI == 2) {
       // fp8 image: [32 rows][80 B pitch] per wave (64 data bytes; the pitch keeps the dword writes 2-way conflicted at most),
       // the wave's 64 inverse output scales behind it
-      const float* isc = (const float*)(tr + 2560);             // (landed by the DMA of the tile's top)
+      float* isc = (float*)(tr + 2560);                         // (landed by the DMA of the tile's top)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // pass 1's reads of the image are done before it is rewritten
+      // QuickGELU, u * sigmoid(1.702 u) * is[n], with two multiplies per element less: a = k u comes straight from the row scale
+      // (k = -1.702 log2 e, folded into sa), and  u is / (1 + 2^a)  =  a / (c + c 2^a)  with c[n] = k / is[n] -- one fma in front of
+      // the reciprocal instead of an add in front and two multiplies behind it.  c replaces is in the wave's image, one value per lane.
+      constexpr float QK = -2.4554669595930156f;
+      if constexpr (ACT == CE_ACT_QUICK_GELU) {
+        const float is1 = isc[lane_e];
+        isc[lane_e] = is1 != 0.f ? QK * __builtin_amdgcn_rcpf(is1) : 1e30f;      // (a zero output scale: the column becomes zero)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) sa[mt] *= QK;
+      }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const int nt = c >> 2, g = c & 3;
           const int col = nt * 32 + g * 8 + he * 4;
-          const f32x4_t is = *(const f32x4_t*)(isc + col);
+          const f32x4_t is = *(const f32x4_t*)(isc + col);      // (the LDS serves one wave's accesses in order: the values written above)
           float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            v[e] = __builtin_amdgcn_fmed3f(act_apply_t<ACT>(acc[mt][nt][g * 4 + e] * sa[mt]) * is[e], -448.0f, 448.0f);
+          for (int e = 0; e < 4; ++e) {
+            if constexpr (ACT == CE_ACT_QUICK_GELU) {
+              const float a = acc[mt][nt][g * 4 + e] * sa[mt];
+              const float den = __builtin_fmaf(__builtin_amdgcn_exp2f(a), is[e], is[e]);
+              v[e] = __builtin_amdgcn_fmed3f(a * __builtin_amdgcn_rcpf(den), -448.0f, 448.0f);
+            } else {
+              v[e] = __builtin_amdgcn_fmed3f(act_apply_t<ACT>(acc[mt][nt][g * 4 + e] * sa[mt]) * is[e], -448.0f, 448.0f);
+            }
+          }
           int wd = 0;
           wd = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], wd, false);
           wd = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], wd, true);
