@@ -40,6 +40,9 @@
 #ifndef F8_EPI3_PARTS
 #define F8_EPI3_PARTS 3
 #endif
+#ifndef F8_EPI3_SCALECVT         // 1: the quantising pass of EPI 3 converts with v_cvt_scalef32_pk_fp8_f32 (no multiply per element)
+#define F8_EPI3_SCALECVT 1
+#endif
 #ifndef F8_LNF_DBG               // timing bisection only (results wrong): 1 unit scale operand, 2 no exponent reads either,
 #define F8_LNF_DBG 0             // 4 no exponent DMA
 #endif
@@ -56,6 +59,7 @@ constexpr int LDS_BYTES = RING + 32768;     // 163840
 
 typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+typedef __attribute__((ext_vector_type(2))) short s16x2_t;
 
 #define LDS_PTR(off) ((__attribute__((address_space(3))) void*)(smem + (off)))
 #define GLOBAL_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -650,7 +654,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
         // |x| < 2^(ex - 126) with ex the biased exponent of the row maximum: e = ex - 134 puts it below 2^8 (e4m3 reaches 448)
         const int ex = (int)((__float_as_uint(a) >> 23) & 0xffu);
         const int eb = max(ex - 7, 0);                            // the E8M0 byte, e + 127
+#if F8_EPI3_SCALECVT
+        mul[mt] = __uint_as_float((unsigned)eb << 23);            // 2^e: the conversion's scale operand
+#else
         mul[mt] = __uint_as_float((unsigned)(254 - eb) << 23);    // 2^-e
+#endif
         const int m = mw0 + mt * 32 + r32e;
         if (wc == 0 && he == 0 && m < p.M) p.out_exp[(size_t)m * p.ld_oexp + (cur.n0 >> 8)] = (unsigned char)eb;
       }
@@ -661,9 +669,17 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
         for (int c = 0; c < 8; ++c) {
           const int nt = c >> 2, g = c & 3;
           const int col = nt * 32 + g * 8 + he * 4;
+#if F8_EPI3_SCALECVT
+          // the conversion divides by the power of two of its scale operand itself (tools/probes/cvt_scalef32_probe.hip)
+          s16x2_t wq = {0, 0};
+          wq = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wq, acc[mt][nt][g * 4 + 0], acc[mt][nt][g * 4 + 1], mul[mt], false);
+          wq = __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(wq, acc[mt][nt][g * 4 + 2], acc[mt][nt][g * 4 + 3], mul[mt], true);
+          const int wd = __builtin_bit_cast(int, wq);
+#else
           int wd = 0;
           wd = __builtin_amdgcn_cvt_pk_fp8_f32(acc[mt][nt][g * 4 + 0] * mul[mt], acc[mt][nt][g * 4 + 1] * mul[mt], wd, false);
           wd = __builtin_amdgcn_cvt_pk_fp8_f32(acc[mt][nt][g * 4 + 2] * mul[mt], acc[mt][nt][g * 4 + 3] * mul[mt], wd, true);
+#endif
           *(int*)(tr + r32e * 80 + col) = wd;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
