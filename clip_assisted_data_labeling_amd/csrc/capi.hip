@@ -1226,7 +1226,7 @@ int jpegdec_destroy(jpegdec_t d) {
 int jpegdec_plan(jpegdec_t d, const void* const* files, const size_t* sizes, int n, int* status, int* widths, int* heights,
                  unsigned long long* rgb_offsets, unsigned long long* rgb_bytes) {
   if (!d || !files || !sizes || !status || !widths || !heights || !rgb_offsets || !rgb_bytes) return fail("jpegdec_plan: NULL argument");
-  if (n < 0) return fail("jpegdec_plan: n %d < 0", n);
+  if (n < 0 || n > 65535) return fail("jpegdec_plan: %d files (0 .. 65535 per call: one grid row per image)", n);
   ce_jpegdec_plan(d->st, files, sizes, n, status, widths, heights, rgb_offsets, rgb_bytes);
   return 0;
 }

@@ -38,12 +38,13 @@ class GpuJpegDecoder:
         return self.lib.jpegdec_reason(int(code)).decode()
 
     @torch.no_grad()
-    def decode(self, files: Sequence[bytes], max_batch_pixels: int = 2_000_000_000) -> Tuple[List[Optional[torch.Tensor]], List[int]]:
+    def decode(self, files: Sequence[bytes], max_batch_pixels: int = 2_000_000_000, max_batch_files: int = 16384) -> Tuple[List[Optional[torch.Tensor]], List[int]]:
         """files: the bytes of each file -> (images, status): images[i] a uint8 [H, W, 3] tensor on the GPU (a view into a
         batch buffer) or None when status[i] != 0 (1..12: not decodable here, see `reason`; >= 100: corrupt or truncated entropy
         data).  The device works on all files of a call at once -- the entropy decoder is one serial stream per file, so its
         throughput IS the number of files in flight -- except that a call is split into groups of at most `max_batch_pixels`
-        pixels (7.5 bytes of device scratch + output per pixel: 15 GB at the default)."""
+        pixels (7.5 bytes of device scratch + output per pixel: 15 GB at the default) and `max_batch_files` files (the C entry point takes
+        65535 per call)."""
         n = len(files)
         if n == 0:
             return [], []
@@ -53,9 +54,9 @@ class GpuJpegDecoder:
         start = 0
         while start < n:
             # headers of the rest (host only, microseconds per file), then as many files as fit the pixel budget
-            m = n - start
-            ptrs = (ctypes.c_char_p * m)(*bufs[start:])
-            sizes = (ctypes.c_size_t * m)(*[len(b) for b in bufs[start:]])
+            m = min(n - start, max(1, min(int(max_batch_files), 65535)))
+            ptrs = (ctypes.c_char_p * m)(*bufs[start:start + m])
+            sizes = (ctypes.c_size_t * m)(*[len(b) for b in bufs[start:start + m]])
             status = (ctypes.c_int * m)()
             widths = (ctypes.c_int * m)()
             heights = (ctypes.c_int * m)()

@@ -267,7 +267,8 @@ int clipenc_mfma_stream_probe(int device, int fp8, const void* operands_dev, flo
 typedef struct jpegdec_s* jpegdec_t;
 int jpegdec_create(int device, jpegdec_t* out);
 int jpegdec_destroy(jpegdec_t d);
-/* files[i] / sizes[i]: the file bytes in host memory (they must stay valid until jpegdec_run returns).  status[i]: 0 = will be
+/* files[i] / sizes[i]: the file bytes in host memory (they must stay valid until jpegdec_run returns); at most 65535 files per
+ * call.  status[i]: 0 = will be
  * decoded, 1..12 = why not (jpegdec_reason); widths / heights: for every file whose header could be read; rgb_offsets[i]: where
  * image i's uint8 [height][width][3] starts in an output buffer of *rgb_bytes bytes (images 256-byte aligned). */
 int jpegdec_plan(jpegdec_t d, const void* const* files, const size_t* sizes, int n, int* status, int* widths, int* heights,

@@ -204,3 +204,27 @@ def test_any_sampling_on_the_device_equals_pillow(gpu):
     for i, (img, data) in enumerate(zip(images, files)):
         assert np.array_equal(img.cpu().numpy(), _pil(data)), i
     dec.close()
+
+
+def test_a_call_is_split_by_file_count_and_by_pixels(gpu):
+    """GpuJpegDecoder.decode groups the files of a call (at most max_batch_files and max_batch_pixels per device batch; the C entry
+    point takes 65535 files): the result does not depend on the grouping."""
+    import ctypes
+    from clip_assisted_data_labeling_amd import _lib
+    rs = np.random.RandomState(3)
+    files = [_jpeg(_smooth(rs, 40 + 7 * i, 50 + 5 * i), quality=85, subsampling=i % 3) for i in range(9)] + [b"not a jpeg"]
+    dec = GpuJpegDecoder(gpu)
+    whole, st0 = dec.decode(files)
+    for kw in ({"max_batch_files": 3}, {"max_batch_files": 1}, {"max_batch_pixels": 5000}):
+        parts, st1 = dec.decode(files, **kw)
+        assert st1 == st0 and st0[:9] == [0] * 9 and st0[9] == 1
+        for a, b in zip(whole, parts):
+            assert (a is None and b is None) or torch.equal(a, b)
+    for im, f in zip(whole[:9], files):
+        assert np.array_equal(im.cpu().numpy(), _pil(f))
+    n = 65536                                                  # one file too many for a single plan: refused with a message
+    arr = (ctypes.c_char_p * n)(); sizes = (ctypes.c_size_t * n)(); ints = (ctypes.c_int * n)(); offs = (ctypes.c_ulonglong * n)()
+    total = ctypes.c_ulonglong()
+    assert dec.lib.jpegdec_plan(dec.handle, arr, sizes, n, ints, ints, ints, offs, ctypes.byref(total)) != 0
+    assert b"65535" in _lib.load().clipenc_last_error()
+    dec.close()
