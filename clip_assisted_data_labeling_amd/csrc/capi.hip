@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -67,6 +68,17 @@ struct LayerDev {
 struct LayerDev8 {                                       // CLIPENC_PREC_FP8: e4m3 [N][K] + per-output-channel scale [N]
   uint8_t *w_qkv, *w_out, *w_fc, *w_proj;
   float *s_qkv, *s_out, *s_fc, *s_proj;
+  uint8_t* e_all;                                        // fused tower (widths <= 1024): the scales are powers of two; their E8M0 bytes, [3 width | width | mlp_dim | width]
+  const uint8_t* wexp(const float* sw, size_t D, size_t M) const {   // the exponent bytes that belong to scale pointer sw (may point into an array)
+    const float* base[4] = {s_qkv, s_out, s_fc, s_proj};
+    const size_t n[4] = {3 * D, D, M, D};
+    size_t off = 0;
+    for (int i = 0; i < 4; ++i) {
+      if (sw >= base[i] && sw < base[i] + n[i]) return e_all + off + (sw - base[i]);
+      off += n[i];
+    }
+    return nullptr;
+  }
   float* is_hid;                                         // [mlp_dim] 1 / static scale of the MLP hidden columns (folded into w_proj)
   float* is_attn;                                        // [width]   1 / static scale of the attention output (folded into w_out)
   float *cs_qkv, *cs_fc;                                 // [3 width], [mlp_dim] column sums of the DEQUANTISED LN-folded rows (the folded mean term)
@@ -280,11 +292,12 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       return err;
     };
     // LayerNorm-folded consumer on M rows of x8, `rstride` rows of the stream apart; row constants `ld_row` floats apart
+    const LayerDev8* curQ = nullptr;                        // (the layer whose weights the lambdas below are handed)
     auto lnf = [&](int M, int rstride, const uint8_t* W8, const float* sw, const float* cs, const float* bias, int N, int act, void* out,
                    int ldo, int epi, const float* out_inv, int ld_row, int kind) -> hipError_t {
       GemmParams q{};
       q.A = e->x8; q.lda = rstride * Dw; q.W = W8; q.ldw = Dw; q.M = M; q.N = N; q.K = Dw; q.out = out; q.ldo = ldo; q.bias = bias;
-      q.scale_w = sw; q.colsum = cs; q.act = act; q.out_inv_scale = out_inv;
+      q.scale_w = sw; q.w_exp = curQ->wexp(sw, (size_t)Dw, (size_t)Mh); q.colsum = cs; q.act = act; q.out_inv_scale = out_inv;
       q.a_exp = e->xe8; q.ld_aexp = rstride * 4; q.row_r = e->rr8; q.row_d = e->rd8; q.ld_row = ld_row;
       return run8(q, epi, kind, -1);
     };
@@ -293,7 +306,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
                      bool quant, int stats_ld, int sub) -> hipError_t {
       GemmParams q{};
       q.A = A8; q.lda = lda; q.W = W8; q.ldw = K; q.M = M; q.N = Dw; q.K = K; q.out = e->x; q.ldo = rstride * Dw; q.bias = bias;
-      q.scale_w = sw; q.act = -1; q.resid = e->x;
+      q.scale_w = sw; q.w_exp = curQ->wexp(sw, (size_t)Dw, (size_t)Mh); q.act = -1; q.resid = e->x;
       q.out8 = e->x8; q.ld8 = rstride * Dw; q.out_exp = e->xe8; q.ld_oexp = rstride * 4; q.stats_out = e->st8; q.stats_ld = stats_ld;
       return run8(q, quant ? EPI_RESID_Q : EPI_RESID, PK_GEMM8_RESID, sub);
     };
@@ -313,6 +326,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     for (int l = 0; l < n_layers; ++l) {
       const LayerDev& L = e->layers[l];
       const LayerDev8& Q = e->layers8[l];
+      curQ = &Q;
       const bool last = l == n_layers - 1;
       HIP_TRY(consts(st_in, parts_in, Tp, T));
       if (cls_only_last && last) {
@@ -675,13 +689,15 @@ int clipenc_set_precision(clipenc_t e, int precision) {
     const size_t D = g.width, M = g.mlp_dim;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes, 256); return o; };
-    struct LOff { size_t w[4], s[4], is_hid, is_attn, cs_qkv, cs_fc; };
+    struct LOff { size_t w[4], s[4], is_hid, is_attn, cs_qkv, cs_fc, e_all; };
+    const int pow2 = fp8_fused(g) ? 1 : 0;                  // the fused tower's GEMMs take the weight scale as an MFMA block exponent
     std::vector<LOff> lo(g.layers);
     const size_t rows[4] = {3 * D, D, M, D}, cols[4] = {D, D, D, M};
     for (auto& o : lo) {
       for (int i = 0; i < 4; ++i) { o.w[i] = take(rows[i] * cols[i]); o.s[i] = take(rows[i] * 4); }
       o.is_hid = take(M * 4); o.is_attn = take(D * 4);
       o.cs_qkv = take(3 * D * 4); o.cs_fc = take(M * 4);
+      o.e_all = take(5 * D + M);
     }
     HIP_TRY(e->weights8.alloc(off));
     DevBuf tmp;                                            // [mlp_dim] static scales + fp32 [width][mlp_dim] folded w_proj
@@ -703,7 +719,7 @@ int clipenc_set_precision(clipenc_t e, int precision) {
       uint8_t* dst[4] = {Q.w_qkv, Q.w_out, Q.w_fc, Q.w_proj};
       float* sc[4] = {Q.s_qkv, Q.s_out, Q.s_fc, Q.s_proj};
       for (int i = 0; i < 3; i += 2)
-        HIP_TRY(ce_quant_rows_fp8(src[i], 0, cols[i], dst[i], cols[i], sc[i], (int)rows[i], (int)cols[i], 0, 0.f, nullptr));
+        HIP_TRY(ce_quant_rows_fp8(src[i], 0, cols[i], dst[i], cols[i], sc[i], (int)rows[i], (int)cols[i], 0, 0.f, nullptr, pow2));
       // the folded mean term multiplies the column sums of the rows the GEMM actually multiplies by: the dequantised ones
       Q.cs_qkv = (float*)(db + lo[l].cs_qkv); Q.cs_fc = (float*)(db + lo[l].cs_fc);
       HIP_TRY(ce_colsum_fp8(Q.w_qkv, Q.s_qkv, (int)(3 * D), (int)D, Q.cs_qkv, nullptr));
@@ -712,12 +728,20 @@ int clipenc_set_precision(clipenc_t e, int precision) {
       Q.is_attn = (float*)(db + lo[l].is_attn);
       HIP_TRY(ce_static_scale(L.w_qkv + 2 * D * D, L.b_qkv + 2 * D, (int)D, (int)D, s_hid, Q.is_attn, nullptr));
       HIP_TRY(ce_scale_cols(L.w_out, s_hid, folded, (int)D, (int)D, nullptr));
-      HIP_TRY(ce_quant_rows_fp8(folded, 1, D, Q.w_out, D, Q.s_out, (int)D, (int)D, 0, 0.f, nullptr));
+      HIP_TRY(ce_quant_rows_fp8(folded, 1, D, Q.w_out, D, Q.s_out, (int)D, (int)D, 0, 0.f, nullptr, pow2));
       // MLP hidden: static column scales from the LN-folded FC1 rows; their product with w_proj's columns is what gets quantised
       Q.is_hid = (float*)(db + lo[l].is_hid);
       HIP_TRY(ce_static_scale(L.w_fc, L.b_fc, (int)M, (int)D, s_hid, Q.is_hid, nullptr));
       HIP_TRY(ce_scale_cols(L.w_proj, s_hid, folded, (int)D, (int)M, nullptr));
-      HIP_TRY(ce_quant_rows_fp8(folded, 1, M, Q.w_proj, M, Q.s_proj, (int)D, (int)M, 0, 0.f, nullptr));
+      HIP_TRY(ce_quant_rows_fp8(folded, 1, M, Q.w_proj, M, Q.s_proj, (int)D, (int)M, 0, 0.f, nullptr, pow2));
+      Q.e_all = (uint8_t*)(db + lo[l].e_all);
+      {
+        size_t eo = 0;
+        for (int i = 0; i < 4; ++i) {
+          HIP_TRY(ce_scale_exponents(sc[i], Q.e_all + eo, (int)rows[i], nullptr, nullptr));
+          eo += rows[i];
+        }
+      }
     }
     HIP_TRY(hipStreamSynchronize(nullptr));
     e->layers8.swap(l8);
@@ -1122,7 +1146,9 @@ int clipenc_op_gemm_nt(const void* a_dev, const void* w_dev, int m, int n, int k
 int clipenc_op_quant_rows_fp8(const void* in_dev, int in_f32, int n_rows, int k, int ln, float eps, void* out8_dev,
                               float* scale_dev, void* stream) {
   if (!in_dev || !out8_dev || !scale_dev) return fail("NULL device pointer");
-  hipError_t err = ce_quant_rows_fp8(in_dev, in_f32, (size_t)k, out8_dev, (size_t)k, scale_dev, n_rows, k, ln, eps, (hipStream_t)stream);
+  if (ln < 0 || ln > 2) return fail("quant_rows_fp8: ln = %d (0 plain, 1 LayerNorm first, 2 plain with power-of-two scales)", ln);
+  hipError_t err = ce_quant_rows_fp8(in_dev, in_f32, (size_t)k, out8_dev, (size_t)k, scale_dev, n_rows, k, ln == 1, eps, (hipStream_t)stream,
+                                     ln == 2);
   if (err != hipSuccess) return fail("quant_rows_fp8(%d,%d) failed: %s", n_rows, k, hipGetErrorString(err));
   return 0;
 }
@@ -1176,6 +1202,27 @@ int clipenc_op_row_norm_consts(const float* stats_dev, int parts, int ld, int n_
   return 0;
 }
 
+namespace {
+// The stand-alone block-exponent GEMM ops take float weight scales like the other fp8 ops; the kernels want their E8M0 bytes
+// (gemm.h: w_exp).  Derived here into one scratch per process (grown as needed, never shrunk): these ops are developer / test
+// entry points, one caller at a time.
+std::mutex g_opexp_mu;
+unsigned char* g_opexp = nullptr; size_t g_opexp_cap = 0; int g_opexp_dev = -1;
+hipError_t op_weight_exponents(const float* scale_w_dev, int n, hipStream_t st, const unsigned char** out) {
+  std::lock_guard<std::mutex> lock(g_opexp_mu);
+  int dev = 0;
+  if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return e;
+  if (dev != g_opexp_dev || g_opexp_cap < (size_t)n) {
+    if (g_opexp) { (void)hipDeviceSynchronize(); (void)hipFree(g_opexp); g_opexp = nullptr; g_opexp_cap = 0; }
+    const size_t want = std::max<size_t>((size_t)n, 65536);
+    if (hipError_t e = hipMalloc((void**)&g_opexp, want); e != hipSuccess) return e;
+    g_opexp_cap = want; g_opexp_dev = dev;
+  }
+  *out = g_opexp;
+  return ce_scale_exponents(scale_w_dev, g_opexp, n, nullptr, st);
+}
+}  // namespace
+
 int clipenc_op_gemm_fp8_lnf(const void* a8_dev, const void* exp_dev, const void* w8_dev, int m, int n, int k,
                             const float* row_r_dev, const float* row_d_dev, const float* scale_w_dev, const float* colsum_dev,
                             const float* bias_dev, int act, const float* out_inv_scale_dev, void* out_dev, void* stream) {
@@ -1183,6 +1230,8 @@ int clipenc_op_gemm_fp8_lnf(const void* a8_dev, const void* exp_dev, const void*
   GemmParams p{};
   p.A = a8_dev; p.lda = k; p.W = w8_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = out_dev; p.ldo = n; p.bias = bias_dev;
   p.scale_w = scale_w_dev; p.colsum = colsum_dev; p.act = act; p.out_inv_scale = out_inv_scale_dev;
+  if (!scale_w_dev || n < 1) return fail("gemm_fp8_lnf: NULL weight scales");
+  HIP_TRY(op_weight_exponents(scale_w_dev, n, (hipStream_t)stream, &p.w_exp));
   p.a_exp = (const unsigned char*)exp_dev; p.ld_aexp = 4; p.row_r = row_r_dev; p.row_d = row_d_dev; p.ld_row = 1;
   FP8_DBG(p);
   hipError_t err = ce_gemm_fp8(p, out_inv_scale_dev ? EPI_STORE_FP8 : EPI_STORE_BF16, (hipStream_t)stream);
@@ -1196,6 +1245,8 @@ int clipenc_op_gemm_fp8_resid_q(const void* a8_dev, const void* w8_dev, int m, i
   GemmParams p{};
   p.A = a8_dev; p.lda = k; p.W = w8_dev; p.ldw = k; p.M = m; p.N = n; p.K = k; p.out = x_inout_dev; p.ldo = n; p.bias = bias_dev;
   p.scale_w = scale_w_dev; p.act = -1; p.resid = x_inout_dev;
+  if (!scale_w_dev || n < 1) return fail("gemm_fp8_resid_q: NULL weight scales");
+  HIP_TRY(op_weight_exponents(scale_w_dev, n, (hipStream_t)stream, &p.w_exp));
   p.out8 = out8_dev; p.ld8 = n; p.out_exp = (unsigned char*)exp_dev; p.ld_oexp = 4; p.stats_out = stats_dev; p.stats_ld = stats_ld;
   FP8_DBG(p);
   hipError_t err = ce_gemm_fp8(p, EPI_RESID_Q, (hipStream_t)stream);

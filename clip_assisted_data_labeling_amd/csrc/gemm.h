@@ -33,6 +33,8 @@ struct GemmParams {
   // fp8 path (gemm_fp8.hip): out = acc * scale_a[m] * scale_w[n] + bias[n]
   const float* scale_a;          // [M] per-token activation scale (NULL: 1)
   const float* scale_w;          // [N] per-output-channel weight scale
+  const unsigned char* w_exp;    // [N] block-exponent consumers / producer (a_exp != NULL or EPI_RESID_Q): scale_w[n] = 2^(w_exp[n] - 127), a
+                                 //     power of two, applied by the MFMA as the weight rows' block scale (no multiply in the epilogue)
   const float* out_inv_scale;    // [N] EPI_STORE_FP8: out8[m][n] = e4m3(value * out_inv_scale[n])  (static per-column scale)
   // fp8 path, block-exponent rows (the residual stream of the fp8 tower): an e4m3 row carries one E8M0 exponent byte per 256
   // columns, x[m][k] ~ a8[m][k] * 2^(exp[m][k / 256] - 127), applied by the scaled MFMA itself.

@@ -26,6 +26,9 @@
 // tile's own 256 columns, no row-wide reduction across tiles, and the LayerNorm of the row is folded into the consumer's
 // epilogue from row statistics (gemm.h).  It replaces the separate LayerNorm-quantise pass over the residual stream
 // (quant_fp8.hip: 1.6 GB of HBM traffic per call, twice per block).
+// In those instantiations the WEIGHT scales are powers of two (capi.hip quantises the fused tower's weights that way) and ride in
+// the same MFMA as the block scale of the weight operand (p.w_exp: one E8M0 byte per output channel, 64 per wave and tile from one
+// scalar load): the accumulator comes out scaled by scale_w[n] and the epilogue has no multiply by it.
 #include "common.h"
 #include "gemm.h"
 
@@ -118,6 +121,9 @@ template <int EPI, int ACT, bool LNF>
 __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   constexpr bool ZERO_C_OK = ZERO_C_SET(EPI, ACT) && (!LNF || F8_LNF_ZERO_C);
   constexpr bool RES = EPI == 1 || EPI == 3;
+  // the fused tower's instantiations: the weight scales are powers of two and ride in the MFMA as the weight rows' block scale
+  // (p.w_exp, one E8M0 byte per output channel), so the epilogue has no multiply by scale_w
+  constexpr bool WEXP = LNF || EPI == 3;
   // wave image, LNF: [0,256) weight scales, [256,512) column sums, [512,768) biases, [1024,1536) row_r, [1536,2048) row_d,
   // [2560,2816) inverse output scales (EPI 2), [3072,3584) the NEXT tile's exponent dwords (row-major, landed by DMA during this
   // tile's last two stages), [3584,4096) this tile's exponent dwords (read by every phase)
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       const int j = (F8_MMA_ORDER && (i & 1)) ? 1 - j_ : j_;      /* serpentine: one operand register set changes per MFMA (gemm_persist.hip) */ \
       acc[(half) * 2 + i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(fb[kh * 2 + j], fa[kh * 2 + i],      \
                                    ((ZC) && kh == 0) ? zero16 : acc[(half) * 2 + i][j], 0, 0,                        \
-                                                                  0, 0x7f7f7f7f, 0, (LNF && !(F8_LNF_DBG & 1)) ? sc[i] : 0x7f7f7f7f); \
+                                                                  0, WEXP ? wsc[j] : 0x7f7f7f7f, 0, (LNF && !(F8_LNF_DBG & 1)) ? sc[i] : 0x7f7f7f7f); \
     }                                                                                       \
     __builtin_amdgcn_s_setprio(0);                                                          \
   } while (0)
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   // the column constants (weight scales, biases, EPI 2: inverse output scales) of the tile are staged into the wave's image at
   // the top of the tile (below): those pieces sit between the previous tile's stores and the first waits (the per-row
   // scale pieces, issued only with per-token scales, are not counted: the wait is then two pieces stricter than need be)
-  constexpr int CB_PIECES = EPI == 4 ? 0 : LNF ? (EPI == 2 ? 8 : 7) : (EPI == 2 ? 3 : 2);
+  constexpr int CB_PIECES = EPI == 4 ? 0 : LNF ? (EPI == 2 ? 7 : 6) : EPI == 3 ? 1 : (EPI == 2 ? 3 : 2);
 
   // ---- cold prologue of the first tile ----
   // E_ROWS(m0v, dst): the exponent dwords of the wave's 128 rows of the tile at m0v, two DMA pieces (lane = row)
@@ -279,6 +285,26 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     i32x8_t fa[4], fb[4];
     [[maybe_unused]] int sc[2];
+    [[maybe_unused]] int wsc[2] = {0x7f7f7f7f, 0x7f7f7f7f};
+    if constexpr (WEXP) {
+      // the exponent bytes of the wave's 64 weight rows: 64 consecutive bytes at a wave-uniform address, fetched as scalar loads
+      // (lgkmcnt, not the vmcnt of the DMA pipeline) and picked per lane: lane (r, h) supplies row r of its 32-row fragment,
+      // byte 0 of the register is what opsel 0 selects
+      typedef __attribute__((address_space(4))) const u32x4_t cu32x4_t;
+      const cu32x4_t* ep = (const cu32x4_t*)(uintptr_t)(p.w_exp + cur.n0 + wc * 64);
+      const u32x4_t q0 = ep[0], q1 = ep[1], q2 = ep[2], q3 = ep[3];
+      int lane_w;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_w));
+      const int rw = lane_w & 31, bsh = (rw & 3) * 8;
+      // dword rw >> 2 of the eight: branch-free selects (the plain ?: form compiled into exec-masked branches)
+      const unsigned m1 = 0u - ((unsigned)(rw >> 2) & 1u), m2 = 0u - ((unsigned)(rw >> 3) & 1u), m4 = 0u - ((unsigned)(rw >> 4) & 1u);
+#define SEL_(x, y, m) ((x) ^ (((x) ^ (y)) & (m)))
+#define PICK_(a, b) ((int)(SEL_(SEL_(SEL_((a)[0], (a)[1], m1), SEL_((a)[2], (a)[3], m1), m2),                                   \
+                                SEL_(SEL_((b)[0], (b)[1], m1), SEL_((b)[2], (b)[3], m1), m2), m4) >> bsh))
+      wsc[0] = PICK_(q0, q1); wsc[1] = PICK_(q2, q3);
+#undef PICK_
+#undef SEL_
+    }
 
     // Column constants of this tile's 64 columns per wave and the per-token scales of its 128 rows, by LDS-DMA into the wave's
     // (idle until the epilogue) 4-KiB image: [0, 256) weight scales, [1024, 1280) biases, [2560, 2816) inverse output scales
@@ -292,7 +318,6 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       if constexpr (LNF) {
         // one dword per lane = the wave's 64 columns / 64 of its 128 rows per piece
         const unsigned coff4 = (unsigned)(cur.n0 + wc * 64 + lane_t) * 4u;
-        glds4_at((const char*)p.scale_w, coff4, ti);
         glds4_at((const char*)p.colsum, coff4, ti + 256);
         glds4_at((const char*)p.bias, coff4, ti + 512);
         if constexpr (EPI == 2) glds4_at((const char*)p.out_inv_scale, coff4, ti + 2560);
@@ -304,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
         glds4_at((const char*)p.row_d, ro1, ti + 1792);
       } else {
         const unsigned coff = (unsigned)(cur.n0 + wc * 64) * 4u + (unsigned)(lane_t & 15) * 16u;
-        glds16_at((const char*)p.scale_w, coff, ti);
+        if constexpr (!WEXP) glds16_at((const char*)p.scale_w, coff, ti);
         glds16_at((const char*)p.bias, coff, ti + 1024);
         if constexpr (EPI == 2) glds16_at((const char*)p.out_inv_scale, coff, ti + 2560);
         if (p.scale_a) {
@@ -485,8 +510,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) {
         const int n = nt * 32 + r32e;                             // the lane's column of this 32-column tile
-        const float swn = *(const float*)(tr + SW_OFF + n * 4);
-        const float isw = swn != 0.f ? __builtin_amdgcn_rcpf(swn) : 0.f;   // (a zero weight scale zeroes the column, bias included)
+        float isw = 1.0f;                                        // WEXP: the accumulator already carries the weight scale
+        if constexpr (!WEXP) {
+          const float swn = *(const float*)(tr + SW_OFF + n * 4);
+          isw = swn != 0.f ? __builtin_amdgcn_rcpf(swn) : 0.f;   // (a zero weight scale zeroes the column, bias included)
+        }
         const float cb = *(const float*)(tr + BS_OFF + n * 4) * isw;
         float ca = 0.f;
         if constexpr (LNF) ca = *(const float*)(tr + CS_OFF + n * 4) * isw;
@@ -504,6 +532,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       // pass 1 (keeps registers low): acc <- acc * sw[n], so that pass 2 only multiplies by sa[m]; the scales of column group
       // c + 1 are read before group c is computed (one LDS latency per tile, not eight)
 #define NL(c) (((c) >> 2) * 32 + ((c) & 3) * 8 + he * 4)          /* column within the wave's 64 */
+      if constexpr (!WEXP) {
       f32x4_t sw_n = *(const f32x4_t*)(tr + SW_OFF + NL(0) * 4);
 #pragma unroll
       for (int c = 0; c < 8; ++c) {
@@ -516,6 +545,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
         }
         // the results exist HERE: without a use hipcc sinks this arithmetic into pass 2 and keeps the constants live until then
         if ((c & 3) == 3) asm volatile("" : "+v"(acc[0][c >> 2]), "+v"(acc[1][c >> 2]), "+v"(acc[2][c >> 2]), "+v"(acc[3][c >> 2]));
+      }
       }
 #undef NL
     }
@@ -590,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
         const int nt = c >> 2, g = c & 3;
         f32x4_t v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[mt][nt][g * 4 + e] * sa[mt];
+        for (int e = 0; e < 4; ++e) v[e] = EPI == 3 ? acc[mt][nt][g * 4 + e] : acc[mt][nt][g * 4 + e] * sa[mt];   // (EPI 3: no row scale)
         if constexpr (RES) {
           const uint2 rr = *(const uint2*)TW_ADDR(c);
           v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
@@ -773,14 +803,14 @@ hipError_t ce_gemm_fp8(const GemmParams& p, int epi, hipStream_t stream) {
   }
   if (epi == EPI_RESID_Q) {
     // one exponent byte per (row, 256-column tile), four of them in a dword: N <= 1024
-    if (!p.resid || p.scale_a || !p.out8 || !p.out_exp || !p.stats_out || p.N > 1024 || p.ld8 < p.N || p.ld8 % 16 != 0 || p.ld_oexp < 4 ||
+    if (!p.resid || p.scale_a || !p.w_exp || !p.out8 || !p.out_exp || !p.stats_out || p.N > 1024 || p.ld8 < p.N || p.ld8 % 16 != 0 || p.ld_oexp < 4 ||
         p.stats_ld < p.M || ((uintptr_t)p.out8 & 15) || ((uintptr_t)p.stats_out & 7))
       return hipErrorInvalidValue;
     return launch_fp8<3, -1>(p, stream);
   }
   if (p.a_exp) {
     // block-exponent A rows with the folded LayerNorm; per-token scales do not combine with it
-    if (p.scale_a || !p.row_r || !p.row_d || !p.colsum || p.K > 1024 || p.ld_aexp < 4 || p.ld_aexp % 4 != 0 || p.ld_row < 1 ||
+    if (p.scale_a || !p.w_exp || !p.row_r || !p.row_d || !p.colsum || p.K > 1024 || p.ld_aexp < 4 || p.ld_aexp % 4 != 0 || p.ld_row < 1 ||
         ((uintptr_t)p.a_exp & 3) || (size_t)(p.M - 1) * p.ld_aexp >= 0x7fffffffull || (size_t)(p.M - 1) * p.ld_row * 4 >= 0x7fffffffull)
       return hipErrorInvalidValue;
     if (epi == EPI_STORE_FP8) {

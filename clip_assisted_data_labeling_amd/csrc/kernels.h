@@ -24,13 +24,14 @@ hipError_t ce_head(const void* x, const float* gamma, const float* beta, const f
 
 // quant_fp8.hip
 hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out8, size_t ld_out, float* scale, int n_rows,
-                             int K, int ln, float eps, hipStream_t stream);
+                             int K, int ln, float eps, hipStream_t stream, int pow2 = 0);
 // block-exponent rows (gemm.h): the standalone quantiser (the tower's first block; later blocks are quantised by the GEMM that
 // produces them), the per-row constants of the folded LayerNorm, the column sums of dequantised fp8 weight rows
 hipError_t ce_quant_block_fp8(const void* in, size_t ld_in, void* out8, size_t ld_out, void* exps, size_t ld_exp, float* stats,
                               int n_rows, int K, hipStream_t stream);
 hipError_t ce_row_norm_consts(const float* stats, int parts, size_t ld, int n_rows, int width, float eps, float* row_r, float* row_d,
                               int ld_row, hipStream_t stream);
+hipError_t ce_scale_exponents(const float* scale, unsigned char* exp_out, int n, unsigned* bad, hipStream_t stream);
 hipError_t ce_colsum_fp8(const void* W8, const float* scale, int N, int K, float* colsum, hipStream_t stream);
 hipError_t ce_static_scale(const void* W_bf16, const float* bias, int N, int K, float* s, float* inv_s, hipStream_t stream);
 hipError_t ce_scale_cols(const void* W_bf16, const float* s, float* out_f32, int N, int K, hipStream_t stream);

@@ -41,7 +41,7 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float (
 // in flight to approach the HBM rate), rows strided over the grid.
 template <typename TIN, bool LN, int CH, int NR>
 __global__ __launch_bounds__(256) void quant_rows_kernel(const TIN* __restrict__ in, size_t ld_in, uint8_t* __restrict__ out,
-                                                         size_t ld_out, float* __restrict__ scale, int n_rows, int K, float eps) {
+                                                         size_t ld_out, float* __restrict__ scale, int n_rows, int K, float eps, int pow2) {
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
   for (int row0 = wave * NR; row0 < n_rows; row0 += n_waves * NR) {
@@ -90,8 +90,16 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const TIN* __restrict__
 #pragma unroll
         for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[r][ci][j]));
       amax = wave_max(amax);
-      const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
-      const float inv = amax > 0.f ? 448.0f / amax : 0.f;
+      float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+      float inv = amax > 0.f ? 448.0f / amax : 0.f;
+      if (pow2 && amax > 0.f) {
+        // the scale rounded UP to a power of two (the weights of the fused fp8 tower: the exponent rides in the MFMA's block
+        // scale, gemm_fp8.hip); e4m3 keeps its relative precision, only its subnormal threshold moves by less than a bit
+        const unsigned b = __float_as_uint(sc);
+        const unsigned e = min(max((b >> 23) + ((b & 0x7fffffu) ? 1u : 0u), 1u), 254u);
+        sc = __uint_as_float(e << 23);
+        inv = __uint_as_float((254u - e) << 23);
+      }
       uint8_t* dst = out + (size_t)row * ld_out;
 #pragma unroll
       for (int ci = 0; ci < CH; ++ci) {
@@ -362,6 +370,24 @@ hipError_t ce_row_norm_consts(const float* stats, int parts, size_t ld, int n_ro
   return hipGetLastError();
 }
 
+namespace {
+// E8M0 byte (the biased exponent) of every scale: what the MFMA applies as the block scale of the weight rows when the scales are
+// powers of two (ce_quant_rows_fp8 with pow2).  `bad` counts the scales that are not (mantissa bits set, zero, infinity, NaN).
+__global__ void scale_exponents_kernel(const float* __restrict__ scale, unsigned char* __restrict__ out, int n, unsigned* __restrict__ bad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned b = __float_as_uint(scale[i]);
+  const unsigned e = (b >> 23) & 0xffu;
+  out[i] = (unsigned char)e;
+  if (bad && ((b & 0x807fffffu) || e == 0u || e == 255u)) atomicAdd(bad, 1u);
+}
+}  // namespace
+
+hipError_t ce_scale_exponents(const float* scale, unsigned char* exp_out, int n, unsigned* bad, hipStream_t stream) {
+  hipLaunchKernelGGL(scale_exponents_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, scale, exp_out, n, bad);
+  return hipGetLastError();
+}
+
 hipError_t ce_colsum_fp8(const void* W8, const float* scale, int N, int K, float* colsum, hipStream_t stream) {
   if (N < 1 || K < 4 || K % 4 != 0 || ((uintptr_t)W8 & 3)) return hipErrorInvalidValue;
   hipLaunchKernelGGL(colsum_fp8_kernel, dim3((N + 3) / 4), dim3(256), 0, stream, (const uint8_t*)W8, scale, N, K, colsum);
@@ -370,9 +396,9 @@ hipError_t ce_colsum_fp8(const void* W8, const float* scale, int N, int K, float
 
 // in: bf16 (in_f32 == 0) or fp32 rows of K elements (K % 8 == 0, K <= 4096); ln != 0 normalises each row first.
 hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out8, size_t ld_out, float* scale, int n_rows,
-                             int K, int ln, float eps, hipStream_t stream) {
+                             int K, int ln, float eps, hipStream_t stream, int pow2) {
   if (n_rows < 1 || K < 8 || K % 8 != 0 || K > QMAXC * 512 || ld_in < (size_t)K || ld_out < (size_t)K) return hipErrorInvalidValue;
-  if (!in_f32 && ln && K % 128 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in | (uintptr_t)out8) % 16 == 0) {
+  if (!pow2 && !in_f32 && ln && K % 128 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in | (uintptr_t)out8) % 16 == 0) {
     // the tower's LayerNorm-quantise pass: 16 lanes per row (quant_ln16_kernel)
     const int waves = (n_rows + 3) / 4;
     dim3 grid((unsigned)std::min((waves + 3) / 4, 16384)), block(256);
@@ -390,7 +416,7 @@ hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out
     const int waves = (n_rows + (NR) - 1) / (NR);                                           \
     dim3 grid((unsigned)std::min((waves + 3) / 4, 8192)), block(256);                       \
     hipLaunchKernelGGL((quant_rows_kernel<T, LNV, CH, NR>), grid, block, 0, stream, (const T*)in, ld_in, (uint8_t*)out8, ld_out, scale, \
-                       n_rows, K, eps);                                                     \
+                       n_rows, K, eps, pow2);                                                     \
   } while (0)
 #define QDISPATCH(T, LNV)                                                                   \
   do {                                                                                      \

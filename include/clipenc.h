@@ -294,7 +294,8 @@ int jpegdec_probe(const void* file, size_t size, int* width, int* height, int* n
 int clipenc_op_gemm_nt(const void* a_dev, const void* w_dev, int m, int n, int k, int dtype, int epi,
                        const float* bias_dev, void* out_dev, void* stream);
 /* Row quantisation to e4m3: out8[r][k] = fp8(f(in[r][k]) * 448 / absmax_r), scale[r] = absmax_r / 448, f = identity or
- * (ln != 0) the LayerNorm normalisation without affine.  in: bf16 (in_f32 == 0) or fp32 [n_rows][k]; k % 8 == 0, k <= 4096 */
+ * (ln == 1) the LayerNorm normalisation without affine; ln == 2: f = identity and the scale rounded UP to a power of two (what the
+ * block-exponent GEMMs below want of their weight scales).  in: bf16 (in_f32 == 0) or fp32 [n_rows][k]; k % 8 == 0, k <= 4096 */
 int clipenc_op_quant_rows_fp8(const void* in_dev, int in_f32, int n_rows, int k, int ln, float eps, void* out8_dev,
                               float* scale_dev, void* stream);
 /* out_bf16[M][N] = act((A8[M][K] . W8[N][K]^T) * scale_a[M] * scale_w[N] + bias[N]) (+ resid_bf16[M][N] when given,
@@ -319,14 +320,18 @@ int clipenc_op_row_norm_consts(const float* stats_dev, int parts, int ld, int n_
                                float* row_d_dev, void* stream);
 /* The LayerNorm-folded fp8 GEMM on block-exponent rows (QKV / FC1 of the fused tower):
  *   v = act(row_r[m] * scale_w[n] * (A8 (2^exp) . W8^T)[m][n] + row_d[m] * colsum[n] + bias[n])
- * stored as bf16 (out_inv_scale_dev == NULL) or as e4m3(v * out_inv_scale[n]);  N % 256 == 0, K % 256 == 0, K <= 1024 */
+ * stored as bf16 (out_inv_scale_dev == NULL) or as e4m3(v * out_inv_scale[n]);  N % 256 == 0, K % 256 == 0, K <= 1024.
+ * scale_w must hold POWERS OF TWO (clipenc_op_quant_rows_fp8 with ln = 2): only their exponent is used -- the MFMA applies it as the
+ * block scale of the weight rows, there is no multiply by scale_w in the epilogue.  (This op and the next keep the exponent bytes in
+ * one scratch per process: developer / test entry points, one caller at a time.) */
 int clipenc_op_gemm_fp8_lnf(const void* a8_dev, const void* exp_dev, const void* w8_dev, int m, int n, int k,
                             const float* row_r_dev, const float* row_d_dev, const float* scale_w_dev, const float* colsum_dev,
                             const float* bias_dev, int act, const float* out_inv_scale_dev, void* out_dev, void* stream);
 /* The residual fp8 GEMM that also quantises what it produces (out-projection / FC2 of the fused tower):
  *   x[m][n] = bf16(x[m][n] + (A8 . W8^T)[m][n] * scale_w[n] + bias[n])   in place, and for the new rows their block-exponent
  *   copy (out8_dev [m][n], exp_dev [m][4]: the fp32 value before the bf16 rounding is what gets quantised) and
- *   stats_dev [n / 64][stats_ld][2]: (sum, sum of squares) of the stored bf16 row over each 64 columns.  N = 256 .. 1024 */
+ *   stats_dev [n / 64][stats_ld][2]: (sum, sum of squares) of the stored bf16 row over each 64 columns.  N = 256 .. 1024;
+ *   scale_w: powers of two, as for clipenc_op_gemm_fp8_lnf */
 int clipenc_op_gemm_fp8_resid_q(const void* a8_dev, const void* w8_dev, int m, int n, int k, const float* scale_w_dev,
                                 const float* bias_dev, void* x_inout_dev, void* out8_dev, void* exp_dev, float* stats_dev,
                                 int stats_ld, void* stream);

@@ -88,9 +88,14 @@ def test_quant_rows_zero_row_and_layernorm(gpu):
 
 
 # ------------------------------------------------------------------------------------------ fp8 GEMM
-def _rand8(m, k, g):
+def _rand8(m, k, g, pow2=False):
+    """random e4m3 rows and their scales; pow2: the scale rounded up to a power of two (what the block-exponent GEMMs want of the
+    weight scales: the MFMA applies the exponent, include/clipenc.h)"""
     x = torch.randn(m, k, generator=g)
     amax = x.abs().amax(1, keepdim=True)
+    if pow2:
+        sc = torch.exp2(torch.ceil(torch.log2(amax / 448.0)))
+        return (x / sc).to(F8).view(torch.uint8), sc.flatten()
     return (x * (448.0 / amax)).to(F8).view(torch.uint8), (amax / 448.0).flatten()
 
 
@@ -258,7 +263,7 @@ def test_gemm_fp8_lnf_matches_torch(gpu, m, n, k, act, q_out):
     lib = _lib.load()
     g = torch.Generator().manual_seed(m + 3 * n + 7 * k)
     a8, eb = _rand_block_rows(m, k, g)
-    w8, sw = _rand8(n, k, g)
+    w8, sw = _rand8(n, k, g, pow2=True)
     bias, cs = torch.randn(n, generator=g), torch.randn(n, generator=g) * 3
     r, d = torch.rand(m, generator=g) * 2 + 0.05, torch.randn(m, generator=g) * 2
     a = _deq_block(a8, eb[:, : k // 256].to(torch.int32))
@@ -301,7 +306,7 @@ def test_gemm_fp8_resid_q_writes_rows_copy_exponents_and_statistics(gpu, m, n, k
     a8, sa = _rand8(m, k, g)
     a_scaled = (_deq(a8) * sa.view(m, 1) * torch.logspace(-2, 2, m).view(m, 1))         # rows of very different magnitude ...
     a8 = a_scaled.clamp(-448, 448).to(F8).view(torch.uint8)                             # ... in one static-scale operand
-    w8, sw = _rand8(n, k, g)
+    w8, sw = _rand8(n, k, g, pow2=True)
     bias = torch.randn(n, generator=g)
     resid = (torch.randn(m, n, generator=g) * torch.logspace(-1, 1, m).view(m, 1)).to(torch.bfloat16)
     ones = torch.ones(m)
@@ -345,8 +350,9 @@ def test_fused_block_ops_chain_like_the_tower(gpu):
     Wf = W * gamma.view(1, k)                                                 # gamma folded into the rows, beta into the bias
     bf = b + W @ beta
     amax = Wf.abs().amax(1, keepdim=True)
-    w8 = (Wf * (448.0 / amax)).to(F8).view(torch.uint8)
-    sw = (amax / 448.0).flatten()
+    sc2 = torch.exp2(torch.ceil(torch.log2(amax / 448.0)))                     # power-of-two weight scales (the MFMA applies the exponent)
+    w8 = (Wf / sc2).to(F8).view(torch.uint8)
+    sw = sc2.flatten()
     cs = (_deq(w8) * sw.view(n, 1)).sum(1)
     xd = x.to(gpu)
     q = torch.empty((m, k), dtype=torch.uint8, device=gpu)

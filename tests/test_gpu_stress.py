@@ -94,8 +94,8 @@ def test_fused_fp8_chain_is_stable_over_repeats_and_row_prefixes(gpu, m, k2):
     a8 = (torch.randn(m, k2, device=gpu, generator=g) * 40).clamp(-448, 448).to(F8).view(torch.uint8)
     w8 = (torch.randn(n, k2, device=gpu, generator=g) * 40).clamp(-448, 448).to(F8).view(torch.uint8)
     w2 = (torch.randn(768, n, device=gpu, generator=g) * 40).clamp(-448, 448).to(F8).view(torch.uint8)
-    sw = torch.rand(n, device=gpu, generator=g) * 1e-4 + 1e-5
-    sw2 = torch.rand(768, device=gpu, generator=g) * 1e-3 + 1e-4
+    sw = torch.exp2(torch.randint(-16, -12, (n,), device=gpu, generator=g).float())        # powers of two: the fused ops' weight scales
+    sw2 = torch.exp2(torch.randint(-13, -10, (768,), device=gpu, generator=g).float())
     bias = torch.randn(n, device=gpu, generator=g)
     cs2, b2 = torch.randn(768, device=gpu, generator=g), torch.randn(768, device=gpu, generator=g)
     x0 = (torch.randn(m, n, device=gpu, generator=g) * torch.logspace(-2, 2, m, device=gpu).view(m, 1)).to(torch.bfloat16)

@@ -18,7 +18,7 @@ for name, N, K, kind in SHAPES:
     if ONLY and name not in ONLY.split(","):
         continue
     a = rnd8(M, K); w = rnd8(N, K)
-    sa = torch.rand(M, device=dev) + 0.5; sw = torch.rand(N, device=dev) * 0.01; bias = torch.randn(N, device=dev)
+    sa = torch.rand(M, device=dev) + 0.5; sw = torch.exp2(torch.randint(-9, -6, (N,), device=dev).float()); bias = torch.randn(N, device=dev)
     inv = torch.rand(N, device=dev) + 0.5
     if kind == "q":
         out = torch.empty(M, N, device=dev, dtype=torch.uint8)

@@ -21,7 +21,7 @@ for name, N, K, kind in SHAPES:
     if ONLY and name not in ONLY.split(","):
         continue
     a = rnd8(M, K, 60 if kind.startswith("lnf") else 0.5); w = rnd8(N, K)
-    sw = torch.rand(N, device=dev) * 0.01; bias = torch.randn(N, device=dev); inv = torch.rand(N, device=dev) + 0.5
+    sw = torch.exp2(torch.randint(-9, -6, (N,), device=dev).float()); bias = torch.randn(N, device=dev); inv = torch.rand(N, device=dev) + 0.5
     tiles = (Mp // 256) * (N // 256)
     stamps = torch.zeros(tiles, 8, dtype=torch.int64, device=dev)
     if kind in ("lnf", "lnf_q"):
