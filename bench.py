@@ -514,8 +514,7 @@ def run_job(args, cfg, vit, reg, dev, rank, world, backend):
     from clip_assisted_data_labeling_amd.job import run_embed_job, synthetic_u8_source
     N, B = args.job_images, args.images
     sel = list(range(CROPS_PER_IMAGE))
-    if backend != "nccl" and world > 1:
-        raise SystemExit("the job runner gathers device tensors: use the nccl (RCCL) backend")
+    gdev = None if backend == "nccl" or world == 1 else torch.device("cpu")     # gloo rehearsal: host-staged gather
     warm = synthetic_u8_source(cfg.image_size, CROPS_PER_IMAGE, args.job_seed - 1000, rank, dev)
     vit.encode_score(warm(0, min(B, 64)), reg, CROPS_PER_IMAGE, sel)          # warm-up (kernel modules, fp8 weight set)
     source = synthetic_u8_source(cfg.image_size, CROPS_PER_IMAGE, args.job_seed, rank, dev)
@@ -536,10 +535,12 @@ def run_job(args, cfg, vit, reg, dev, rank, world, backend):
     t0 = time.perf_counter()
     res = run_embed_job(N, B, CROPS_PER_IMAGE, cfg.embed_dim, reg.sizes[-1], source,
                         lambda c: vit.encode_score(c, reg, CROPS_PER_IMAGE, sel), dev, rank, world, gather=True,
-                        sync=torch.cuda.synchronize, progress=progress, gather_dst=0)   # a true gather: rank 0 collects
+                        sync=torch.cuda.synchronize, progress=progress, gather_dst=0,    # a true gather: rank 0 collects
+                        gather_device=gdev)
     fence()
     elapsed = time.perf_counter() - t0
-    times = torch.tensor([elapsed, res["t_encode"], res["t_gather"]], device=dev, dtype=torch.float64)
+    ranks = rank_report(dev, world, rank, res["t_encode"], res["n_local"])
+    times = torch.tensor([elapsed, res["t_encode"], res["t_gather"]], device=gdev or dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     elapsed, t_enc, t_gat = (float(x) for x in times.tolist())
@@ -549,7 +550,7 @@ def run_job(args, cfg, vit, reg, dev, rank, world, backend):
     if rank == 0:
         assert emb.shape == (N, CROPS_PER_IMAGE, cfg.embed_dim) and score.shape[0] == N
         assert torch.isfinite(emb).all() and torch.isfinite(score).all()
-        assert torch.equal(emb[res["lo"]:res["hi"]], loc_e) and torch.equal(score[res["lo"]:res["hi"]], loc_s)
+        assert torch.equal(emb[res["lo"]:res["hi"]].to(dev), loc_e) and torch.equal(score[res["lo"]:res["hi"]].to(dev), loc_s)
         norm_err = float((emb.norm(dim=-1) - 1.0).abs().max().item())
     else:
         assert emb is None and score is None
@@ -567,6 +568,10 @@ def run_job(args, cfg, vit, reg, dev, rank, world, backend):
         print(json.dumps({
             "metric": "images/sec (4 crops each) ViT-L/14 encode+score, whole sharded job", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1, "ranks": ranks,
+            "distinct_devices": len({r["uuid"] or r["pci"] for r in ranks}),
+            "images_per_s_per_rank": {"min": min(r["images_per_s"] or 0.0 for r in ranks), "max": max(r["images_per_s"] or 0.0 for r in ranks)},
+            "t_gather": round(t_gat, 4),
             "config": {"workload": f"BASELINE.json configs[3]: {N} synthetic images x 4 crops sharded over {world} rank(s), uint8 crops "
                                    f"generated on the device per {B}-image batch (Philox counter generator, seed {args.job_seed} + rank), "
                                    f"{args.dtype} block GEMMs, fused fp32 regressor, embeddings + scores kept in HBM, one gather onto rank 0 at the end",
@@ -580,6 +585,50 @@ def run_job(args, cfg, vit, reg, dev, rank, world, backend):
             "checks": {"finite": True, "max_abs_norm_minus_1": norm_err, "first_batch_reproduced_bitwise": same},
         }), flush=True)
     assert same, "re-encoding the first batch from the same seed did not reproduce the stored rows"
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` with N > 1 and no torchrun around it: this process has made NO GPU call yet (importing torch
+    does not initialise HIP), so it starts N fresh rank processes -- `python -m torch.distributed.run --nproc-per-node N bench.py
+    <same arguments>` on a free loopback port -- as a CHILD, forwards rank 0's single JSON line and exits with the child's
+    status.  Nothing is re-executed in place: a process that has touched the GPU is never replaced by another program."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n_gpus) // n_gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)      # stderr passes straight through
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    result = [ln for ln in lines if ln.lstrip().startswith("{") and '"metric"' in ln]
+    for ln in lines:
+        if ln not in result:
+            print(ln, file=sys.stderr)
+    if result:
+        print(result[-1], flush=True)
+    if proc.returncode != 0:
+        return proc.returncode
+    return 0 if result else 1
+
+
+def rank_report(dev, world, rank, seconds, images):
+    """What every rank measured, collected on all ranks: device UUID / name, its own seconds for its own images.  Proves the ranks ran
+    on DIFFERENT GPUs through an initialised process group (rccl_ranks = dist.get_world_size())."""
+    import torch.distributed as dist
+    pr = torch.cuda.get_device_properties(dev)
+    mine = {"rank": rank, "device_index": dev.index, "uuid": str(getattr(pr, "uuid", "")), "name": pr.name,
+            "pci": f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}",
+            "seconds": round(seconds, 4), "images_per_s": round(images / seconds, 2) if seconds > 0 else None}
+    if world == 1:
+        return [mine]
+    out = [None] * world
+    dist.all_gather_object(out, mine)
+    return out
 
 
 def main():
@@ -608,9 +657,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))                     # before anything touches the GPU
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     import torch.distributed as dist
     from clip_assisted_data_labeling_amd import vit_config
@@ -675,10 +724,24 @@ def main():
             emb, score = step()
         fence()
         elapsed = time.perf_counter() - t0
+    ranks = rank_report(dev, world, rank, elapsed, n_img * args.steps)      # every rank's own clock, before the MAX
+    t_gather_ms = None
     if world > 1:
         t = torch.tensor([elapsed], device=gdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # the exchange alone, outside the timed region: 5 x {embeddings + scores all-gather} with nothing to hide behind
+        fence()
+        tg = time.perf_counter()
+        for _ in range(5):
+            dist.all_gather_into_tensor(emb_all, emb.to(gdev))
+            dist.all_gather_into_tensor(score_all, score.to(gdev))
+        fence()
+        t = torch.tensor([(time.perf_counter() - tg) / 5 * 1e3], device=gdev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_gather_ms = round(float(t.item()), 3)
+        # every rank's block must sit at its own rows of the gathered result
+        assert torch.equal(emb_all[rank * n_img:(rank + 1) * n_img].to(dev), emb), "gathered rows differ from the local block"
     assert torch.isfinite(emb).all() and torch.isfinite(score).all()
 
     # ---- per-kernel durations for the roofline block: extra steps AFTER the timed region, HIP events around every kernel
@@ -720,6 +783,10 @@ def main():
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
+            "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,
+            "ranks": ranks, "distinct_devices": len({r["uuid"] or r["pci"] for r in ranks}),
+            "images_per_s_per_rank": {"min": min(r["images_per_s"] for r in ranks), "max": max(r["images_per_s"] for r in ranks)},
+            "t_gather_ms": t_gather_ms,
             "config": {"workload": f"{workload} of {n_img} images x 4 crops per GPU "
                                    "+ fused fp32 regressor 3072-264-128-64-1, seeded random-init weights, crops resident in HBM",
                        "images_per_gpu": n_img, "crops_per_image": CROPS_PER_IMAGE, "parallelism": f"image-sharded x{world}",

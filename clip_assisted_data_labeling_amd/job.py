@@ -42,12 +42,14 @@ def run_embed_job(n_images: int, batch_images: int, crops_per_image: int, embed_
                   source: Callable[[int, int], torch.Tensor],
                   encode_score: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]],
                   device, rank: int = 0, world: int = 1, gather: bool = True, sync: Optional[Callable[[], None]] = None,
-                  progress: Optional[Callable[[int, int], None]] = None, gather_dst: Optional[int] = None) -> Dict:
+                  progress: Optional[Callable[[int, int], None]] = None, gather_dst: Optional[int] = None,
+                  gather_device=None) -> Dict:
     """Runs this rank's shard of the job.  `encode_score(crops) -> (emb [b, crops, E], score [b, score_dim])` on `device`.
     Returns {'emb_local', 'score_local'} (this rank's block) and {'emb', 'score'} (gather=True: the FULL job on every rank, or -- with gather_dst=r -- on rank r only and None
     elsewhere; gather=False: the local block), 'n_local', 'lo', 'hi', 'batches' and wall-clock seconds of the encode phase
     and of the gather ('t_encode', 't_gather'; `sync` is called before each clock is read -- torch.cuda.synchronize on a
-    GPU).  The gather allocates nothing but the result (sharding.gather_rows)."""
+    GPU).  The gather allocates nothing but the result (sharding.gather_rows).  `gather_device` (rehearsals only: several ranks
+    on one GPU under gloo) stages the local blocks there before the exchange; RCCL gathers the device tensors in place."""
     if n_images < 0 or batch_images < 1:
         raise ValueError(f"bad job shape: {n_images} images in batches of {batch_images}")
     lo, hi = shard_bounds(n_images, rank, world)
@@ -74,8 +76,9 @@ def run_embed_job(n_images: int, batch_images: int, crops_per_image: int, embed_
     if gather and world > 1:
         if not (dist.is_available() and dist.is_initialized()):
             raise RuntimeError("world > 1 needs an initialised torch.distributed process group")
-        full_e = gather_rows(emb, n_images, dst=gather_dst)   # the one exchange of the path
-        full_s = gather_rows(score, n_images, dst=gather_dst)
+        ge, gs = (emb, score) if gather_device is None else (emb.to(gather_device), score.to(gather_device))
+        full_e = gather_rows(ge, n_images, dst=gather_dst)    # the one exchange of the path
+        full_s = gather_rows(gs, n_images, dst=gather_dst)
         sync()
         out["t_gather"] = time.perf_counter() - t1
         out["emb"], out["score"] = full_e, full_s

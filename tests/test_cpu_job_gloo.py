@@ -75,14 +75,31 @@ def _worker(rank, world, port, n_total, batch, gather_dst, q):
 @pytest.mark.parametrize("n_total,batch,expect", [(11, 3, [(0, True, 6, 2), (1, True, 5, 2)]), (1, 4, [(0, True, 1, 1), (1, True, 0, 0)]),
                                                   (12, 4, [(0, True, 6, 2), (1, True, 6, 2)])])
 def test_job_world2_gloo(n_total, batch, expect, gather_dst):
+    assert _run_world(2, n_total, batch, gather_dst) == expect
+
+
+def _run_world(world, n_total, batch, gather_dst):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, batch, gather_dst, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, batch, gather_dst, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
+    res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    assert res == expect
+    return res
+
+
+@pytest.mark.parametrize("gather_dst", [None, 0])
+def test_job_world8_gloo_ragged_shards(gather_dst):
+    """The rank count of BASELINE.json configs[3] (8 ranks) with a job that does not divide: 1003 images -> shards of 126 x3 and
+    125 x5, batches of 50 -> every rank ends on a ragged batch (26 / 25 images); rank 0 (or every rank) holds all rows in order."""
+    res = _run_world(8, 1003, 50, gather_dst)
+    assert res == [(r, True, 126 if r < 3 else 125, 3) for r in range(8)]
+
+
+def test_job_world8_gloo_fewer_images_than_ranks():
+    res = _run_world(8, 5, 4, 0)                                          # ranks 5..7 own nothing and still take part in the gather
+    assert res == [(r, True, 1 if r < 5 else 0, 1 if r < 5 else 0) for r in range(8)]

@@ -3,6 +3,7 @@ and that the C-ABI library loads and exports every symbol include/clipenc.h decl
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -306,3 +307,29 @@ def test_dedup_screen_scratch_size_is_host_arithmetic():
     assert b(1000, 100, 0) == 256 + 1024 * 512 + 1024 * 4                     # d 100 -> 128 -> at least 512 e4m3 columns
     assert b(10, 1000, 5) == 256 + 256 * 1024 + 256 * 4 + 40
     assert b(-1, 768, 10) == 0 and b(10, 0, 10) == 0
+
+
+def test_bench_self_launch_builds_a_torchrun_child_and_forwards_one_line(monkeypatch, capsys):
+    """bench.py --gpus N without torchrun: the parent (no GPU call made) starts N ranks as a child `torch.distributed.run` on
+    127.0.0.1, forwards rank 0's JSON line only, and returns the child's status."""
+    import subprocess
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return types.SimpleNamespace(returncode=seen.get("rc", 0),
+                                     stdout='noise from a rank\n{"metric": "images/sec", "value": 1.0, "n_gpus": 4}\n')
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3"])
+    assert bench.self_launch(4) == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert cmd[-5].endswith("bench.py") and seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    out = capsys.readouterr()
+    assert out.out.strip() == '{"metric": "images/sec", "value": 1.0, "n_gpus": 4}' and "noise from a rank" in out.err
+    seen["rc"] = 3
+    assert bench.self_launch(4) == 3                        # a failing child fails the command

@@ -62,3 +62,44 @@ def test_two_ranks_report_the_whole_job(gpu):
     assert d["n_gpus"] == 2 and "cpu_baseline" not in d
     assert abs(d["value"] - 2 * 32 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-3  # both ranks' images over the max-over-ranks time
     assert d["config"]["parallelism"] == "image-sharded x2"
+
+
+def test_plain_command_with_gpus_2_launches_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` WITHOUT torchrun (the form the driver uses): the parent starts two fresh rank processes before it
+    touches the GPU, forwards rank 0's one line and the children's exit status."""
+    env = dict(os.environ, BENCH_DEVICE="0", BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--images", "32",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["backend"] == "gloo" and d["config"]["parallelism"] == "image-sharded x2"
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and all(r["images_per_s"] > 0 and r["uuid"] for r in d["ranks"])
+    assert d["distinct_devices"] == 1                       # the rehearsal shares the box's one GPU; the real run reports N
+    assert d["t_gather_ms"] > 0 and d["images_per_s_per_rank"]["min"] <= d["images_per_s_per_rank"]["max"]
+    assert abs(d["value"] - 2 * 32 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 1e-3
+
+
+def test_plain_command_job_runner_launches_its_own_ranks(gpu):
+    """BASELINE.json configs[3]'s control flow from the plain command: 2 ranks, a ragged job (75 images in batches of 32: shards
+    of 38 and 37, last batches of 6 and 5), fp8, one gather onto rank 0."""
+    env = dict(os.environ, BENCH_DEVICE="0", BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--job-images", "75", "--images", "32", "--dtype", "fp8"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["dtype"] == "fp8" and d["config"]["job_images"] == 75
+    assert d["checks"]["first_batch_reproduced_bitwise"] is True and d["checks"]["max_abs_norm_minus_1"] < 1e-3
+    assert d["result_bytes"] == 75 * (4 * 768 + 1) * 4 and d["t_gather"] >= 0
+
+
+def test_a_failing_rank_fails_the_plain_command(gpu):
+    env = dict(os.environ, BENCH_DEVICE="0", BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--job-images", "10", "--images", "0"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
