@@ -12,7 +12,8 @@ What is pinned against what:
                          run on a planted-pair set written as <uuid>.jpg/.pt files: reported pairs+values.
   encoder_*.npz          oracle/vit_oracle.py outputs on seeded weights, after asserting agreement with
                          transformers.CLIPVisionModelWithProjection (independent implementation; the
-                         reference has no vectors at the open_clip boundary).
+                         reference has no vectors at the open_clip boundary).  encoder_*-erf.npz: the erf-GELU
+                         tower of the non-openai tags, cross-checked with hidden_act="gelu".
   simsearch_small.npz    the reference's `compute_distance` and `topN` (/root/reference/tools/find_similar_imgs.py)
                          on a seeded embedding set: l2 and cosine distances, the top-N set it keeps.
   train_small.npz        the reference's SimpleFC trained by torch.optim.Adam + CosineAnnealingWarmRestarts + MSELoss (the
@@ -228,9 +229,15 @@ def make_train():
     print("train_small: oracle == reference SimpleFC + torch Adam + CosineAnnealingWarmRestarts over", epochs, "epochs; final train mse", losses[-1])
 
 
-def make_encoder(arch, n_crops, seed, in_seed):
+def make_encoder(arch, n_crops, seed, in_seed, pretrained="openai"):
+    """`pretrained` other than 'openai' selects the erf-GELU tower open_clip builds for laion* / datacomp* tags
+    (/root/reference/utils/embedder.py:63-73 accepts any "<arch>/<pretrained>"); the cross-check then runs transformers with
+    hidden_act="gelu" and the fixture is written as encoder_<arch>-erf.npz."""
     from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
-    cfg = vit_config.ARCHS[arch]
+    cfg = vit_config.config_for(f"{arch}/{pretrained}")
+    erf = cfg.act == vit_config.ACT_GELU_ERF
+    assert erf == (pretrained != "openai")
+    name = arch + ("-erf" if erf else "")
     sd = vit_config.seeded_state_dict(cfg, seed)
     g = torch.Generator().manual_seed(in_seed)
     u = torch.randint(0, 256, (n_crops, 3, cfg.image_size, cfg.image_size), generator=g).float()
@@ -242,7 +249,7 @@ def make_encoder(arch, n_crops, seed, in_seed):
     # independent cross-check: transformers tower with the same weights (SURVEY.md Appendix A.3 mapping)
     hf_cfg = CLIPVisionConfig(hidden_size=cfg.width, intermediate_size=cfg.mlp_dim, projection_dim=cfg.embed_dim,
                               num_hidden_layers=cfg.layers, num_attention_heads=cfg.heads,
-                              image_size=cfg.image_size, patch_size=cfg.patch, hidden_act="quick_gelu",
+                              image_size=cfg.image_size, patch_size=cfg.patch, hidden_act="gelu" if erf else "quick_gelu",
                               layer_norm_eps=cfg.ln_eps)
     hf = CLIPVisionModelWithProjection(hf_cfg).eval()
     hsd = {}
@@ -277,12 +284,12 @@ def make_encoder(arch, n_crops, seed, in_seed):
     back = vit_config.normalise_state_dict(hf.state_dict(), cfg)
     assert all(torch.equal(back[k], sd[k]) for k in sd)
     wsum = float(sum(v.double().abs().sum() for v in sd.values()))
-    np.savez_compressed(os.path.join(HERE, f"encoder_{arch}.npz"), arch=arch, weight_seed=seed, input_seed=in_seed,
+    np.savez_compressed(os.path.join(HERE, f"encoder_{name}.npz"), arch=arch, pretrained=pretrained, weight_seed=seed, input_seed=in_seed,
                         n_crops=n_crops, weight_abs_sum=wsum, crops_abs_sum=float(crops.double().abs().sum()),
                         emb=emb.numpy(), ln_pre_cls=taps["ln_pre"][:, 0].numpy(),
                         block0_cls=taps["block0"][:, 0].numpy(),
                         last_block_tok1=taps[f"block{cfg.layers - 1}"][:, 1].numpy())
-    print(f"encoder_{arch}: oracle vs transformers max-abs {err:.2e}")
+    print(f"encoder_{name}: oracle vs transformers max-abs {err:.2e}")
 
 
 def make_crop_boxes():
@@ -320,6 +327,9 @@ def make_crop_boxes():
 
 if __name__ == "__main__":
     torch.manual_seed(0)
+    if sys.argv[1:] == ["erf"]:          # only the fixture added in round 4 (needs transformers, not the reference)
+        make_encoder("ViT-small-test", 5, seed=1, in_seed=2, pretrained="laion2b_s32b_b82k")
+        sys.exit(0)
     make_crop_boxes()
     make_regressor()
     make_dedup()
@@ -328,3 +338,4 @@ if __name__ == "__main__":
     make_encoder("ViT-tiny-test", 6, seed=3, in_seed=4)
     make_encoder("ViT-small-test", 5, seed=1, in_seed=2)
     make_encoder("ViT-B-32", 8, seed=0, in_seed=1234)
+    make_encoder("ViT-small-test", 5, seed=1, in_seed=2, pretrained="laion2b_s32b_b82k")

@@ -38,10 +38,18 @@ def test_regressor_oracle_4crop_golden(golden_dir):
     assert np.abs(y - g["y"]).max() < 2e-6
 
 
-@pytest.mark.parametrize("arch", ["ViT-tiny-test", "ViT-small-test", "ViT-B-32"])
+def golden_cfg(g):
+    """ViTConfig of a committed encoder fixture: '<arch>/<pretrained>' through the product's own name parsing (fixtures from
+    before the erf-GELU one carry no tag: 'openai')."""
+    tag = str(g["pretrained"]) if "pretrained" in g.files else "openai"
+    return vit_config.config_for(f"{str(g['arch'])}/{tag}")
+
+
+@pytest.mark.parametrize("arch", ["ViT-tiny-test", "ViT-small-test", "ViT-B-32", "ViT-small-test-erf"])
 def test_vit_oracle_matches_golden(golden_dir, arch):
     g = np.load(os.path.join(golden_dir, f"encoder_{arch}.npz"))
-    cfg = vit_config.ARCHS[arch]
+    cfg = golden_cfg(g)
+    assert (cfg.act == vit_config.ACT_GELU_ERF) == arch.endswith("-erf")
     sd = vit_config.seeded_state_dict(cfg, int(g["weight_seed"]))
     wsum = float(sum(v.double().abs().sum() for v in sd.values()))
     assert abs(wsum - float(g["weight_abs_sum"])) < 1e-6 * wsum, "seeded weights drifted from the fixture"

@@ -405,9 +405,10 @@ def test_attention_e4m3_output_with_static_channel_scales(gpu, n_crops, n_tok, h
 
 
 # ------------------------------------------------------------------------------------------ encoder in fp8
-@pytest.mark.parametrize("arch", ["ViT-tiny-test", "ViT-small-test", "ViT-B-32"])
+@pytest.mark.parametrize("arch", ["ViT-tiny-test", "ViT-small-test", "ViT-B-32", "ViT-small-test/laion2b_s32b_b82k"])
 def test_encoder_fp8_within_tolerance_of_oracle(gpu, arch):
-    cfg = vit_config.ARCHS[arch]
+    cfg = vit_config.config_for(arch)                      # the laion tag: erf-GELU in FC1's quantising epilogue
+    assert (cfg.act == vit_config.ACT_GELU_ERF) == ("laion" in arch)
     sd = vit_config.seeded_state_dict(cfg, 3)
     crops = synthetic_crops(8, cfg.image_size, 12)
     ref = vit_oracle.encode_image(sd, cfg, crops)

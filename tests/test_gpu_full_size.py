@@ -67,3 +67,44 @@ def test_vit_l14_properties_at_batch_size(vit_l14, gpu):
     assert one_minus_cos(e1.cpu(), chunked.cpu()).max().item() < 1e-6
     cs = (e1[:256] @ e1[:256].T).cpu()
     assert cs.fill_diagonal_(0).abs().max().item() < 0.999          # distinct inputs stay distinct
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_vit_l_width_erf_gelu_tower_matches_fp32_oracle(gpu, precision):
+    """A non-openai tag (/root/reference/utils/embedder.py:63-73 accepts any "<arch>/<pretrained>"; open_clip builds those towers
+    with erf-GELU): ViT-L/14's full widths (1024 / 4096 / 16 heads / 257 tokens), 2 layers so the fp32 oracle finishes in seconds.
+    Runs gemm_persist_kernel<2, 1> (bf16) and gemm_fp8_kernel<2, 1, true> (fp8) at the shapes a laion2b ViT-L-14 would."""
+    import dataclasses
+    cfg = dataclasses.replace(vit_config.config_for("ViT-L-14/laion2b_s32b_b82k"), layers=2)
+    cfg_q = dataclasses.replace(cfg, act=vit_config.ACT_QUICK_GELU)
+    assert cfg.act == vit_config.ACT_GELU_ERF and cfg.width == 1024 and cfg.mlp_dim == 4096
+    sd = vit_config.seeded_state_dict(cfg, 5)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    crops = synthetic_crops(12, 224, 78)
+    taps = {}
+    ref = vit_oracle.encode_image(sd, cfg, crops, taps)
+    ref_q = vit_oracle.encode_image(sd, cfg_q, crops)
+    out = {}
+    for name, c in (("erf", cfg), ("quick", cfg_q)):
+        vit = HipViT(c, sd, gpu, precision=precision)
+        try:
+            out[name] = vit.encode(crops.to(gpu)).cpu()
+            if name == "erf":
+                x2 = vit.debug_run_layers(crops.to(gpu), 2).float().cpu() if precision == "bf16" else None
+                vit.profile_enable(True)
+                vit.encode(crops.to(gpu))
+                prof = vit.profile_read()
+        finally:
+            vit.close()
+    omc = one_minus_cos(out["erf"], ref)
+    print(f"ViT-L-width erf tower {precision} 1-cos:", omc.max().item(), "erf vs QuickGELU oracles:", one_minus_cos(ref, ref_q).max().item())
+    assert omc.max().item() < 1e-3, omc
+    fc1 = "gemm_persist_kernel<2, 1>" if precision == "bf16" else "gemm_fp8_kernel<2, 1, true>"
+    assert prof[fc1][1] == 2 and prof[fc1][0] > 0 and all(v[1] == 0 for k, v in prof.items() if "<2, 0" in k)
+    assert not torch.equal(out["erf"], out["quick"])        # the activation bit reaches the kernels
+    if precision == "bf16":
+        # QuickGELU approximates erf-GELU to ~0.02, so the two towers are 1.5e-5 apart in 1 - cos: each GPU tower must be
+        # nearer to the oracle of ITS activation than to the other one's (bf16 noise is below that distance; e4m3's is not)
+        assert one_minus_cos(out["erf"], ref).max().item() < one_minus_cos(out["erf"], ref_q).min().item()
+        assert one_minus_cos(out["quick"], ref_q).max().item() < one_minus_cos(out["quick"], ref).min().item()
+        assert one_minus_cos(x2.flatten(1), taps["block1"].flatten(1)).max().item() < 5e-4

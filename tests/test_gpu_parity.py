@@ -193,10 +193,14 @@ def test_regressor_odd_layer_sizes_vs_oracle(gpu):
 
 
 # --------------------------------------------------------------------------------------- encoder
-@pytest.mark.parametrize("arch", ["ViT-tiny-test", "ViT-small-test", "ViT-B-32"])
+@pytest.mark.parametrize("arch", ["ViT-tiny-test", "ViT-small-test", "ViT-B-32", "ViT-small-test-erf"])
 def test_encoder_matches_golden_and_oracle(gpu, golden_dir, arch):
+    """'-erf': the erf-GELU tower open_clip builds for every non-openai tag (/root/reference/utils/embedder.py:63-73 takes any
+    "<arch>/<pretrained>") -> gemm_persist_kernel<2, 1>; fixture cross-checked against transformers with hidden_act="gelu"."""
     g = np.load(os.path.join(golden_dir, f"encoder_{arch}.npz"))
-    cfg = vit_config.ARCHS[arch]
+    tag = str(g["pretrained"]) if "pretrained" in g.files else "openai"
+    cfg = vit_config.config_for(f"{str(g['arch'])}/{tag}")
+    assert (cfg.act == vit_config.ACT_GELU_ERF) == arch.endswith("-erf")
     sd = vit_config.seeded_state_dict(cfg, int(g["weight_seed"]))
     crops = synthetic_crops(int(g["n_crops"]), cfg.image_size, int(g["input_seed"]))
     vit = HipViT(cfg, sd, gpu)
