@@ -85,10 +85,31 @@ __device__ __forceinline__ TileId tri_tile(const unsigned* list, int i) {
   return TileId{tm * BM, tn * BN, tn};
 }
 
+// GEMM_WALK_SG > 0 (experiment, round 4): the XCD sweeps GEMM_WALK_SG tiles along M for a block of GEMM_WALK_NB tiles along N,
+// then the next N block of the same super-group: the NB W panels of a block (NB x 512 KiB at K = 1024) stay in the XCD's L2 for
+// SG * NB / 32 rounds while the A panels stream through once per N block (re-read from the Infinity Cache tiles_n / NB times).
+#ifndef GEMM_WALK_SG
+#define GEMM_WALK_SG 0
+#endif
+#ifndef GEMM_WALK_NB
+#define GEMM_WALK_NB 4
+#endif
 __device__ __forceinline__ TileId decode_tile(int idx, int tiles_m, int tiles_n, bool deep_narrow) {
   const int nwg = tiles_m * tiles_n;
   const int q = nwg >> 3, r = nwg & 7, xcd = idx & 7, pos = idx >> 3;
   const int bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;   // XCD-aware, bijective
+#if GEMM_WALK_SG > 0
+  if (!deep_narrow && tiles_n > GEMM_WALK_NB && tiles_n % GEMM_WALK_NB == 0) {
+    const int per_sg = GEMM_WALK_SG * tiles_n;
+    const int sg = bid / per_sg, rr = bid - sg * per_sg;
+    const int first = sg * GEMM_WALK_SG;
+    const int gsz_ = min(tiles_m - first, GEMM_WALK_SG);
+    const int per_blk = gsz_ * GEMM_WALK_NB;
+    const int nb = rr / per_blk, rem = rr - nb * per_blk;
+    const int tm_ = first + rem / GEMM_WALK_NB, tn_ = nb * GEMM_WALK_NB + rem % GEMM_WALK_NB;
+    return TileId{tm_ * BM, tn_ * BN, tn_};
+  }
+#endif
   const int GM = deep_narrow ? 2 : 8;         // tiles along M per group; FC2's shape (4 N-tiles, K = 4096) measured 2.3 % faster with 2
   const int group = bid / (GM * tiles_n);
   const int first_m = group * GM;
@@ -186,12 +207,32 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   // (128 v_mov per wave and tile with the matrix pipe idle otherwise) -- or, for EPI_RESID, the BIAS of its four columns:
   // the sum starts from the bias and the epilogue has no bias add
 #define CINIT(j) (EPI == EPI_RESID ? binit[(j)] : f32x4_t{0.f, 0.f, 0.f, 0.f})
-// Issue order: serpentine over the 4 x 4 block (j runs 0..3, 3..0, ...), so that exactly ONE operand register set changes
-// between consecutive MFMAs; with j restarting at 0 both srcA and srcB changed at every fourth.  A pure stream of this
-// block on all CUs (tools/probes/power_probe.py, PROBE_ONLY=order) runs 2.0 % faster at the same board power.
+// Issue order of a phase's 32 MFMAs (16 accumulators x 2 k halves).  What the board pays for is switching: a pure stream of this
+// block on all CUs (tools/probes/power_probe.py) runs 2.0 % faster when exactly ONE operand register set changes between
+// consecutive MFMAs (serpentine: j runs 0..3, 3..0, ...; PROBE_ONLY=order) -- and 5.0 % faster still when the two k halves of an
+// accumulator are issued BACK TO BACK (PROBE_ONLY=acc, round 4: 126.3 -> 132.6 G MFMA/s at the same board power), although both
+// operands then change at every instruction (one operand pair and ONE accumulator for all 16: +16 %: the accumulator port costs
+// more than both operand ports together).  In THIS kernel that order (GEMM_MMA_ORDER 2, bit-identical: every accumulator still
+// sees k half 0, then k half 1 of every stage) measured equal for QKV / FC1 and 1 % slower for the residual GEMMs, whose
+// instantiation then spills one accumulator in the last stage (three interleaved same-box pairs, tools/experiments/README.md):
+// the pure stream runs into a ~1.33 kW limit of the matrix pipes alone, the GEMM into the 1.4 kW board cap with the clock
+// already at 1.75 GHz, where a few per cent of MFMA energy move the clock by less than the noise.  Order 1 stays.
+//   GEMM_MMA_ORDER 1: k half outer, serpentine (shipped) | 2: i, j serpentine, k half inner | 0: k half outer, j restarts at 0
 #ifndef GEMM_MMA_ORDER
 #define GEMM_MMA_ORDER 1
 #endif
+#if GEMM_MMA_ORDER == 2
+#define MMA2(half, ZC)                                                                      \
+  do {                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                           \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_)                                        \
+    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) {                                      \
+      const int j = (i & 1) ? 3 - j_ : j_;                                                  \
+      acc[(half) * 4 + i][j] = mfma16(fb[kh * 4 + j], fa[kh * 4 + i],                                               \
+                                   ((ZC) && kh == 0) ? CINIT(j) : acc[(half) * 4 + i][j]);                            \
+    }                                                                                       \
+  } while (0)
+#else
 #define MMA2(half, ZC)                                                                      \
   do {                                                                                      \
     _Pragma("unroll") for (int kh = 0; kh < 2; ++kh)                                        \
@@ -202,6 +243,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
                                    ((ZC) && kh == 0) ? CINIT(j) : acc[(half) * 4 + i][j]);                            \
     }                                                                                       \
   } while (0)
+#endif
 #define BARRIER() asm volatile("s_barrier" ::: "memory")
 #define WAIT_LDS()                                                                          \
   do {                                                                                      \

@@ -13,7 +13,11 @@ typedef __attribute__((ext_vector_type(8))) int i32x8_t;
 
 enum Role { SLEEP = 0, M32 = 1, M16 = 2, EXP = 3, FMA = 4, LDS128 = 5, LDSTR = 6, M32_EXP = 7, MAX3 = 8, M32Z = 9, M16Z = 10, DOT2 = 11, M32_LDS = 12, F8_32 = 13, F8_16 = 14, F8_32Z = 15,
             // issue ORDER of a 4 x 4 block of 16x16x32 MFMAs (16 accumulators, 4 srcA and 4 srcB fragments), round 3:
-            ORD_ROW = 16, ORD_SERP = 17, ORD_DIAG = 18, ORD_COL = 19, ORD_SAME = 20, ORD_SERP_COL = 21 };
+            ORD_ROW = 16, ORD_SERP = 17, ORD_DIAG = 18, ORD_COL = 19, ORD_SAME = 20, ORD_SERP_COL = 21,
+            // round 4: does the ACCUMULATOR port matter?  one operand pair AND one accumulator for all 16; and the GEMM's real
+            // 32-MFMA phase (two k halves: 8 srcA, 8 srcB, 16 accumulators) in the shipped order (k half outer, serpentine inside)
+            // against orders that put the two k halves of one accumulator back to back (the accumulator changes every 2nd MFMA)
+            ORD_SAME_ACC1 = 22, ORD2_SERP = 23, ORD2_KIN = 24, ORD2_KIN_ALT = 25 };
 
 #define MFMA32(acc, a_, b_) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_))
 #define MFMA16(acc, a_, b_) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a_), "v"(b_))
@@ -27,8 +31,8 @@ __global__ __launch_bounds__(512, 2) void power_kernel(const uint32_t* __restric
   f32x16_t acc[4]; f32x4_t acc4[4]; f32x4_t acc16[16];
   for (int i = 0; i < 16; ++i) for (int e = 0; e < 4; ++e) acc16[i][e] = 0.f;
   for (int i = 0; i < 4; ++i) { for (int e = 0; e < 16; ++e) acc[i][e] = 0.f; for (int e = 0; e < 4; ++e) acc4[i][e] = 0.f; }
-  u32x4_t aw[4], bw[4];
-  for (int i = 0; i < 4; ++i)
+  u32x4_t aw[8], bw[8];
+  for (int i = 0; i < 8; ++i)
     for (int e = 0; e < 4; ++e) {
       const bool z = (ROLE == M32Z || ROLE == M16Z);
       aw[i][e] = z ? 0u : rnd[(lane * 16 + i * 4 + e) & 4095];
@@ -66,6 +70,22 @@ __global__ __launch_bounds__(512, 2) void power_kernel(const uint32_t* __restric
         if constexpr (ROLE == ORD_DIAG) { i = n & 3; j = ((n & 3) + (n >> 2)) & 3; }
         const int ia = ROLE == ORD_SAME ? 0 : j, ib = ROLE == ORD_SAME ? 0 : i;
         MFMA16(acc16[i * 4 + j], __builtin_bit_cast(bf16x8_t, aw[ia]), __builtin_bit_cast(bf16x8_t, bw[ib]));
+      }
+    } else if constexpr (ROLE == ORD_SAME_ACC1) {
+#pragma unroll
+      for (int n = 0; n < 16; ++n) MFMA16(acc16[0], __builtin_bit_cast(bf16x8_t, aw[0]), __builtin_bit_cast(bf16x8_t, bw[0]));
+    } else if constexpr (ROLE >= ORD2_SERP && ROLE <= ORD2_KIN_ALT) {
+      // 32 MFMAs: acc16[i][j] += srcA[kh][j] . srcB[kh][i] for kh = 0, 1
+#pragma unroll
+      for (int n = 0; n < 32; ++n) {
+        int kh, i, j;
+        if constexpr (ROLE == ORD2_SERP) { kh = n >> 4; i = (n >> 2) & 3; j = n & 3; j = (i & 1) ? 3 - j : j; }
+        else {
+          const int c = n >> 1; i = c >> 2; j = c & 3; j = (i & 1) ? 3 - j : j;
+          kh = n & 1;
+          if constexpr (ROLE == ORD2_KIN_ALT) kh = (c & 1) ? 1 - kh : kh;     // 0,1 | 1,0 | 0,1 ...: one operand set survives each accumulator change
+        }
+        MFMA16(acc16[i * 4 + j], __builtin_bit_cast(bf16x8_t, aw[kh * 4 + j]), __builtin_bit_cast(bf16x8_t, bw[kh * 4 + i]));
       }
     } else if constexpr (ROLE == EXP) {
 #pragma unroll
@@ -136,6 +156,7 @@ extern "C" int power_probe_run(int role, const void* rnd, void* out, int iters, 
     LAUNCH(SLEEP) LAUNCH(M32) LAUNCH(M16) LAUNCH(EXP) LAUNCH(FMA) LAUNCH(LDS128) LAUNCH(LDSTR) LAUNCH(M32_EXP) LAUNCH(MAX3) LAUNCH(M32Z) LAUNCH(M16Z)
     LAUNCH(DOT2) LAUNCH(M32_LDS) LAUNCH(F8_32) LAUNCH(F8_16) LAUNCH(F8_32Z)
     LAUNCH(ORD_ROW) LAUNCH(ORD_SERP) LAUNCH(ORD_DIAG) LAUNCH(ORD_COL) LAUNCH(ORD_SAME) LAUNCH(ORD_SERP_COL)
+    LAUNCH(ORD_SAME_ACC1) LAUNCH(ORD2_SERP) LAUNCH(ORD2_KIN) LAUNCH(ORD2_KIN_ALT)
     default: return -1;
   }
   return (int)hipGetLastError();

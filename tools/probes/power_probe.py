@@ -16,7 +16,12 @@ ROLES = [("sleep", 0, 0, ""), ("mfma 32x32x16 bf16", 1, 8, "mfma"), ("mfma 32x32
          # issue order of a 4 x 4 block of 16x16x32 MFMAs (PROBE_ONLY=order runs just these, three interleaved rounds)
          ("4x4 block, shipped order (srcA every MFMA, srcB every 4th)", 16, 16, "order"), ("4x4 block, serpentine (one operand per MFMA)", 17, 16, "order"),
          ("4x4 block, diagonal (both operands every MFMA)", 18, 16, "order"), ("4x4 block, transposed (srcB every MFMA, srcA every 4th)", 19, 16, "order"),
-         ("4x4 block, transposed serpentine", 21, 16, "order"), ("4x4 block, one operand pair for all 16", 20, 16, "order")]
+         ("4x4 block, transposed serpentine", 21, 16, "order"), ("4x4 block, one operand pair for all 16", 20, 16, "order"),
+         # round 4 (PROBE_ONLY=acc): the accumulator port
+         ("one operand pair AND one accumulator for all 16", 22, 16, "acc"), ("4x4 block, one operand pair, 16 accumulators", 20, 16, "acc"),
+         ("2 k halves, shipped: k half outer, serpentine (acc changes every MFMA)", 23, 32, "acc"),
+         ("2 k halves back to back per accumulator (k 0,1 | 0,1)", 24, 32, "acc"),
+         ("2 k halves back to back, alternating (k 0,1 | 1,0)", 25, 32, "acc")]
 
 
 def main():
