@@ -376,13 +376,64 @@ def pmc_traffic(kernel_name):
             doc = json.load(open(path))
         except Exception:
             continue
+        base = kernel_name[kernel_name.index("(") + 1:-1] if kernel_name.startswith("shape:") else kernel_name
         for k, v in doc.items():
-            if k != "_meta" and kernel_name in k:
-                recorded = doc.get("_meta", {}).get("source_sha", {}).get(kernel_name)
-                if recorded != kernel_source_sha(kernel_name):
+            if k != "_meta" and (k == kernel_name if kernel_name.startswith("shape:") else (kernel_name in k and not k.startswith("shape:"))):
+                recorded = doc.get("_meta", {}).get("source_sha", {}).get(base)
+                if recorded != kernel_source_sha(base):
                     return None                       # taken with other sources (or before shas were recorded)
                 return round(float(v.get("bytes_per_launch", v.get("hbm_bytes", 0.0))), 1)
     return None
+
+
+def algorithmic_bytes_per_step(cfg, crops):
+    """ALGORITHMIC bytes one step moves per kernel kind (every operand read once, every result written once; bf16 activations and
+    weights, fp32 row statistics left out): what `roofline.per_kernel[*].traffic_ratio` divides the measured L2-miss bytes by.
+    The tower's last block runs K | V for every token and the rest on the class-token rows only."""
+    T, D, M, L = crops * cfg.tokens, cfg.width, cfg.mlp_dim, cfg.layers
+    full = L - 1
+    return {
+        "qkv": full * (T * D * 2 + 3 * D * D * 2 + T * 3 * D * 2) + (T * D * 2 + 2 * D * D * 2 + T * 2 * D * 2) + (2 * crops * D * 2 + D * D * 2),
+        "attention": full * (T * 3 * D * 2 + T * D * 2) + (T * 2 * D * 2 + 2 * crops * 32 * D * 2),
+        "out_proj": full * (3 * T * D * 2 + D * D * 2) + (3 * crops * D * 2 + D * D * 2),
+        "fc1": full * (T * D * 2 + M * D * 2 + T * M * 2) + (crops * D * 2 + M * D * 2 + crops * M * 2),
+        "fc2": full * (T * M * 2 + D * M * 2 + 2 * T * D * 2) + (crops * M * 2 + D * M * 2 + 2 * crops * D * 2),
+    }
+
+
+def per_kernel_table(prof, prof_steps, cfg, crops, fp8=False):
+    """roofline.per_kernel: for QKV / attention / out-proj / FC1 / FC2 the launches of the profiled pass priced against the dense MFMA
+    peak of their arithmetic type, and the committed L2-miss traffic of that kernel over its algorithmic bytes."""
+    names = list(prof)
+
+    def find(*subs, shape=None):
+        for k in names:
+            if shape is not None:
+                if k.startswith("shape:" + shape):
+                    return k
+            elif not k.startswith("shape:") and all(x in k for x in subs) and prof[k][1] > 0:
+                return k
+        return None
+    rows = {"qkv": find("gemm_fp8_kernel<0") if fp8 else find("gemm_persist_kernel<2, -1>"),
+            "attention": find("attn_"),
+            "out_proj": find(shape="out_proj"), "fc2": find(shape="fc2"),
+            "fc1": (find("gemm_fp8_kernel<2") if fp8 else (find("gemm_persist_kernel<2, 0>") or find("gemm_persist_kernel<2, 1>")))}
+    alg = algorithmic_bytes_per_step(cfg, crops)
+    out = {}
+    for key, k in rows.items():
+        if k is None or prof[k][1] == 0 or prof[k][0] <= 0:
+            continue
+        ms, n, fl = prof[k]
+        peak = PEAK_FP8_TFLOPS if "fp8" in k else PEAK_BF16_TFLOPS
+        tf = fl / (ms * 1e-3) / 1e12
+        launches = n / prof_steps
+        alg_b = alg[key] / launches
+        tr = pmc_traffic(k)
+        out[key] = {"kernel": k.replace("shape:", ""), "ms_per_step": round(ms / prof_steps, 3), "launches_per_step": round(launches, 2),
+                    "tflops": round(tf, 1), "peak": peak, "frac": round(tf / peak, 4),
+                    "algorithmic_bytes_per_launch": round(alg_b, 1), "traffic": tr,
+                    "traffic_ratio": round(tr / alg_b, 3) if tr else None}
+    return out
 
 
 def timed_steps(fn, steps, warmup=1):
@@ -420,6 +471,7 @@ def fp8_step(vit, reg, crops, cfg, n_img):
             "value": round(value, 2), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "fp8",
             "end_to_end_tflops": round(value * flop / 1e12, 1), "frac_of_fp8_peak": round(value * flop / 1e12 / PEAK_FP8_TFLOPS, 4),
             "dominant_kernel": dom, "dominant_tflops": round(tf, 1), "dominant_frac": round(tf / peak, 4), "dominant_peak": peak,
+            "per_kernel": per_kernel_table(prof, 1, cfg, n_img * CROPS_PER_IMAGE, True),
             "kernels_ms_per_step": {k: round(v[0], 3) for k, v in prof.items() if v[0] > 0 and not k.startswith("shape:")}}
 
 
@@ -744,15 +796,20 @@ def main():
         assert torch.equal(emb_all[rank * n_img:(rank + 1) * n_img].to(dev), emb), "gathered rows differ from the local block"
     assert torch.isfinite(emb).all() and torch.isfinite(score).all()
 
-    # ---- per-kernel durations for the roofline block: extra steps AFTER the timed region, HIP events around every kernel
-    #      on the launch stream; the one-wave clock probe runs beside them on a side stream
-    prof_steps = max(1, min(args.steps, 3))
+    # ---- per-kernel durations for the roofline block: a SECOND timed pass over the same steps with HIP events around every
+    #      kernel on the launch stream (its own wall time is reported next to the un-profiled one, so that the sum of the kernels
+    #      can be held against the step they were taken in); the one-wave clock probe runs beside it on a side stream
+    prof_steps = max(1, min(args.steps, 10))
     vit.profile_enable(True)
+    prof_wall = [0.0]
 
     def profiled():
+        fence()
+        t0p = time.perf_counter()
         for _ in range(prof_steps):
             step()
-        torch.cuda.synchronize()
+        fence()
+        prof_wall[0] = time.perf_counter() - t0p
     inkernel_mhz, n_probes, _ = probe_clock_during(profiled, dev) if rank == 0 else (None, 0, profiled())
     prof = vit.profile_read()
     vit.profile_enable(False)
@@ -806,7 +863,12 @@ def main():
                          # peak x sustained / 2400 MHz (nominal peak = CUs x 4 SIMDs x FLOP/clk x 2.4 GHz)
                          "frac_at_sustained_clock": (round(achieved / (d_peak * cu_count / 256.0 * sustained / 2400.0), 4)
                                                      if sustained else None),
-                         "measured_over": f"{prof_steps} extra profiled steps after the timed region"},
+                         "measured_over": f"a second timed pass of {prof_steps} steps with HIP events around every kernel (profiled_pass)",
+                         "per_kernel": per_kernel_table(prof, prof_steps, cfg, n_img * CROPS_PER_IMAGE, fp8)},
+            # the pass the per-kernel numbers come from: its own wall time per step, and the kernels' sum inside it
+            "profiled_pass": {"steps": prof_steps, "ms_per_step": round(prof_wall[0] / prof_steps * 1e3, 3),
+                              "kernels_sum_ms_per_step": round(sum(v[0] for k, v in prof.items() if not k.startswith("shape:")) / prof_steps, 3),
+                              "slowdown_vs_timed_region": round(prof_wall[0] / prof_steps / (elapsed / args.steps), 4)},
             "env": {"device": props.name, "cu_count": cu_count, "sclk_mhz_during_run": sclk,
                     "power_w": sampler.median("power_w"), "power_cap_w": sampler.cap_w,
                     "samples": len(sampler.samples["power_w"]) or len(sampler.samples["sclk_mhz"]), "source": sampler.source,

@@ -33,6 +33,16 @@ def test_single_gpu_line_has_the_contract_keys(gpu):
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert "traffic" in r and "kernel" in r
+    # per-kernel roofline rows, taken in a second timed pass whose own wall time is reported: the kernels' sum fits the step they
+    # were measured in by construction
+    pk = r["per_kernel"]
+    assert set(pk) == {"qkv", "attention", "out_proj", "fc1", "fc2"}
+    for row in pk.values():
+        assert 0 < row["frac"] < 1 and abs(row["frac"] - row["tflops"] / row["peak"]) < 1e-3 and row["algorithmic_bytes_per_launch"] > 0
+        assert row["traffic_ratio"] is None or row["traffic_ratio"] > 0.5
+    pp = d["profiled_pass"]
+    assert pp["steps"] == 2 and pp["kernels_sum_ms_per_step"] <= pp["ms_per_step"] and pp["slowdown_vs_timed_region"] > 0.9
+    assert abs(sum(d["kernels_ms_per_step"].values()) - pp["kernels_sum_ms_per_step"]) < 0.05
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "images/s" and c["sample"]
     # the executed-arithmetic fraction next to the reference-count fraction (the last block runs on the class-token rows only)
@@ -42,6 +52,7 @@ def test_single_gpu_line_has_the_contract_keys(gpu):
     sec = d["secondary"]
     assert sec["fp8_step"]["dtype"] == "fp8" and sec["fp8_step"]["value"] > 0 and "fp8" in sec["fp8_step"]["dominant_kernel"]
     assert sec["fp8_step"]["dominant_peak"] == 5033.2 and 0 < sec["fp8_step"]["dominant_frac"] < 1
+    assert {"qkv", "fc1", "out_proj", "fc2", "attention"} <= set(sec["fp8_step"]["per_kernel"]) and sec["fp8_step"]["per_kernel"]["fc1"]["peak"] == 5033.2
     assert sec["dedup_100k"]["pairs_found"] == 1000 and sec["dedup_100k"]["ms"] > 0
     assert sec["dedup_100k"]["candidates"] == 1000 and sec["dedup_100k"]["exact_search"]["pairs_found"] == 1000
     l336 = sec["vit_l14_336"]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer: turn gpurun_out/<tag>/ rocprofv3 output into the committed summaries under profiles/<tag>/."""
-import collections, csv, glob, json, os, shutil, sys
+import collections, csv, glob, json, os, re, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,11 +15,26 @@ def newest(pattern):
 shutil.copy(newest(os.path.join(src, "stats", "*", "*kernel_stats.csv")), os.path.join(dst, "bench_n1_kernel_stats.csv"))
 
 
+def shape_of(kernel_name, dispatch_ids):
+    """The residual GEMM runs two shapes under one kernel name, alternating per block: out-projection (K = width), then FC2
+    (K = mlp_dim).  Dispatches of that kernel in launch order: even = out-proj, odd = FC2 (the tower's last block keeps the order)."""
+    order = {d: i for i, d in enumerate(sorted(dispatch_ids, key=int))}
+    return lambda d: ("out_proj", "fc2")[order[d] & 1]
+
+
 def per_kernel(path, names):
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(set)
     dur = collections.defaultdict(float)
-    for r in csv.DictReader(open(path)):
+    rows = list(csv.DictReader(open(path)))
+    resid = [k for k in {r["Kernel_Name"] for r in rows} if "gemm_persist_kernel<3, -1>" in k or "gemm_fp8_kernel<3, -1, false>" in k]
+    splitters = {k: shape_of(k, {r["Dispatch_Id"] for r in rows if r["Kernel_Name"] == k}) for k in resid}
+    rows_extra = []
+    for r in rows:                                               # the same rows again under "shape:<which>(<kernel>)"
+        if r["Kernel_Name"] in splitters:
+            short = re.search(r"(\w+_kernel<[^>]*>)", r["Kernel_Name"]).group(1)
+            rows_extra.append(dict(r, Kernel_Name=f"shape:{splitters[r['Kernel_Name']](r['Dispatch_Id'])}({short})"))
+    for r in rows + rows_extra:
         k = r["Kernel_Name"]
         if not any(s in k for s in ("gemm", "attn", "fcreg", "head_kernel", "patchify", "embed_ln", "quant_", "row_norm")):
             continue
@@ -49,6 +64,15 @@ for k in traffic:
     m = re.search(r"(\w+_kernel(<[^>]*>)?)", k)
     if m:
         short[m.group(1)] = bench.kernel_source_sha(m.group(1))
+# the bench run this profile sits next to: which box, and what its matrix pipes get alone
+try:
+    bl = json.loads([l for l in open(os.path.join(src, "bench_n1.json")) if l.startswith("{")][-1])
+    box = {"value": bl.get("value"), "ms_per_step": bl.get("ms_per_step"), "env": bl.get("env"),
+           "power_capped_mfma_stream": bl.get("roofline", {}).get("power_capped_mfma_stream")}
+    json.dump(box, open(os.path.join(dst, "box.json"), "w"), indent=1)
+    print("box:", box["value"], "images/s;", (box["power_capped_mfma_stream"] or {}).get("value"), "TFLOP/s pure MFMA stream")
+except Exception as exc:
+    print("no box record:", exc)
 traffic["_meta"] = {"source_sha": short, "note": "sha256[:16] of the kernel's .hip sources + common.h + gemm.h at profile time"}
 json.dump(traffic, open(os.path.join(dst, "pmc_hbm_traffic_per_kernel.json"), "w"), indent=1)
 del traffic["_meta"]
