@@ -511,7 +511,7 @@ def vit_l14_336_step(dev, Ws, bs):
             "kernels_ms_per_step": {k: round(v[0], 3) for k, v in prof.items() if v[0] > 0 and not k.startswith("shape:")}}
 
 
-def embed_e2e(dev, n=4096, size=512, workers=16, batch=256):
+def embed_e2e(dev, n=4096, size=512, workers=16, batch=512):
     """The real-data rate of the embed driver (/root/reference/_1_embed_with_CLIP.py:95-184 -> embed_driver.Feature_Dataset):
     `n` generated JPEG files -> decode -> GPU crop/resize front end -> ViT-L/14 encoder -> one .pt per image, start-up included.
     Two runs over the same files: JPEG decode in DataLoader workers on the host cores (a property of the box's CPU share too), and
@@ -544,6 +544,8 @@ def embed_e2e(dev, n=4096, size=512, workers=16, batch=256):
                 n_emb = ds.process()[0]
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t0
+                log = ds.progress_log                       # (time, images stored) after every batch
+                steady = ((log[-1][1] - log[0][1]) / (log[-1][0] - log[0][0])) if len(log) > 2 and log[-1][0] > log[0][0] else None
             n_pt = sum(f.endswith(".pt") for f in os.listdir(tmp))
             enc.model.close()
             how = ("JPEG decode on the GPU (bit-identical to Pillow), the main process reads the bytes" if gpu_decode
@@ -551,6 +553,9 @@ def embed_e2e(dev, n=4096, size=512, workers=16, batch=256):
             out.append({"workload": f"embed_driver on {n} generated {size}x{size} noise JPEG files (quality 90, 4:2:0, ~230 KB each: the entropy "
                                     f"decoder's worst case): {how} -> GPU front end -> ViT-L/14 bf16 -> one .pt per image, start-up included",
                         "value": round(n_emb / dt, 1), "unit": "images/s", "seconds": round(dt, 2), "images": int(n_emb), "pt_files_written": n_pt,
+                        # the same run without its start-up: from the first batch in the store to the last one
+                        "first_batch_stored_after_s": round(log[0][0] - t0, 3) if log else None,
+                        "steady_images_per_s": round(steady, 1) if steady else None,
                         "workers": 0 if gpu_decode else workers, "batch": batch})
         return tuple(out)
     finally:

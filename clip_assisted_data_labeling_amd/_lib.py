@@ -104,6 +104,7 @@ SIGNATURES = {
     "jpegdec_destroy": (c_int, [c_void_p]),
     "jpegdec_plan": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "jpegdec_run": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "jpegdec_reserve": (c_int, [c_void_p, ctypes.c_ulonglong, ctypes.c_ulonglong]),
     "jpegdec_reason": (ctypes.c_char_p, [c_int]),
     "jpegdec_probe": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
 }

@@ -1286,7 +1286,17 @@ int jpegdec_run(jpegdec_t d, void* rgb_dev, int* status, void* stream) {
   if (!d || !status) return fail("jpegdec_run: NULL argument");
   HIP_TRY(hipSetDevice(d->device));
   hipError_t err = ce_jpegdec_run(d->st, rgb_dev, status, (hipStream_t)stream);
+  if (err == hipErrorOutOfMemory) { fail("jpegdec_run: no device scratch / page-locked staging for this batch"); return CLIPENC_JPEGDEC_NO_MEMORY; }
   if (err != hipSuccess) return fail("jpegdec_run failed: %s", hipGetErrorString(err));
+  return 0;
+}
+
+int jpegdec_reserve(jpegdec_t d, unsigned long long scratch_bytes, unsigned long long staging_bytes) {
+  if (!d) return fail("jpegdec_reserve: NULL argument");
+  HIP_TRY(hipSetDevice(d->device));
+  hipError_t err = ce_jpegdec_reserve(d->st, (size_t)scratch_bytes, (size_t)staging_bytes);
+  if (err == hipErrorOutOfMemory) { fail("jpegdec_reserve: %llu + %llu bytes not available", scratch_bytes, staging_bytes); return CLIPENC_JPEGDEC_NO_MEMORY; }
+  if (err != hipSuccess) return fail("jpegdec_reserve failed: %s", hipGetErrorString(err));
   return 0;
 }
 

@@ -75,8 +75,13 @@ __global__ __launch_bounds__(ENT_THREADS) void jpeg_entropy_kernel(const ImageDe
     sc[i].dirty = 1;
   }
   __syncthreads();
-  // ---- synchronisation passes: at most N (after pass t the entries 0 .. t are the true ones); typically 2-3
-  for (uint32_t pass = 0; pass <= N; ++pass) {
+  // ---- synchronisation passes: at most N (after pass t the entries 0 .. t are the true ones); typically 2-3.  Capped: files are
+  // untrusted, and one made not to re-synchronise would walk its up to 32 768 subsequences one pass each (the serial walk's time,
+  // tens of seconds on one workgroup while the host waits).  Content that needs more than MAX_SYNC_PASSES passes -- megabytes of
+  // flat scan data, i.e. hundreds of megapixels -- is flagged like corrupt entropy data and goes to the caller's Pillow path.
+  constexpr uint32_t MAX_SYNC_PASSES = 1024;
+  bool converged = false;
+  for (uint32_t pass = 0; pass <= N && pass < MAX_SYNC_PASSES; ++pass) {
     for (uint32_t i = tid; i < N; i += ENT_THREADS) {
       if (!sc[i].dirty) continue;
       sc[i].dirty = 0;
@@ -97,7 +102,11 @@ __global__ __launch_bounds__(ENT_THREADS) void jpeg_entropy_kernel(const ImageDe
       if (q.last) continue;                                      // the next subsequence starts an interval: its entry is known
       if (sc[i + 1].entry != sc[i].exit) { sc[i + 1].entry = sc[i].exit; sc[i + 1].dirty = 1; changed = 1; }
     }
-    if (!__syncthreads_or(changed)) break;
+    if (!__syncthreads_or(changed)) { converged = true; break; }
+  }
+  if (!converged) {                                               // (uniform: every thread saw the same votes)
+    if (tid == 0) status[blockIdx.x] = 4;
+    return;
   }
   // ---- block index and DC predictors at every entry: prefix sums inside each restart interval
   for (int j = tid; j < n_iv; j += ENT_THREADS) {
@@ -349,24 +358,35 @@ void ce_jpegdec_plan(JpegDecState* s, const void* const* files, const size_t* si
   *rgb_bytes = rgb;
 }
 
+// Device scratch and page-locked staging of at least these sizes (never shrinks; 0 = leave as is).  On failure the state keeps
+// no buffer of that kind (capacity 0) and the error is returned.
+hipError_t ce_jpegdec_reserve(JpegDecState* s, size_t arena_bytes, size_t stage_bytes) {
+  if (arena_bytes > s->arena_cap) {
+    if (s->arena) (void)hipFree(s->arena);
+    s->arena = nullptr; s->arena_cap = 0;
+    if (hipError_t e = hipMalloc(&s->arena, arena_bytes); e != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
+    s->arena_cap = arena_bytes;
+  }
+  if (stage_bytes > s->stage_cap) {
+    if (s->stage) (void)hipHostFree(s->stage);
+    s->stage = nullptr; s->stage_cap = 0;
+    if (hipError_t e = hipHostMalloc(&s->stage, stage_bytes, hipHostMallocDefault); e != hipSuccess) { (void)hipGetLastError(); return hipErrorOutOfMemory; }
+    s->stage_cap = stage_bytes;
+  }
+  return hipSuccess;
+}
+
 // Decodes the planned batch into rgb_dev (>= the plan's rgb_bytes); synchronises the stream; dev_status[i] for every INPUT file:
 // unchanged for the ones the plan refused, 0 or 100 + code for the decoded ones (entropy data ran out / invalid code).
 hipError_t ce_jpegdec_run(JpegDecState* s, void* rgb_dev, int* status, hipStream_t stream) {
   const size_t m = s->descs.size();
   if (m == 0) return hipSuccess;
-  if (s->arena_cap < s->arena_bytes) {
-    if (s->arena) (void)hipFree(s->arena);
-    s->arena = nullptr; s->arena_cap = 0;
-    const size_t want = s->arena_bytes + s->arena_bytes / 4;
-    if (hipError_t e = hipMalloc(&s->arena, want); e != hipSuccess) return e;
-    s->arena_cap = want;
-  }
-  if (s->stage_cap < s->stage_bytes) {
-    if (s->stage) (void)hipHostFree(s->stage);
-    s->stage = nullptr; s->stage_cap = 0;
-    const size_t want = s->stage_bytes + s->stage_bytes / 4;
-    if (hipError_t e = hipHostMalloc(&s->stage, want, hipHostMallocDefault); e != hipSuccess) return e;
-    s->stage_cap = want;
+  // (growth only when a batch exceeds what ce_jpegdec_reserve set aside: hipFree / hipMalloc synchronise the whole device, i.e.
+  //  stall an encoder running on another stream -- the embed driver reserves once, before the encoder starts)
+  if (hipError_t e = ce_jpegdec_reserve(s, s->arena_bytes > s->arena_cap ? s->arena_bytes + s->arena_bytes / 2 : 0,
+                                        s->stage_bytes > s->stage_cap ? s->stage_bytes + s->stage_bytes / 2 : 0); e != hipSuccess) {
+    // not even the exact size?  (the caller hands the batch to its own decoder on hipErrorOutOfMemory)
+    if (hipError_t e2 = ce_jpegdec_reserve(s, s->arena_bytes, s->stage_bytes); e2 != hipSuccess) return e2;
   }
   uint8_t* st = (uint8_t*)s->stage;
   memset(st, 0xff, m * sizeof(int));                          // status words: -1 until the entropy kernel has written them

@@ -175,7 +175,7 @@ int parse_jpeg(const uint8_t* data, size_t len, ImageDesc* d, size_t* scan_off, 
     if (seg < 2 || pos + (size_t)seg > len) return JPG_TRUNCATED;
     const uint8_t* s = data + pos + 2;
     const int n = seg - 2;
-    if (m == 0xE0 && n >= 5 && !memcmp(s, "JFIF\0", 5)) jfif = true;
+    if (m == 0xE0 && n >= 14 && !memcmp(s, "JFIF\0", 5)) jfif = true;   // libjpeg's examine_app0: a JFIF APP0 has >= 14 data bytes
     else if (m == 0xEE && n >= 12 && !memcmp(s, "Adobe", 5)) { adobe = true; adobe_transform = s[11]; }
     else if (m == 0xDB) {                                         // DQT
       if (frame_done) return JPG_TABLES;                          // (redefined between scans: not met in practice)

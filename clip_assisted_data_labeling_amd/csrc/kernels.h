@@ -43,6 +43,7 @@ void ce_jpegdec_destroy(JpegDecState* s);
 void ce_jpegdec_plan(JpegDecState* s, const void* const* files, const size_t* sizes, int n, int* status, int* widths, int* heights,
                      unsigned long long* rgb_offsets, unsigned long long* rgb_bytes);
 hipError_t ce_jpegdec_run(JpegDecState* s, void* rgb_dev, int* status, hipStream_t stream);
+hipError_t ce_jpegdec_reserve(JpegDecState* s, size_t arena_bytes, size_t stage_bytes);
 
 // fctrain.hip
 struct FcTrainState;

@@ -87,6 +87,19 @@ def _collate(batch):
     return ok, bad
 
 
+def chunk_cut(pixels: Sequence[int], max_files: int, max_pixels: int) -> int:
+    """How many of the next files form one decode chunk: at most `max_files`, and as many as fit `max_pixels` decoded pixels --
+    but always at least one (a single image over the budget is decoded alone).  `pixels[i]` = width * height of file i as its
+    header states it (0 for files that do not go to the device)."""
+    take, total = 0, 0
+    for px in pixels[:max(1, max_files)]:
+        if take > 0 and total + px > max_pixels:
+            break
+        total += px
+        take += 1
+    return take
+
+
 def find_images(root_dir: str) -> List[str]:
     paths = []
     for root, _, files in os.walk(root_dir):
@@ -118,6 +131,11 @@ class Feature_Dataset:
         self.gpu_decode = bool(gpu_decode)
         self.decode_chunk = max(int(decode_chunk), 1)
         self.gpu_decode_max_bytes = 64 << 20                # larger files: Pillow in the reader threads (see gpu_decoded_batches)
+        # Device memory of one decode chunk: its decoded images (3 bytes per pixel) live from the decode until the chunk's crops
+        # are cut, next to ~4.5 bytes per pixel of decoder scratch.  A chunk is therefore cut at `decode_chunk` files OR at this
+        # many pixels, whichever comes first (1 Gpx = 7.5 GB; 2 048 twelve-megapixel photos would be 74 GB of RGB alone).
+        self.gpu_decode_max_pixels = 1_000_000_000
+        self.gpu_decode_read_ahead_bytes = 2 << 30          # file bytes the reader pool may hold ahead of the decoder
         # Progressive files: the device takes them, but walks each with ONE lane (scans are serial), 0.25 - 0.5 s for a chunk
         # during which its small workgroups sit on every CU and the encoder's persistent kernels cannot be placed -- with host
         # cores to spare Pillow in the reader threads is the better deal; set True on a box without them.
@@ -199,8 +217,18 @@ class Feature_Dataset:
         # background), so the per-image upload is an asynchronous DMA instead of a 0.6 ms synchronous pageable copy
         loader = DataLoader(dataset, pin_memory=on_gpu, **kwargs) if self.jpeg is None else []   # (gpu_decode: no workers)
 
+        import time as _time
+        self.progress_log = []                             # (perf_counter, images stored so far) after every batch: start-up vs steady state
+
         def finish(batch, features):
             """Host side of one batch: embeddings [sum crops, E] (CPU fp32) -> the store."""
+            nonlocal writer, n_embedded
+            try:
+                _finish(batch, features)
+            finally:
+                self.progress_log.append((_time.perf_counter(), n_embedded))
+
+        def _finish(batch, features):
             nonlocal writer, n_embedded
             counts = [b[0].shape[0] for b in batch]
             if self.packed_store:                          # one sequential write per batch instead of one pickle per image
@@ -233,118 +261,204 @@ class Feature_Dataset:
                     print(f"Error saving features to {feature_save_path}: {e}")
                 n_embedded += 1
 
-        # Two-deep pipeline on the GPU: while batch i is being encoded (kernel launches are asynchronous), the host
-        # decodes / crops batch i+1 and writes batch i-1 to the store; the only waits are on that older batch's copy event.
-        pending = None                                     # (batch meta, pinned host tensor, event)
+        # Three stages, each on its own thread, handing batches on through bounded queues:
+        #   stager  (gpu_decode only): file bytes read ahead by a reader pool -> JPEG decode of one chunk on a SIDE stream -> the
+        #           chunk's crops cut on that stream batch by batch (the decoded images are dropped as soon as their crops exist)
+        #   encoder (this thread): waits for a batch's crops (stream event), encodes, starts the copy of the embeddings to
+        #           page-locked memory and moves on -- kernel launches are asynchronous, so the GPU never waits for the host
+        #   writer: waits for a batch's copy event and writes the store (one torch.save per image, or one append per batch)
+        import queue
+        import threading
+        out_q: "queue.Queue" = queue.Queue(maxsize=4)
+        writer_errors: List[BaseException] = []
+
+        def writer_loop():
+            while True:
+                item = out_q.get()
+                if item is None:
+                    return
+                if writer_errors:                           # keep draining so that the encoder never blocks on a dead writer
+                    continue
+                try:
+                    meta, host, ev = item
+                    if ev is not None:
+                        ev.synchronize()
+                    finish(meta, host)
+                except BaseException as e:                  # noqa: BLE001 -- re-raised in the main thread
+                    writer_errors.append(e)
 
         def gpu_decoded_batches():
-            """`decode_chunk` files at a time: bytes (read ahead by a thread pool while the GPU works on the chunk before) ->
-            GPU JPEG decode -> encode batches of (uint8 [H, W, 3] device tensor, "", path, True)"""
+            """-> (batch meta [(_Shape(crops), names, path, True)], uint8 crops [sum crops, 3, R, R] on the GPU, stream event)"""
             nonlocal n_failed
+            import collections
+            import io
             import numpy as np
             from concurrent.futures import ThreadPoolExecutor
 
             def read(path):
-                """file bytes -- or, for a file the device decoder does not take (a header check, microseconds) or one over
-                `gpu_decode_max_bytes` (64 MiB: a guard, not a tuning knob), the image decoded right here with Pillow: the
-                pool's threads run in parallel, Pillow and the check release the GIL"""
+                """-> (payload, pixels): the file's bytes (pixels = width * height from its header) -- or, for a file the device
+                decoder does not take (a header check, microseconds) or one over `gpu_decode_max_bytes` (64 MiB: a guard, not a
+                tuning knob), the image decoded right here with Pillow (pixels = 0): the pool's threads run in parallel, Pillow
+                and the check release the GIL.  (None, 0): unreadable."""
                 try:
                     with open(path, "rb") as f:
                         blob = f.read()
-                    if len(blob) > self.gpu_decode_max_bytes or not self.jpeg.takes(blob, progressive=self.gpu_decode_progressive):
+                    ok, w, h, scans = self.jpeg.probe(blob) if len(blob) <= self.gpu_decode_max_bytes else (False, 0, 0, 0)
+                    if not ok or (scans != 1 and not self.gpu_decode_progressive):
                         # CMYK / PNG / ... and, unless asked for, progressive JPEG: Pillow, as the reference -- here, in the
-                        # pool, so that such files are decoded in parallel and not one after the other in the main process
-                        import io
-                        return torch.from_numpy(np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"), dtype=np.uint8).copy())
-                    return blob
+                        # pool, so that such files are decoded in parallel and not one after the other
+                        return torch.from_numpy(np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"), dtype=np.uint8).copy()), 0
+                    return blob, w * h
                 except Exception as e:
                     print(f"Error loading or processing image {path}: {e}")
-                    return None
+                    return None, 0
 
-            chunks = [todo[i:i + self.decode_chunk] for i in range(0, len(todo), self.decode_chunk)]
-            side = torch.cuda.Stream(device=self.device)            # the decode of chunk i + 1 runs beside the encode of chunk i
+            side = torch.cuda.Stream(device=self.device)            # decode + crop of what comes next, beside the encoder
+            in_q: "queue.Queue" = queue.Queue(maxsize=3)
+            stop = threading.Event()
 
-            def stage(chunk):
-                """one chunk, in the staging thread: its files read by the reader pool (in parallel), its JPEGs decoded on
-                the side stream (host part -- parsing, unstuffing, the copy -- and kernels; the call returns when they are done)"""
-                blobs = list(readers.map(read, chunk))
-                with torch.cuda.stream(side):
-                    images, status = self.jpeg.decode([b if isinstance(b, bytes) else b"" for b in blobs])
-                return blobs, images, status
+            def put(item):
+                while not stop.is_set():
+                    try:
+                        in_q.put(item, timeout=0.2)
+                        return True
+                    except queue.Full:
+                        continue
+                return False
 
-            with ThreadPoolExecutor(max(2, min(16, self.num_workers or 8))) as readers, ThreadPoolExecutor(1) as stager:
-                ahead = [stager.submit(stage, c) for c in chunks[:1]]
-                for ci, chunk in enumerate(chunks):
-                    if ci + 1 < len(chunks):
-                        ahead.append(stager.submit(stage, chunks[ci + 1]))
-                    blobs, images, status = ahead.pop(0).result()
-                    for im in images:                               # decoded on the side stream, consumed on this one
-                        if im is not None:
-                            im.record_stream(torch.cuda.current_stream(self.device))
-                    acc = []
-                    for path, blob, img, st in zip(chunk, blobs, images, status):
-                        if isinstance(blob, torch.Tensor):          # decoded by Pillow in a reader thread
-                            img, blob = blob, None
-                        if img is None and blob is not None:      # the device flagged its entropy data: Pillow decides, as the reference
-                            try:
-                                import io
-                                arr = np.asarray(Image.open(io.BytesIO(blob)).convert("RGB"), dtype=np.uint8)
-                                img = torch.from_numpy(arr.copy())
-                            except Exception as e:
-                                print(f"Error loading or processing image {path}: {e}")
-                        if img is None:
-                            n_failed += 1
-                            continue
-                        acc.append((img, "", path, True))
-                        if len(acc) == self.batch_size:
-                            yield acc
-                            acc = []
-                    if acc:
-                        yield acc
+            def stager():
+                try:
+                    with ThreadPoolExecutor(max(2, min(16, self.num_workers or 8))) as readers:
+                        ahead = collections.deque()             # (path, future, file bytes) in file order
+                        nxt, ahead_bytes, limit, reserved = 0, 0, self.batch_size, False
+                        while (nxt < len(todo) or ahead) and not stop.is_set():
+                            # the first chunk is ONE encode batch (the encoder starts after a few milliseconds of decoding),
+                            # then chunks double up to `decode_chunk` files: the entropy decoder's parallelism is the files in flight
+                            while nxt < len(todo) and len(ahead) < max(limit, self.batch_size) * 2 and ahead_bytes < self.gpu_decode_read_ahead_bytes:
+                                try:
+                                    size = os.path.getsize(todo[nxt])
+                                except OSError:
+                                    size = 0
+                                ahead.append((todo[nxt], readers.submit(read, todo[nxt]), size))
+                                ahead_bytes += size
+                                nxt += 1
+                            window = []
+                            for path, fut, size in list(ahead)[:limit]:
+                                window.append((path, fut.result(), size))
+                            take = chunk_cut([w[1][1] for w in window], limit, self.gpu_decode_max_pixels)
+                            chunk = window[:take]
+                            if not reserved:
+                                # scratch for a FULL chunk of files like these, set aside now -- the encoder has not started, so
+                                # the allocation's device synchronisation costs nothing (later growth would stall it)
+                                reserved = True
+                                dev_files = [w for w in window if isinstance(w[1][0], bytes)]
+                                if dev_files:
+                                    scale = self.decode_chunk / len(dev_files)
+                                    px = min(self.gpu_decode_max_pixels, int(sum(w[1][1] for w in dev_files) * scale * 1.1))
+                                    self.jpeg.reserve(px, int(sum(len(w[1][0]) for w in dev_files) * scale * 1.1))
+                            for _ in range(take):
+                                ahead_bytes -= ahead.popleft()[2]
+                            limit = min(self.decode_chunk, limit * 2)
+                            with torch.cuda.stream(side):
+                                images, status = self.jpeg.decode([c[1][0] if isinstance(c[1][0], bytes) else b"" for c in chunk],
+                                                                  max_batch_pixels=max(self.gpu_decode_max_pixels, 1))
+                                acc, failed = [], 0
+                                for (path, (payload, _px), _sz), img, st in zip(chunk, images, status):
+                                    if isinstance(payload, torch.Tensor):   # decoded by Pillow in a reader thread
+                                        img = payload
+                                    elif img is None and payload is not None:   # the device flagged its entropy data: Pillow decides, as the reference
+                                        try:
+                                            img = torch.from_numpy(np.asarray(Image.open(io.BytesIO(payload)).convert("RGB"), dtype=np.uint8).copy())
+                                        except Exception as e:
+                                            print(f"Error loading or processing image {path}: {e}")
+                                    if img is None:
+                                        failed += 1
+                                        continue
+                                    acc.append((img, path))
+                                del images
+                                for b0 in range(0, len(acc), self.batch_size):
+                                    part = acc[b0:b0 + self.batch_size]
+                                    stacked, names_all = self.cropper.batch([im for im, _ in part])
+                                    ev = torch.cuda.Event()
+                                    ev.record(side)
+                                    meta = [(_Shape(len(n)), ",".join(n), path, True) for n, (_, path) in zip(names_all, part)]
+                                    if not put(("batch", meta, stacked, ev, failed)):
+                                        return
+                                    failed = 0
+                                if failed:
+                                    put(("batch", [], None, None, failed))
+                                del acc                          # the chunk's decoded images: their crops are cut (stream-ordered free)
+                    put(("end",))
+                except BaseException as e:                      # noqa: BLE001 -- re-raised in the main thread
+                    put(("error", e))
+
+            th = threading.Thread(target=stager, name="embed-stager", daemon=True)
+            th.start()
+            try:
+                while True:
+                    item = in_q.get()
+                    if item[0] == "end":
+                        break
+                    if item[0] == "error":
+                        raise item[1]
+                    _, meta, stacked, ev, failed = item
+                    n_failed += failed
+                    if meta:
+                        yield meta, stacked, ev
+            finally:
+                stop.set()
+                th.join()
 
         def encode_batches():
-            """loader batches regrouped into encode batches of `batch_size` images"""
+            """-> (batch meta, crops on the GPU, event or None): loader batches regrouped into encode batches of `batch_size` images"""
             nonlocal n_failed
             if self.jpeg is not None:
                 yield from gpu_decoded_batches()
                 return
+
+            def ready(ok):
+                if self.cropper:
+                    # all images of the batch go through the GPU front end in three launches (crop geometry on the host,
+                    # uploads from page-locked memory are asynchronous)
+                    stacked, names_all = self.cropper.batch([b[0] for b in ok])
+                    return [(_Shape(len(n)), ",".join(n), b[2], True) for n, b in zip(names_all, ok)], stacked, None
+                stacked = torch.cat([b[0] for b in ok], 0).to(self.device, non_blocking=True)   # [sum crops, 3, R, R], row = image-major
+                return [(_Shape(b[0].shape[0]), b[1], b[2], b[3]) for b in ok], stacked, None    # the crop tensors are not kept: only their counts
             acc = []
             for ok_part, bad in loader:
                 n_failed += len(bad)
                 acc.extend(ok_part)
                 while len(acc) >= self.batch_size:
-                    yield acc[:self.batch_size]
+                    yield ready(acc[:self.batch_size])
                     acc = acc[self.batch_size:]
             if acc:
-                yield acc
+                yield ready(acc)
 
         def run():
-            nonlocal pending
-            for ok in encode_batches():
-                if self.cropper:
-                    # all images of the batch go through the GPU front end in three launches (crop geometry on the host,
-                    # uploads from page-locked memory are asynchronous)
-                    stacked, names_all = self.cropper.batch([b[0] for b in ok])
-                    per = [len(n) for n in names_all]
-                    ok = [(_Shape(k), ",".join(n), b[2], True) for k, n, b in zip(per, names_all, ok)]
-                else:
-                    stacked = torch.cat([b[0] for b in ok], 0).to(self.device, non_blocking=True)   # [sum crops, 3, R, R], row = image-major
-                features = self.encoder.encode_image(stacked).float()                            # :130
-                counts_only = [(_Shape(b[0].shape[0]), b[1], b[2], b[3]) for b in ok]           # the crop tensors are not kept: only their counts
-                if on_gpu:
-                    host = torch.empty(features.shape, dtype=torch.float32, pin_memory=True)
-                    host.copy_(features, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                    if pending is not None:
-                        pending[2].synchronize()
-                        finish(pending[0], pending[1])
-                    pending = (counts_only, host, ev)
-                else:
-                    finish(counts_only, features.cpu())
-            if pending is not None:
-                pending[2].synchronize()
-                finish(pending[0], pending[1])
+            wt = threading.Thread(target=writer_loop, name="embed-writer", daemon=True)
+            wt.start()
+            try:
+                for meta, stacked, ev in encode_batches():
+                    if writer_errors:
+                        break
+                    if ev is not None:                          # crops cut on the side stream: order this stream behind them
+                        cur = torch.cuda.current_stream(stacked.device)
+                        cur.wait_event(ev)
+                        stacked.record_stream(cur)
+                    features = self.encoder.encode_image(stacked).float()                        # :130
+                    if on_gpu:
+                        host = torch.empty(features.shape, dtype=torch.float32, pin_memory=True)
+                        host.copy_(features, non_blocking=True)
+                        done = torch.cuda.Event()
+                        done.record()
+                        out_q.put((meta, host, done))
+                    else:
+                        out_q.put((meta, features.cpu(), None))
+            finally:
+                out_q.put(None)
+                wt.join()
+            if writer_errors:
+                raise writer_errors[0]
 
         try:
             run()
@@ -372,7 +486,7 @@ def main(argv=None):
                         help="Workers only decode; crops, bicubic resize and normalise run on the GPU (bit-exact with Pillow)")
     parser.add_argument("--gpu_decode", action="store_true",
                         help="JPEG files are decoded on the GPU too (bit-identical to Pillow; implies --gpu_preprocess); other "
-                             "formats and JPEG variants the decoder does not take go through Pillow in the main process")
+                             "formats and JPEG variants the decoder does not take go through Pillow in the reader threads")
     parser.add_argument("--packed_store", type=str, default=None,
                         help="Write embeddings to packed shards in this directory instead of one .pt per image")
     args = parser.parse_args(argv)

@@ -34,14 +34,35 @@ class GpuJpegDecoder:
             return False
         return progressive or n.value == 1
 
+    def probe(self, data: bytes):
+        """host only, thread-safe: (taken, width, height, n_scans) from the file's headers (0 x 0 when it is not a JPEG the decoder
+        can read at all); what the driver's reader threads cut decode chunks by."""
+        n, w, h = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        rc = self.lib.jpegdec_probe(data, len(data), ctypes.byref(w), ctypes.byref(h), ctypes.byref(n))
+        return rc == 0, int(w.value), int(h.value), int(n.value)
+
+    NO_MEMORY = 77            # CLIPENC_JPEGDEC_NO_MEMORY (include/clipenc.h); as a per-file status: "decode it yourself"
+
+    def reserve(self, pixels: int, file_bytes: int) -> bool:
+        """Sets aside device scratch and page-locked staging for batches of up to `pixels` decoded pixels from `file_bytes` of
+        files (about 4.5 bytes per pixel + the files' bytes; the staging buffer takes the files' bytes).  Call it before other
+        work runs on the device: growing these buffers later synchronises the device.  False when the memory is not there."""
+        rc = self.lib.jpegdec_reserve(self.handle, int(pixels * 4.5) + int(file_bytes * 1.25) + (1 << 20), int(file_bytes * 1.25) + (1 << 20))
+        if rc == self.NO_MEMORY:
+            return False
+        _lib.check(rc, "jpegdec_reserve")
+        return True
+
     def reason(self, code: int) -> str:
+        if int(code) == self.NO_MEMORY:
+            return "no device scratch for this batch"
         return self.lib.jpegdec_reason(int(code)).decode()
 
     @torch.no_grad()
     def decode(self, files: Sequence[bytes], max_batch_pixels: int = 2_000_000_000, max_batch_files: int = 16384) -> Tuple[List[Optional[torch.Tensor]], List[int]]:
         """files: the bytes of each file -> (images, status): images[i] a uint8 [H, W, 3] tensor on the GPU (a view into a
-        batch buffer) or None when status[i] != 0 (1..12: not decodable here, see `reason`; >= 100: corrupt or truncated entropy
-        data).  The device works on all files of a call at once -- the entropy decoder is one serial stream per file, so its
+        batch buffer) or None when status[i] != 0 (1..12: not decodable here, see `reason`; 77: no device memory for its group;
+        >= 100: corrupt or truncated entropy data).  The device works on all files of a call at once -- the entropy decoder is one serial stream per file, so its
         throughput IS the number of files in flight -- except that a call is split into groups of at most `max_batch_pixels`
         pixels (7.5 bytes of device scratch + output per pixel: 15 GB at the default) and `max_batch_files` files (the C entry point takes
         65535 per call)."""
@@ -73,8 +94,17 @@ class GpuJpegDecoder:
             if take < m:                                          # plan again for the group that fits
                 _lib.check(self.lib.jpegdec_plan(self.handle, ptrs, sizes, take, status, widths, heights, offsets, ctypes.byref(total)),
                            "jpegdec_plan")
-            rgb = torch.empty(max(int(total.value), 1), dtype=torch.uint8, device=self.device)
-            _lib.check(self.lib.jpegdec_run(self.handle, rgb.data_ptr(), status, _lib.current_stream_ptr(self.device)), "jpegdec_run")
+            try:
+                rgb = torch.empty(max(int(total.value), 1), dtype=torch.uint8, device=self.device)
+                rc = self.lib.jpegdec_run(self.handle, rgb.data_ptr(), status, _lib.current_stream_ptr(self.device))
+            except torch.OutOfMemoryError:
+                rc = self.NO_MEMORY
+            if rc == self.NO_MEMORY:                              # no room for this group: its files go back to the caller undecoded
+                for i in range(take):
+                    status_all[start + i] = int(status[i]) or self.NO_MEMORY
+                start += take
+                continue
+            _lib.check(rc, "jpegdec_run")
             for i in range(take):
                 status_all[start + i] = int(status[i])
                 if status[i] == 0:

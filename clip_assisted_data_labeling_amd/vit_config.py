@@ -230,12 +230,18 @@ _TAG_ALIASES = {"openai": ("openai",), "laion2b_s32b_b82k": ("laion2b-s32b-b82k"
                 "dfn2b": ("dfn2b",)}
 
 
+# what open_clip appends to an architecture name to make ANOTHER architecture: 'ViT-B-16-plus-240', 'ViT-B-32-quickgelu',
+# 'ViT-L-14-CLIPA-336', 'ViT-B-16-SigLIP-256', 'ViT-L-14-336', 'ViT-B-32-256', ...
+_ARCH_QUALIFIERS = r"-(?:\d|plus|quickgelu|clipa|siglip|so400m|worldwide|xl|bigg|g\b)"
+
+
 def _has_component(name: str, part: str) -> bool:
-    """`part` occurs in `name` as a whole component: not glued to more letters/digits on either side and not followed by
-    '-<digit>' ('vit-l-14' must not accept a 'vit-l-14-336' repository)."""
+    """`part` occurs in `name` as a whole architecture name: not glued to more letters/digits on either side and not followed
+    by a qualifier that names another architecture ('vit-l-14' must not accept a 'vit-l-14-336' repository, 'vit-b-16' not a
+    'vit-b-16-plus-240' or 'vit-b-16-siglip' one)."""
     for m in re.finditer(re.escape(part), name):
         before = name[m.start() - 1] if m.start() > 0 else "-"
-        if not before.isalnum() and not re.match(r"[a-z0-9]|-\d", name[m.end():]):
+        if not before.isalnum() and not re.match(r"[a-z0-9]|" + _ARCH_QUALIFIERS, name[m.end():]):
             return True
     return False
 

@@ -277,6 +277,13 @@ int jpegdec_plan(jpegdec_t d, const void* const* files, const size_t* sizes, int
  * plan filled, or a copy): entries of decoded images become 0, or 100 + code if their entropy-coded data was invalid or short
  * (their pixels are then undefined). */
 int jpegdec_run(jpegdec_t d, void* rgb_dev, int* status, void* stream);
+/* Returned by jpegdec_run / jpegdec_reserve when the device scratch or the page-locked staging buffer cannot be allocated (the
+ * caller decodes that batch by other means -- the embed driver: Pillow -- and goes on). */
+#define CLIPENC_JPEGDEC_NO_MEMORY 77
+/* Sets aside device scratch (about 4.5 bytes per decoded pixel + the files' bytes) and page-locked staging (about the files'
+ * bytes) for the batches to come; never shrinks.  jpegdec_run grows them on demand, but hipFree / hipMalloc synchronise the whole
+ * device -- a caller that runs other work beside the decoder (the embed driver: the encoder) reserves once, up front. */
+int jpegdec_reserve(jpegdec_t d, unsigned long long scratch_bytes, unsigned long long staging_bytes);
 const char* jpegdec_reason(int code);
 /* Host only, no handle, thread-safe: would jpegdec_plan take this file?  Returns 0 or the reason code; *width / *height (may be
  * NULL) whenever the header could be read; *n_scans (may be NULL): 1 for a sequential file, the number of scans of a progressive

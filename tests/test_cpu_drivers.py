@@ -145,3 +145,21 @@ def test_saved_regressor_is_loadable_by_the_reference_class(tmp_path):
     lin = m._linears()
     ref = fcreg_oracle.forward_np([l.weight.detach().numpy() for l in lin], [l.bias.detach().numpy() for l in lin], x)
     assert np.abs(np.load(str(tmp_path / "y.npy")) - ref).max() < 1e-6
+
+
+def test_decode_chunks_are_cut_by_files_and_by_pixels():
+    """embed_driver --gpu_decode: a decode chunk holds at most `decode_chunk` files AND at most `gpu_decode_max_pixels` decoded
+    pixels (3 bytes of RGB + ~4.5 bytes of scratch each on the device) -- but always at least one file."""
+    from clip_assisted_data_labeling_amd.embed_driver import chunk_cut
+    mp12 = 4000 * 3000
+    assert chunk_cut([mp12] * 2048, 2048, 1_000_000_000) == 83                  # 83 x 12 Mpx = 996 Mpx (2 048 of them: 74 GB of RGB)
+    assert chunk_cut([512 * 512] * 5000, 2048, 1_000_000_000) == 2048            # small files: the file count cuts
+    assert chunk_cut([mp12] * 3, 10, 1000) == 1                                  # one image over the budget is decoded alone
+    assert chunk_cut([0, 0, mp12, mp12], 10, mp12) == 3                          # files that go to Pillow (0 pixels) cost nothing
+    assert chunk_cut([], 10, 100) == 0 and chunk_cut([5], 0, 100) == 1
+    sizes, pos, chunks = [100] * 7 + [1000] + [100] * 4, 0, []
+    while pos < len(sizes):
+        n = chunk_cut(sizes[pos:], 5, 450)
+        chunks.append(n)
+        pos += n
+    assert chunks == [4, 3, 1, 4] and sum(chunks) == len(sizes)

@@ -258,6 +258,29 @@ def test_structural_variants_of_the_same_stream_decode_like_pillow():
     assert n >= 60
 
 
+def test_short_jfif_app0_does_not_count_as_jfif():
+    """libjpeg (and so Pillow) sets saw_JFIF_marker only for an APP0 of >= 14 data bytes.  A 3-component file with a 13-byte
+    'JFIF' APP0 and an Adobe marker with transform 0 is RGB-coded for libjpeg -- read as JFIF it would be converted from YCbCr,
+    i.e. differ from Pillow.  The parser must take the Adobe rule (and leave RGB-coded files to the caller's Pillow path)."""
+    import struct
+    img = np.random.RandomState(1).randint(0, 256, (24, 31, 3), dtype=np.uint8)
+    data = _jpeg(img, quality=90, subsampling=0)
+    segs, rest = _segments(data)
+    adobe = (0xEE, struct.pack('>H', 2 + 12) + b'Adobe' + struct.pack('>HHHB', 100, 0, 0, 0))           # transform = 0
+    assert segs[0][0] == 0xE0                                              # Pillow writes the JFIF APP0 first
+    for n_app0 in (12, 13):
+        short = (0xE0, struct.pack('>H', 2 + n_app0) + (b'JFIF\0\x01\x01\x00\x00\x01\x00\x01\x00\x00')[:n_app0])
+        v = _rebuild([short, adobe] + segs[1:], rest)
+        ref = _pil(v)                                                  # Pillow / libjpeg: Adobe transform 0 = no colour conversion
+        rc = jpeg_oracle.info(v)[0]
+        if rc == 0:
+            assert np.array_equal(jpeg_oracle.decode(v), ref), n_app0
+        else:
+            assert jpeg_oracle.REASONS[rc] == "colour space", (n_app0, rc)
+    full = _rebuild([segs[0], adobe] + segs[1:], rest)                   # a proper 14-byte JFIF APP0 wins over Adobe, as in libjpeg
+    assert np.array_equal(jpeg_oracle.decode(full), _pil(full))
+
+
 def test_any_sampling_libjpeg_upsamples_equals_pillow():
     """Streams Pillow cannot be asked to write (tests/jpeg_writer.py entropy-codes random quantised coefficients): 4:4:0 (what a
     losslessly rotated 4:2:2 photo is), 4:1:1, 1x4, 4x2 and 2x4 luma (ten blocks per MCU), chroma planes sampled differently from

@@ -235,6 +235,13 @@ def test_load_weights_from_what_open_clip_leaves_in_cache_dir(tmp_path):
     assert vit_config._has_component("models--laion--clip-vit-l-14-laion2b-s32b-b82k", "vit-l-14")
     assert not vit_config._has_component("models--laion--clip-vit-l-14-336-laion2b", "vit-l-14")
     assert not vit_config._has_component("models--x--clip-convit-l-14-laion2b", "vit-l-14")
+    # qualifiers that name ANOTHER architecture (their tags overlap: laion400m-e32 exists for vit-b-16 and vit-b-16-plus-240)
+    assert not vit_config._has_component("models--timm--vit-b-16-plus-240-laion400m-e32", "vit-b-16")
+    assert not vit_config._has_component("models--x--vit-b-32-quickgelu-metaclip-400m", "vit-b-32")
+    assert not vit_config._has_component("models--timm--vit-b-16-siglip-webli", "vit-b-16")
+    assert not vit_config._has_component("models--x--vit-l-14-clipa-datacomp1b", "vit-l-14")
+    assert vit_config._has_component("models--laion--clip-vit-b-16-laion400m-e32", "vit-b-16")
+    assert vit_config._has_component("models--laion--clip-vit-b-32-datacomp-xl-s13b-b90k", "vit-b-32")    # '-xl' belongs to the TAG here
     # the exact hand-placed file wins over a hub snapshot of the same name pair
     exact = {k: v + 1.0 for k, v in sd.items()}
     torch.save(exact, str(hub / "ViT-tiny-test-laion2b_s32b_b82k.pt"))

@@ -94,6 +94,29 @@ def test_embed_predict_dedup_pipeline(gpu, tmp_path):
     for f in ("b_prog.jpg", "b_prog.pt", "b_png.png", "b_png.pt"):
         os.remove(os.path.join(root, f))
 
+    # a tiny pixel budget (every decode chunk is one or two images) and a device decoder that reports "no memory" for every other
+    # group (those files then take the Pillow route): the same store
+    ds6 = embed_driver.Feature_Dataset(root, MODEL, 4, shuffle_filenames=False, num_workers=0, device="cuda", force_reencode=True,
+                                       gpu_decode=True)
+    ds6.gpu_decode_max_pixels = 30_000                      # images are 100..200 pixels a side
+    calls, real_run = [], ds6.jpeg.lib.jpegdec_run
+
+    class _Lib:                                             # the loaded library with one entry point wrapped
+        def __getattr__(self, name):
+            return getattr(ds6_lib, name)
+
+        def jpegdec_run(self, *a):
+            calls.append(1)
+            return ds6.jpeg.NO_MEMORY if len(calls) % 2 == 0 else real_run(*a)
+    ds6_lib, ds6.jpeg.lib = ds6.jpeg.lib, _Lib()
+    assert ds6.process() == (9, 0, 0) and len(calls) >= 5
+    ds6.jpeg.lib = ds6_lib
+    for f, old in before.items():
+        if f in ("b_prog.pt", "b_png.pt"):
+            continue
+        new = torch.load(os.path.join(root, f), weights_only=True)
+        assert all(torch.equal(new[MODEL][c], old[MODEL][c]) for c in CROP_NAMES), f
+
     # regressor checkpoint in the reference's pickle format, then the predict driver
     sizes = [2 * cfg.embed_dim, 32, 16, 8, 1]
     Ws, bs = np_fc_weights(sizes, 5)
