@@ -556,6 +556,7 @@ def embed_e2e(dev, n=4096, size=512, workers=16, batch=512):
                         # the same run without its start-up: from the first batch in the store to the last one
                         "first_batch_stored_after_s": round(log[0][0] - t0, 3) if log else None,
                         "steady_images_per_s": round(steady, 1) if steady else None,
+                        "timeline_s": {k: round(v - ds.marks["start"], 3) for k, v in ds.marks.items() if k != "start"},
                         "workers": 0 if gpu_decode else workers, "batch": batch})
         return tuple(out)
     finally:

@@ -136,6 +136,8 @@ class Feature_Dataset:
         # many pixels, whichever comes first (1 Gpx = 7.5 GB; 2 048 twelve-megapixel photos would be 74 GB of RGB alone).
         self.gpu_decode_max_pixels = 1_000_000_000
         self.gpu_decode_read_ahead_bytes = 2 << 30          # file bytes the reader pool may hold ahead of the decoder
+        self.pt_writers = 1                                 # threads writing the per-image .pt files of a batch (pickling holds the GIL:
+                                                            # 2 and 4 measured slower than 1 next to the stager thread, tools/ab_embed_e2e.py)
         # Progressive files: the device takes them, but walks each with ONE lane (scans are serial), 0.25 - 0.5 s for a chunk
         # during which its small workgroups sit on every CU and the encoder's persistent kernels cannot be placed -- with host
         # cores to spare Pillow in the reader threads is the better deal; set True on a box without them.
@@ -219,6 +221,8 @@ class Feature_Dataset:
 
         import time as _time
         self.progress_log = []                             # (perf_counter, images stored so far) after every batch: start-up vs steady state
+        self.marks = {"start": _time.perf_counter()}       # first_batch_ready / first_encode_issued / last_encode_issued / done
+        self.stager_log = []                               # gpu_decode: per decode chunk, where the stager's time went
 
         def finish(batch, features):
             """Host side of one batch: embeddings [sum crops, E] (CPU fp32) -> the store."""
@@ -241,8 +245,15 @@ class Feature_Dataset:
                               features.view(len(batch), len(self.crop_names), features.shape[-1]))
                 n_embedded += len(batch)
                 return
-            row = 0
+            # one pickle per image (the reference's store): a few threads -- torch.save spends part of its time in file I/O
+            # outside the GIL, and the LAST batch of a run is written with nothing left to hide behind
+            rows, jobs = 0, []
             for (crops, names, img_path, _), n in zip(batch, counts):
+                jobs.append((img_path, names, rows, n))
+                rows += n
+
+            def write_one(job):
+                img_path, names, row, n = job
                 feature_save_path = os.path.splitext(img_path)[0] + ".pt"
                 final = {}
                 if os.path.exists(feature_save_path) and not self.force_reencode:
@@ -253,13 +264,13 @@ class Feature_Dataset:
                 per_model = {}
                 for j, crop_name in enumerate(names.split(",")):
                     per_model[crop_name] = features[row + j].unsqueeze(0).clone()       # float32 [1, E] on CPU (:157-161)
-                row += n
                 final[self.model_name] = per_model                                     # :164
                 try:
                     torch.save(final, feature_save_path)
                 except Exception as e:
                     print(f"Error saving features to {feature_save_path}: {e}")
-                n_embedded += 1
+                return 1
+            n_embedded += sum(pt_pool.map(write_one, jobs))
 
         # Three stages, each on its own thread, handing batches on through bounded queues:
         #   stager  (gpu_decode only): file bytes read ahead by a reader pool -> JPEG decode of one chunk on a SIDE stream -> the
@@ -269,6 +280,8 @@ class Feature_Dataset:
         #   writer: waits for a batch's copy event and writes the store (one torch.save per image, or one append per batch)
         import queue
         import threading
+        from concurrent.futures import ThreadPoolExecutor as _Pool
+        pt_pool = _Pool(max(1, int(getattr(self, "pt_writers", 1))))
         out_q: "queue.Queue" = queue.Queue(maxsize=4)
         writer_errors: List[BaseException] = []
 
@@ -313,8 +326,15 @@ class Feature_Dataset:
                     print(f"Error loading or processing image {path}: {e}")
                     return None, 0
 
-            side = torch.cuda.Stream(device=self.device)            # decode + crop of what comes next, beside the encoder
-            in_q: "queue.Queue" = queue.Queue(maxsize=3)
+            # The stager enqueues its decode and crop kernels into the ENCODER's stream (HIP streams take launches from several host
+            # threads): they then run between two of the encoder's kernels with the whole GPU to themselves.  On a stream of their
+            # own they only found CUs in the encoder's tail rounds -- its persistent kernels hold every CU -- and a 10-ms entropy
+            # workgroup that got one kept the next persistent kernel waiting for that CU (rocprofv3: 0.37 s of GPU idle time and
+            # stretched kernels in a 2.66-s run).  gpu_decode_side_stream=True restores the separate stream.
+            mode = getattr(self, "gpu_decode_stream", "priority")
+            side = (torch.cuda.current_stream(self.device) if mode == "same" else
+                    torch.cuda.Stream(device=self.device, priority=-1 if mode == "priority" else 0))
+            in_q: "queue.Queue" = queue.Queue(maxsize=int(getattr(self, "gpu_decode_queue", 6)))
             stop = threading.Event()
 
             def put(item):
@@ -330,10 +350,10 @@ class Feature_Dataset:
                 try:
                     with ThreadPoolExecutor(max(2, min(16, self.num_workers or 8))) as readers:
                         ahead = collections.deque()             # (path, future, file bytes) in file order
-                        nxt, ahead_bytes, limit, reserved = 0, 0, self.batch_size, False
+                        # the first chunk is a QUARTER of an encode batch (the encoder starts after a few milliseconds of decoding)
+                        nxt, ahead_bytes, limit, reserved = 0, 0, max(min(32, self.batch_size), self.batch_size // int(getattr(self, "first_chunk_div", 4))), False
                         while (nxt < len(todo) or ahead) and not stop.is_set():
-                            # the first chunk is ONE encode batch (the encoder starts after a few milliseconds of decoding),
-                            # then chunks double up to `decode_chunk` files: the entropy decoder's parallelism is the files in flight
+                            # chunks double up to `decode_chunk` files: the entropy decoder's parallelism is the files in flight
                             while nxt < len(todo) and len(ahead) < max(limit, self.batch_size) * 2 and ahead_bytes < self.gpu_decode_read_ahead_bytes:
                                 try:
                                     size = os.path.getsize(todo[nxt])
@@ -342,9 +362,11 @@ class Feature_Dataset:
                                 ahead.append((todo[nxt], readers.submit(read, todo[nxt]), size))
                                 ahead_bytes += size
                                 nxt += 1
+                            tl = {"t": _time.perf_counter() - self.marks["start"]}
                             window = []
                             for path, fut, size in list(ahead)[:limit]:
                                 window.append((path, fut.result(), size))
+                            tl["reads_s"] = _time.perf_counter() - self.marks["start"] - tl["t"]
                             take = chunk_cut([w[1][1] for w in window], limit, self.gpu_decode_max_pixels)
                             chunk = window[:take]
                             if not reserved:
@@ -359,9 +381,12 @@ class Feature_Dataset:
                             for _ in range(take):
                                 ahead_bytes -= ahead.popleft()[2]
                             limit = min(self.decode_chunk, limit * 2)
+                            tl["files"] = take
+                            t_dec = _time.perf_counter()
                             with torch.cuda.stream(side):
                                 images, status = self.jpeg.decode([c[1][0] if isinstance(c[1][0], bytes) else b"" for c in chunk],
                                                                   max_batch_pixels=max(self.gpu_decode_max_pixels, 1))
+                                tl["decode_s"] = _time.perf_counter() - t_dec
                                 acc, failed = [], 0
                                 for (path, (payload, _px), _sz), img, st in zip(chunk, images, status):
                                     if isinstance(payload, torch.Tensor):   # decoded by Pillow in a reader thread
@@ -376,8 +401,13 @@ class Feature_Dataset:
                                         continue
                                     acc.append((img, path))
                                 del images
-                                for b0 in range(0, len(acc), self.batch_size):
-                                    part = acc[b0:b0 + self.batch_size]
+                                # encode batches of this chunk; the job's LAST batch goes out as two halves, so that the store
+                                # writes of the first half (one pickle per image: ~0.3 ms each) run under the encode of the second
+                                bounds = list(range(0, len(acc), self.batch_size)) + [len(acc)] if acc else [0]
+                                if len(bounds) > 1 and nxt >= len(todo) and not ahead and len(acc) - bounds[-2] > 64:
+                                    bounds.insert(-1, bounds[-2] + (len(acc) - bounds[-2] + 1) // 2)
+                                for b0, b1 in zip(bounds[:-1], bounds[1:]):
+                                    part = acc[b0:b1]
                                     stacked, names_all = self.cropper.batch([im for im, _ in part])
                                     ev = torch.cuda.Event()
                                     ev.record(side)
@@ -387,6 +417,8 @@ class Feature_Dataset:
                                     failed = 0
                                 if failed:
                                     put(("batch", [], None, None, failed))
+                                tl["crop_and_queue_s"] = _time.perf_counter() - t_dec - tl["decode_s"]
+                                self.stager_log.append({k: round(v, 4) if isinstance(v, float) else v for k, v in tl.items()})
                                 del acc                          # the chunk's decoded images: their crops are cut (stream-ordered free)
                     put(("end",))
                 except BaseException as e:                      # noqa: BLE001 -- re-raised in the main thread
@@ -439,6 +471,7 @@ class Feature_Dataset:
             wt.start()
             try:
                 for meta, stacked, ev in encode_batches():
+                    self.marks.setdefault("first_batch_ready", _time.perf_counter())
                     if writer_errors:
                         break
                     if ev is not None:                          # crops cut on the side stream: order this stream behind them
@@ -454,9 +487,12 @@ class Feature_Dataset:
                         out_q.put((meta, host, done))
                     else:
                         out_q.put((meta, features.cpu(), None))
+                    self.marks.setdefault("first_encode_issued", _time.perf_counter())
+                    self.marks["last_encode_issued"] = _time.perf_counter()
             finally:
                 out_q.put(None)
                 wt.join()
+                self.marks["done"] = _time.perf_counter()
             if writer_errors:
                 raise writer_errors[0]
 
@@ -467,6 +503,7 @@ class Feature_Dataset:
             # invisible to readers and to the resume check, i.e. every image already embedded into it would be lost
             if writer is not None:
                 writer.close()
+            pt_pool.shutdown(wait=True)
         print("\n--- Feature encoding done! ---\n")
         print(f"Embedded {n_embedded} images ({n_skipped} images were already embedded, {n_failed} unreadable). "
               f"Features saved with model key '{self.model_name}'.")

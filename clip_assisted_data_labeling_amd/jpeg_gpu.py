@@ -43,11 +43,13 @@ class GpuJpegDecoder:
 
     NO_MEMORY = 77            # CLIPENC_JPEGDEC_NO_MEMORY (include/clipenc.h); as a per-file status: "decode it yourself"
 
-    def reserve(self, pixels: int, file_bytes: int) -> bool:
-        """Sets aside device scratch and page-locked staging for batches of up to `pixels` decoded pixels from `file_bytes` of
-        files (about 4.5 bytes per pixel + the files' bytes; the staging buffer takes the files' bytes).  Call it before other
-        work runs on the device: growing these buffers later synchronises the device.  False when the memory is not there."""
-        rc = self.lib.jpegdec_reserve(self.handle, int(pixels * 4.5) + int(file_bytes * 1.25) + (1 << 20), int(file_bytes * 1.25) + (1 << 20))
+    def reserve(self, pixels: int, file_bytes: int, staging: bool = False) -> bool:
+        """Sets aside device scratch for batches of up to `pixels` decoded pixels from `file_bytes` of files (about 4.5 bytes per
+        pixel + the files' bytes) and, with staging=True, the page-locked staging buffer (the files' bytes; page-locking takes
+        ~0.2 s per GB, so by default it grows with the batches instead).  Call it before other work runs on the device: growing
+        the device scratch later (hipFree + hipMalloc) synchronises the device.  False when the memory is not there."""
+        rc = self.lib.jpegdec_reserve(self.handle, int(pixels * 4.5) + int(file_bytes * 1.25) + (1 << 20),
+                                      int(file_bytes * 1.25) + (1 << 20) if staging else 0)
         if rc == self.NO_MEMORY:
             return False
         _lib.check(rc, "jpegdec_reserve")
