@@ -409,7 +409,7 @@ def per_kernel_table(prof, prof_steps, cfg, crops, fp8=False):
     def find(*subs, shape=None):
         for k in names:
             if shape is not None:
-                if k.startswith("shape:" + shape):
+                if k.startswith("shape:" + shape) and prof[k][1] > 0:
                     return k
             elif not k.startswith("shape:") and all(x in k for x in subs) and prof[k][1] > 0:
                 return k
