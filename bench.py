@@ -585,7 +585,7 @@ def run_job(args, cfg, vit, reg, dev, rank, world, backend):
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -599,7 +599,7 @@ def run_job(args, cfg, vit, reg, dev, rank, world, backend):
     elapsed = time.perf_counter() - t0
     ranks = rank_report(dev, world, rank, res["t_encode"], res["n_local"])
     times = torch.tensor([elapsed, res["t_encode"], res["t_gather"]], device=gdev or dev, dtype=torch.float64)
-    if world > 1:
+    if dist.is_initialized():
         dist.all_reduce(times, op=dist.ReduceOp.MAX)
     elapsed, t_enc, t_gat = (float(x) for x in times.tolist())
     emb, score = res["emb"], res["score"]                 # the whole job on rank 0, None elsewhere
@@ -626,7 +626,7 @@ def run_job(args, cfg, vit, reg, dev, rank, world, backend):
         print(json.dumps({
             "metric": "images/sec (4 crops each) ViT-L/14 encode+score, whole sharded job", "value": round(value, 2), "unit": "images/s",
             "n_gpus": world, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "rccl_ranks": dist.get_world_size() if world > 1 else 1, "ranks": ranks,
+            "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "ranks": ranks,
             "distinct_devices": len({r["uuid"] or r["pci"] for r in ranks}),
             "images_per_s_per_rank": {"min": min(r["images_per_s"] or 0.0 for r in ranks), "max": max(r["images_per_s"] or 0.0 for r in ranks)},
             "t_gather": round(t_gat, 4),
@@ -682,7 +682,7 @@ def rank_report(dev, world, rank, seconds, images):
     mine = {"rank": rank, "device_index": dev.index, "uuid": str(getattr(pr, "uuid", "")), "name": pr.name,
             "pci": f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}",
             "seconds": round(seconds, 4), "images_per_s": round(images / seconds, 2) if seconds > 0 else None}
-    if world == 1:
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()):
         return [mine]
     out = [None] * world
     dist.all_gather_object(out, mine)
@@ -719,6 +719,10 @@ def main():
         sys.exit(self_launch(args.gpus))                     # before anything touches the GPU
     if world != args.gpus:
         args.gpus = world
+    # Under a launcher (WORLD_SIZE set) the process group is initialised even for ONE rank: `torchrun --nproc-per-node 1 bench.py`
+    # then runs the same RCCL calls as the 8-GPU job (communicator set-up, all-gather of the results, MAX all-reduce, barrier) on
+    # the one GPU that is there -- the only RCCL execution a 1-GPU box can offer (tests/test_gpu_bench_contract.py).
+    use_dist = "WORLD_SIZE" in os.environ
     import torch.distributed as dist
     from clip_assisted_data_labeling_amd import vit_config
     from clip_assisted_data_labeling_amd.embedder import HipViT
@@ -730,7 +734,7 @@ def main():
     backend = os.environ.get("BENCH_BACKEND", "nccl")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
@@ -745,20 +749,20 @@ def main():
     n_img = args.images
     if args.job_images > 0:
         run_job(args, cfg, vit, reg, dev, rank, world, backend)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
     crops = synthetic_crops(n_img * CROPS_PER_IMAGE, cfg.image_size, 1234 + rank, dev)   # resident in HBM
     sel = list(range(CROPS_PER_IMAGE))
     gdev = dev if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    if use_dist:
         emb_all = torch.empty((world * n_img, CROPS_PER_IMAGE, cfg.embed_dim), device=gdev)
         score_all = torch.empty((world * n_img, 1), device=gdev)
 
     def step():
         emb, score = vit.encode_score(crops, reg, CROPS_PER_IMAGE, sel)
-        if world > 1:                                       # the one exchange of the path: gather results
+        if use_dist:                                       # the one exchange of the path: gather results
             dist.all_gather_into_tensor(emb_all, emb.to(gdev))
             dist.all_gather_into_tensor(score_all, score.to(gdev))
         return emb, score
@@ -768,7 +772,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -784,7 +788,7 @@ def main():
         elapsed = time.perf_counter() - t0
     ranks = rank_report(dev, world, rank, elapsed, n_img * args.steps)      # every rank's own clock, before the MAX
     t_gather_ms = None
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=gdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -846,7 +850,7 @@ def main():
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend if world > 1 else None,
+            "rccl_ranks": dist.get_world_size() if use_dist else 1, "backend": backend if use_dist else None,
             "ranks": ranks, "distinct_devices": len({r["uuid"] or r["pci"] for r in ranks}),
             "images_per_s_per_rank": {"min": min(r["images_per_s"] for r in ranks), "max": max(r["images_per_s"] for r in ranks)},
             "t_gather_ms": t_gather_ms,
@@ -911,7 +915,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, Ws, bs)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

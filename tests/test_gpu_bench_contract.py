@@ -114,3 +114,27 @@ def test_a_failing_rank_fails_the_plain_command(gpu):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--job-images", "10", "--images", "0"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert p.returncode != 0 and not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_one_rank_under_the_launcher_runs_the_rccl_calls(gpu):
+    """`torchrun --nproc-per-node 1 bench.py`: with WORLD_SIZE set the process group is initialised even for one rank, so the
+    step's all-gather, the MAX all-reduce, the barrier and the rank report go through RCCL ("nccl" on ROCm) on the box's GPU --
+    the one execution of the 8-GPU run's RCCL code path that a 1-GPU box can offer."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BENCH_BACKEND", "BENCH_DEVICE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29577", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--images", "32",
+           "--no-cpu-baseline", "--no-secondary"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _last_json(p.stdout)
+    assert d["n_gpus"] == 1 and d["rccl_ranks"] == 1 and d["backend"] == "nccl" and d["t_gather_ms"] > 0
+    assert d["ranks"][0]["uuid"] and d["distinct_devices"] == 1
+    # ... and the whole-job runner the same way (fp8, ragged: 70 images in batches of 32)
+    cmd = cmd[:cmd.index("--gpus")] + ["--gpus", "1", "--job-images", "70", "--images", "32", "--dtype", "fp8"]
+    cmd[cmd.index("29577")] = "29578"
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = _last_json(p.stdout)
+    assert d["rccl_ranks"] == 1 and d["config"]["job_images"] == 70 and d["checks"]["first_batch_reproduced_bitwise"] is True
