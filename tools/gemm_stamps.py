@@ -45,3 +45,10 @@ for (N, K, kind) in ((1024, 1024, "random"), (1024, 4096, "random"), (4096, 1024
     # how synchronised are the workgroups: spread of the epilogue start times of the k-th tile of every WG
     kth = [sorted(v)[min(3, len(v) - 1)][1] for v in per_wg.values()]
     print(f"   4th-tile epilogue start: spread p10..p90 {np.percentile(kth, 90) - np.percentile(kth, 10):.2f} us")
+    # how much of the launch do the workgroups spend waiting for the slowest one?  (what a dynamic hand-out of the last rounds could win)
+    fin = np.array([max(x[2] for x in v) for v in per_wg.values()]); t_begin = t[:, 0].min()
+    n_tiles = np.array([len(v) for v in per_wg.values()])
+    idle = (fin.max() - fin).mean() / (fin.max() - t_begin)
+    print(f"   finish of the workgroups after the first start: p10 {np.percentile(fin, 10) - t_begin:.1f}  p50 {np.median(fin) - t_begin:.1f}  p90 {np.percentile(fin, 90) - t_begin:.1f}  "
+          f"max {fin.max() - t_begin:.1f} us; tiles per WG {n_tiles.min()}..{n_tiles.max()}; mean idle at the end {100 * idle:.2f} % of the launch "
+          f"(of which the static tail round accounts for {100 * (n_tiles.max() - n_tiles.mean()) / n_tiles.max():.2f} %)")
