@@ -176,6 +176,8 @@ struct clipenc_s {
   DevBuf ws;
   bf16_t *a_patch = nullptr, *pe = nullptr, *x = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr;
   float *stats0 = nullptr, *stats_a = nullptr, *stats_b = nullptr, *stats_c = nullptr;   // stats_c: [parts][chunk] of the CLS rows
+  unsigned* tickets = nullptr;                           // [1024] zeroed per pass: one ticket counter per persistent GEMM launch (gemm.h)
+  bool dynamic_tail = true;                              // (the diagnostic build reads CLIPENC_STATIC_TILES=1 to switch the tickets off)
 };
 
 struct preproc_s {
@@ -228,6 +230,7 @@ int ensure_workspace(clipenc_s* e) {
   const size_t Tp = align_up(T, 256);
   const size_t o_s0 = take(Tp * 8), o_sa = take(parts * Tp * 8), o_sb = take(parts * Tp * 8);
   const size_t o_sc = take(parts * align_up((size_t)c, 256) * 8);
+  const size_t o_tk = take(1024 * sizeof(unsigned));
   const bool f8 = e->precision == CLIPENC_PREC_FP8;
   const size_t o_a8 = f8 ? take(T * (size_t)g.width) : 0, o_sa8 = f8 ? take(T * 4) : 0;
   const bool f8f = f8 && fp8_fused(g);
@@ -245,6 +248,7 @@ int ensure_workspace(clipenc_s* e) {
   e->a_patch = (bf16_t*)(b + o_ap); e->pe = (bf16_t*)(b + o_pe); e->x = (bf16_t*)(b + o_x);
   e->qkv = (bf16_t*)(b + o_qkv); e->attn = (bf16_t*)(b + o_at); e->hid = (bf16_t*)(b + o_h);
   e->stats0 = (float*)(b + o_s0); e->stats_a = (float*)(b + o_sa); e->stats_b = (float*)(b + o_sb); e->stats_c = (float*)(b + o_sc);
+  e->tickets = (unsigned*)(b + o_tk);
   e->a8 = f8 ? (uint8_t*)(b + o_a8) : nullptr; e->sa8 = f8 ? (float*)(b + o_sa8) : nullptr;
   e->x8 = f8f ? (uint8_t*)(b + o_x8) : nullptr; e->xe8 = f8f ? (uint8_t*)(b + o_xe8) : nullptr;
   e->st8 = f8f ? (float*)(b + o_st8) : nullptr; e->rr8 = f8f ? (float*)(b + o_rr8) : nullptr; e->rd8 = f8f ? (float*)(b + o_rd8) : nullptr;
@@ -261,12 +265,16 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
   const int Tp = (int)align_up((size_t)T, 256);
   Profiler& pf = e->prof;
   const double dT = (double)T, dD = (double)g.width;
+  // ticket counters of this pass's persistent GEMM launches (at most 6 per block + the patch GEMM): zeroed by one fill
+  int tk = 0;
+  if (e->dynamic_tail) HIP_TRY(hipMemsetAsync(e->tickets, 0, 1024 * sizeof(unsigned), st));
+  auto ticket = [&]() -> unsigned* { return (e->dynamic_tail && tk < 1024) ? e->tickets + tk++ : nullptr; };
   pf.begin(PK_PATCHIFY, 0.0, st);
   HIP_TRY(ce_patchify(crops, in_dtype, e->a_patch, c, g.image_size, g.patch, e->kpad, e->pix_mean, e->pix_std, st));
   pf.end(st);
   GemmParams p{};
   p.A = e->a_patch; p.lda = e->kpad; p.W = e->w_conv; p.ldw = e->kpad; p.M = P; p.N = g.width; p.K = e->kpad;
-  p.out = e->pe; p.ldo = g.width; p.bias = nullptr;
+  p.out = e->pe; p.ldo = g.width; p.bias = nullptr; p.ticket = ticket();
   pf.begin(PK_GEMM_PATCH, 2.0 * P * dD * (3.0 * g.patch * g.patch), st);
   HIP_TRY(ce_gemm_nt(p, CE_DT_BF16, EPI_STORE_BF16, st));
   pf.end(st);
@@ -451,6 +459,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       kv.A = e->x; kv.lda = Dw; kv.W = L.w_qkv + (size_t)Dw * Dw; kv.ldw = Dw; kv.M = T; kv.N = 2 * Dw; kv.K = Dw;
       kv.out = e->qkv + Dw; kv.ldo = 3 * Dw; kv.bias = L.b_qkv + Dw; kv.colsum = L.cs_qkv + Dw;
       kv.stats_in = stats_in; kv.stats_in_parts = stats_parts; kv.stats_ld = Tp; kv.inv_width = 1.0f / Dw; kv.eps = g.ln_eps; kv.act = -1;
+      kv.ticket = ticket();
       pf.begin(PK_GEMM_QKV, 2.0 * dT * 2.0 * dD * dD, st);
       HIP_TRY(ce_gemm_nt(kv, CE_DT_BF16, EPI_LNFOLD, st));
       pf.end(st);
@@ -464,6 +473,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       qc.A = e->x; qc.lda = stride * Dw; qc.W = L.w_qkv; qc.ldw = Dw; qc.M = c; qc.N = Dw; qc.K = Dw;
       qc.out = e->qkv; qc.ldo = stride * 3 * Dw; qc.bias = L.b_qkv; qc.colsum = L.cs_qkv;
       qc.stats_in = stats_c; qc.stats_in_parts = stats_parts; qc.stats_ld = Tpc; qc.inv_width = 1.0f / Dw; qc.eps = g.ln_eps; qc.act = -1;
+      qc.ticket = ticket();
       pf.begin(PK_GEMM_QKV, 2.0 * c * dD * dD, st);
       HIP_TRY(ce_gemm_nt(qc, CE_DT_BF16, EPI_LNFOLD, st));
       pf.end(st);
@@ -475,6 +485,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       GemmParams o{};
       o.A = e->attn; o.lda = stride * Dw; o.W = L.w_out; o.ldw = Dw; o.M = c; o.N = Dw; o.K = Dw;
       o.out = e->x; o.ldo = stride * Dw; o.bias = L.b_out; o.resid = e->x; o.stats_out = e->stats_a; o.stats_ld = Tpc;
+      o.ticket = ticket();
       pf.begin(PK_GEMM_RESID, 2.0 * c * dD * dD, st, PK_SUB_OUT);
       HIP_TRY(ce_gemm_nt(o, CE_DT_BF16, EPI_RESID, st));
       pf.end(st);
@@ -483,6 +494,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       f.A = e->x; f.lda = stride * Dw; f.W = L.w_fc; f.ldw = Dw; f.M = c; f.N = g.mlp_dim; f.K = Dw;
       f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
       f.stats_in = e->stats_a; f.stats_in_parts = parts; f.stats_ld = Tpc; f.inv_width = 1.0f / Dw; f.eps = g.ln_eps; f.act = g.act;
+      f.ticket = ticket();
       pf.begin(PK_GEMM_FC1, 2.0 * c * dD * g.mlp_dim, st);
       HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
       pf.end(st);
@@ -490,6 +502,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       GemmParams r{};
       r.A = e->hid; r.lda = g.mlp_dim; r.W = L.w_proj; r.ldw = g.mlp_dim; r.M = c; r.N = Dw; r.K = g.mlp_dim;
       r.out = e->x; r.ldo = stride * Dw; r.bias = L.b_proj; r.resid = e->x; r.stats_out = e->stats_b; r.stats_ld = Tpc;
+      r.ticket = ticket();
       pf.begin(PK_GEMM_RESID, 2.0 * c * dD * g.mlp_dim, st, PK_SUB_FC2);
       HIP_TRY(ce_gemm_nt(r, CE_DT_BF16, EPI_RESID, st));
       pf.end(st);
@@ -500,6 +513,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     q.A = e->x; q.lda = g.width; q.W = L.w_qkv; q.ldw = g.width; q.M = T; q.N = 3 * g.width; q.K = g.width;
     q.out = e->qkv; q.ldo = 3 * g.width; q.bias = L.b_qkv; q.colsum = L.cs_qkv;
     q.stats_in = stats_in; q.stats_in_parts = stats_parts; q.stats_ld = Tp; q.inv_width = 1.0f / g.width; q.eps = g.ln_eps; q.act = -1;
+      q.ticket = ticket();
     pf.begin(PK_GEMM_QKV, 2.0 * dT * 3.0 * dD * dD, st);
     HIP_TRY(ce_gemm_nt(q, CE_DT_BF16, EPI_LNFOLD, st));
     pf.end(st);
@@ -511,6 +525,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     GemmParams o{};
     o.A = e->attn; o.lda = g.width; o.W = L.w_out; o.ldw = g.width; o.M = T; o.N = g.width; o.K = g.width;
     o.out = e->x; o.ldo = g.width; o.bias = L.b_out; o.resid = e->x; o.stats_out = e->stats_a; o.stats_ld = Tp;
+      o.ticket = ticket();
     pf.begin(PK_GEMM_RESID, 2.0 * dT * dD * dD, st, PK_SUB_OUT);
     HIP_TRY(ce_gemm_nt(o, CE_DT_BF16, EPI_RESID, st));
     pf.end(st);
@@ -519,6 +534,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     f.A = e->x; f.lda = g.width; f.W = L.w_fc; f.ldw = g.width; f.M = T; f.N = g.mlp_dim; f.K = g.width;
     f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
     f.stats_in = e->stats_a; f.stats_in_parts = parts; f.stats_ld = Tp; f.inv_width = 1.0f / g.width; f.eps = g.ln_eps; f.act = g.act;
+      f.ticket = ticket();
     pf.begin(PK_GEMM_FC1, 2.0 * dT * dD * g.mlp_dim, st);
     HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
     pf.end(st);
@@ -526,6 +542,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     GemmParams r{};
     r.A = e->hid; r.lda = g.mlp_dim; r.W = L.w_proj; r.ldw = g.mlp_dim; r.M = T; r.N = g.width; r.K = g.mlp_dim;
     r.out = e->x; r.ldo = g.width; r.bias = L.b_proj; r.resid = e->x; r.stats_out = e->stats_b; r.stats_ld = Tp;
+      r.ticket = ticket();
     pf.begin(PK_GEMM_RESID, 2.0 * dT * dD * g.mlp_dim, st, PK_SUB_FC2);
     HIP_TRY(ce_gemm_nt(r, CE_DT_BF16, EPI_RESID, st));
     pf.end(st);
@@ -575,6 +592,7 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
 #ifdef CLIPENC_DIAG                         // diagnostic library only: run the last block on every token (tests/test_gpu_cls_only.py)
   e->cls_only_last = getenv("CLIPENC_FULL_LAST_BLOCK") == nullptr;
   e->fp8_unfused = getenv("CLIPENC_FP8_UNFUSED") != nullptr;
+  e->dynamic_tail = getenv("CLIPENC_STATIC_TILES") == nullptr;
 #endif
   const int kreal = 3 * g.patch * g.patch;
   e->kpad = (int)align_up(kreal, 128);

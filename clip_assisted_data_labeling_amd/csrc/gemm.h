@@ -27,6 +27,9 @@ struct GemmParams {
   float* vals;                   // [cap]
   unsigned long long cap;
   unsigned long long* count;
+  unsigned* ticket;              // optional (bf16 persistent kernel, EPI_STORE_BF16 / LNFOLD / RESID): a zeroed device word.  The tiles of the launch's last
+                                 // one-to-two rounds are then handed out from it in the order the workgroups get there instead of by stride, so that
+                                 // a workgroup that runs ahead takes more of them (gemm_persist.hip); the results do not depend on who runs a tile
   const unsigned* tile_list;     // [tt (tt + 1) / 2] tm | tn << 16: execution order of the upper-triangular tiles (set by ce_gemm_tri_persist)
   const unsigned long long* run_if_over;   // EPI_THRESH, optional: the launch does nothing unless *run_if_over > run_if_limit (read on the
   unsigned long long run_if_limit;         // device when the launch starts: the exact search as the fall-back of the screened one, dedup.hip)

@@ -138,6 +138,23 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   const bool deep_narrow = tiles_n <= 4 && p.K >= 2048;
 #define DECODE_TILE(i_) (EPI == EPI_THRESH ? tri_tile(p.tile_list, (i_)) : decode_tile((i_), tiles_m, tiles_n, deep_narrow))
   const int G = gridDim.x;
+  // Dynamic tail (p.ticket): workgroup b walks b, b + G, ... by stride through all rounds but the last full one; the tiles from
+  // S on -- between one and two rounds -- are taken from a global ticket counter in the order the workgroups arrive.  The
+  // workgroups of a launch drift apart (tools/gemm_stamps.py: finish times spread over more than a tile time; mean idle at the end
+  // of a launch 2-3.4 %, of which the static partial round is 0.4-2.7 %), and with tickets the ones that run ahead take the extra
+  // tiles.  The ticket is a SCALAR atomic (s_atomic_add, counted in lgkmcnt): a vector atomic would join the in-order vmcnt
+  // queue that the DMA pipeline's hand-counted waits are written against.  One wave takes it at the top of a tile, a tile
+  // before it is needed, and parks it in a free word of its epilogue image; which workgroup runs a tile changes no result bit.
+#ifndef GEMM_DYN_ROUNDS
+#define GEMM_DYN_ROUNDS 1                    // full rounds handed out by ticket in front of the partial one (0: every tile by stride)
+#endif
+  const int S = (GEMM_DYN_ROUNDS > 0 && EPI != EPI_THRESH && p.ticket != nullptr && nwg / G >= GEMM_DYN_ROUNDS + 2)
+                    ? (nwg / G - GEMM_DYN_ROUNDS) * G : 0x7fffffff;
+  // where the ticket waits in LDS: EPI_LNFOLD -- word 0 of part 1 of the CURRENT raw-statistics buffer (dead once this tile's
+  // (mean, rstd) are converted, which the ticket-taking wave has done itself by then; the next tile's statistics land in the other
+  // buffer); otherwise the unused fourth quarter of AUX.  (The waves' epilogue images are NOT free during the main loop: the
+  // column-sum / bias pieces are whole 1-KiB DMA writes.)
+#define TICKET_SLOT (EPI == EPI_LNFOLD ? AUX_OFF + (tile_iter & 1) * 8192 + 2048 : AUX_OFF + 12288)
   const size_t lda_b = (size_t)p.lda * 2, ldw_b = (size_t)p.ldw * 2;
   const int kend = p.K * 2;                  // bytes along K; one stage = 128 B; K % 128 == 0 (stages come in pairs)
 
@@ -351,6 +368,12 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
         const float var = fmaxf(ss_ * p.inv_width - mean * mean, 0.f);
         *(float2*)(raw + row * 8) = float2{mean, rsqrtf(var + p.eps)};
       }
+      if (EPI != EPI_THRESH && w == 4 && idx + G >= S) {
+        // the tile after this one comes from the ticket counter: take the ticket now (~1 us; this wave row waits here anyway)
+        unsigned tk = 1;
+        asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(tk) : "s"(p.ticket) : "memory");
+        if (lane == 0) *(volatile unsigned*)(smem + TICKET_SLOT) = tk;
+      }
       BARRIER();                             // second wave row runs half a phase behind
     }
 
@@ -369,8 +392,10 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
         for (int j = 0; j < 4; ++j) acc[i][j] = CINIT(j);
     }
     // ---- last two stages: the DMA crosses into the next tile ----
-    const int nidx = idx + G;
-    const bool has_next = nidx < nwg;
+    int nidx = idx + G;
+    if (EPI != EPI_THRESH && nidx >= S)      // (wave-uniform) written at the top of this tile, many barriers ago; read before the epilogue reuses the image
+      nidx = S + (int)__builtin_amdgcn_readfirstlane(*(volatile const unsigned*)(smem + TICKET_SLOT));
+    const bool has_next = (unsigned)nidx < (unsigned)nwg;
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
     if (has_next) {

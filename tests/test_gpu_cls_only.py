@@ -54,3 +54,39 @@ def test_cls_only_last_block_equals_full_last_block_bitwise(gpu, tmp_path):
                              capture_output=True, text=True).stdout
     for name in ("CLIPENC_FULL_LAST_BLOCK", "CLIPENC_ATTN_IMPL", "CLIPENC_ATTN_DBG"):
         assert name not in strings, f"developer switch {name} is compiled into the product library"
+
+
+_CHILD_TAIL = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+from clip_assisted_data_labeling_amd import vit_config
+from clip_assisted_data_labeling_amd.embedder import HipViT
+dev = torch.device("cuda", 0)
+cfg = vit_config.ARCHS["ViT-L-14"]
+vit = HipViT(cfg, vit_config.seeded_state_dict(cfg, 0), dev)
+g = torch.Generator(device=dev).manual_seed(5)
+# 700 crops = 179 900 token rows = 703 row tiles: 2 812 / 8 436 / 11 248 tiles = 10.98 / 32.95 / 43.9 rounds of 256 workgroups
+crops = torch.randint(0, 256, (700, 3, 224, 224), device=dev, generator=g, dtype=torch.int32).to(torch.uint8)
+out = {"a": vit.encode(crops).cpu(), "b": vit.encode(crops).cpu(), "tokens": vit.forward_tokens(crops[:300]).float().cpu()}
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_tiles_handed_out_by_ticket_give_the_bits_of_the_strided_walk(gpu, tmp_path):
+    """The persistent GEMMs hand the tiles of a launch's last one-to-two rounds out from a ticket counter, in the order the
+    workgroups get there (gemm_persist.hip): WHICH workgroup runs a tile must not change a bit.  The diagnostic library reads
+    CLIPENC_STATIC_TILES=1 at clipenc_create and then walks every tile by stride, as rounds 1-3 did."""
+    def run(path, env_extra):
+        env = {k: v for k, v in os.environ.items() if k not in ("CLIPENC_STATIC_TILES", "CLIPENC_LIB_PATH")}
+        env.update(env_extra)
+        subprocess.run([sys.executable, "-c", _CHILD_TAIL, path, ROOT], env=env, check=True, timeout=600)
+        return torch.load(path)
+    product = run(str(tmp_path / "p.pt"), {})
+    ticket = run(str(tmp_path / "t.pt"), {"CLIPENC_LIB_PATH": DIAG_LIB})
+    strided = run(str(tmp_path / "s.pt"), {"CLIPENC_LIB_PATH": DIAG_LIB, "CLIPENC_STATIC_TILES": "1"})
+    assert torch.isfinite(product["a"]).all() and torch.equal(product["a"], product["b"])          # run to run, whatever the hand-out order was
+    for k in ("a", "b", "tokens"):
+        assert torch.equal(product[k], ticket[k]) and torch.equal(ticket[k], strided[k]), k
+    strings = subprocess.run(["strings", os.path.join(ROOT, "clip_assisted_data_labeling_amd", "libclipenc_hip.so")],
+                             capture_output=True, text=True).stdout
+    assert "CLIPENC_STATIC_TILES" not in strings
