@@ -294,6 +294,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     const int Dw = g.width, Mh = g.mlp_dim, sparts = g.width / 64;
     uint8_t* h8 = (uint8_t*)e->hid;
     auto run8 = [&](GemmParams& q, int epi, int kind, int sub) -> hipError_t {
+      q.ticket = ticket();
       pf.begin(kind, 2.0 * (double)q.M * (double)q.N * (double)q.K, st, sub);
       hipError_t err = ce_gemm_fp8(q, epi, st);
       pf.end(st);

@@ -140,6 +140,15 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   const int nwg = EPI == 4 ? tiles_n * (tiles_n + 1) / 2 : tiles_m * tiles_n;
 #define DECODE_TILE(i_) (EPI == 4 ? tri_tile(p.tile_list, (i_)) : decode_tile((i_), tiles_m, tiles_n))
   const int G = gridDim.x;
+  // Dynamic tail (p.ticket; gemm_persist.hip has the argument and the measurements): the tiles from S on -- the launch's last
+  // one-to-two rounds -- are taken from a global ticket counter (a scalar atomic: lgkmcnt, not the DMA pipeline's vmcnt) in the
+  // order the workgroups get there.  The ticket waits in word 512 of wave 4's image: [2048, 2560) of an image is written by no
+  // DMA piece of any instantiation, and the epilogue, which owns the whole image, starts after the ticket has been read.
+#ifndef F8_DYN_ROUNDS
+#define F8_DYN_ROUNDS 1
+#endif
+  const int S = (F8_DYN_ROUNDS > 0 && EPI != 4 && p.ticket != nullptr && nwg / G >= F8_DYN_ROUNDS + 2) ? (nwg / G - F8_DYN_ROUNDS) * G : 0x7fffffff;
+  constexpr int TICKET_SLOT = TR_OFF + 4 * 4096 + 2048;
   const size_t lda_b = (size_t)p.lda, ldw_b = (size_t)p.ldw;      // fp8: 1 byte per element
   const int kend = p.K;                      // bytes along K; one stage = 128 B; K % 256 == 0 (stages come in pairs)
 
@@ -342,7 +351,14 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
 #ifdef CLIPENC_DIAG
     if (p.dbg && tid == 0) { p.dbg[(size_t)idx * 8 + 1] = __builtin_amdgcn_s_memrealtime(); p.dbg[(size_t)idx * 8 + 4] = __builtin_amdgcn_s_memtime(); }
 #endif
-    if (wr == 1) BARRIER();                  // second wave row runs half a phase behind
+    if (wr == 1) {
+      if (EPI != 4 && w == 4 && idx + G >= S) {             // the tile after this one comes from the ticket counter
+        unsigned tk = 1;
+        asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(tk) : "s"(p.ticket) : "memory");
+        if (lane == 0) *(volatile __attribute__((address_space(3))) unsigned*)LDS_PTR(TICKET_SLOT) = tk;
+      }
+      BARRIER();                             // second wave row runs half a phase behind
+    }
 
     constexpr bool ZERO_C = ZERO_C_OK;
     if (ZERO_C && kend > 256) {
@@ -366,8 +382,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       }
     }
     // ---- last two stages: the DMA crosses into the next tile (or re-fetches this one into dead buffers) ----
-    const int nidx = idx + G;
-    const bool has_next = nidx < nwg;
+    int nidx = idx + G;
+    if (EPI != 4 && nidx >= S)               // (wave-uniform) the ticket taken at the top of this tile
+      nidx = S + (int)__builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) const unsigned*)LDS_PTR(TICKET_SLOT));
+    const bool has_next = (unsigned)nidx < (unsigned)nwg;
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
     if (has_next) {

@@ -68,6 +68,9 @@ g = torch.Generator(device=dev).manual_seed(5)
 # 700 crops = 179 900 token rows = 703 row tiles: 2 812 / 8 436 / 11 248 tiles = 10.98 / 32.95 / 43.9 rounds of 256 workgroups
 crops = torch.randint(0, 256, (700, 3, 224, 224), device=dev, generator=g, dtype=torch.int32).to(torch.uint8)
 out = {"a": vit.encode(crops).cpu(), "b": vit.encode(crops).cpu(), "tokens": vit.forward_tokens(crops[:300]).float().cpu()}
+vit.set_precision("fp8")
+out["fp8"] = vit.encode(crops).cpu()
+out["fp8_b"] = vit.encode(crops).cpu()
 torch.save(out, sys.argv[1])
 """
 
@@ -85,7 +88,8 @@ def test_tiles_handed_out_by_ticket_give_the_bits_of_the_strided_walk(gpu, tmp_p
     ticket = run(str(tmp_path / "t.pt"), {"CLIPENC_LIB_PATH": DIAG_LIB})
     strided = run(str(tmp_path / "s.pt"), {"CLIPENC_LIB_PATH": DIAG_LIB, "CLIPENC_STATIC_TILES": "1"})
     assert torch.isfinite(product["a"]).all() and torch.equal(product["a"], product["b"])          # run to run, whatever the hand-out order was
-    for k in ("a", "b", "tokens"):
+    assert torch.equal(product["fp8"], product["fp8_b"]) and not torch.equal(product["fp8"], product["a"])
+    for k in ("a", "b", "tokens", "fp8", "fp8_b"):
         assert torch.equal(product[k], ticket[k]) and torch.equal(ticket[k], strided[k]), k
     strings = subprocess.run(["strings", os.path.join(ROOT, "clip_assisted_data_labeling_amd", "libclipenc_hip.so")],
                              capture_output=True, text=True).stdout
