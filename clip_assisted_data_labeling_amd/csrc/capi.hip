@@ -145,6 +145,7 @@ struct Profiler {
   }
 };
 
+constexpr int CE_TICKET_WORDS = 2048;                   // 256 launches x 8 words per pass (a 24-block tower issues 146)
 struct clipenc_s {
   Profiler prof;
   clipenc_config cfg;
@@ -176,7 +177,7 @@ struct clipenc_s {
   DevBuf ws;
   bf16_t *a_patch = nullptr, *pe = nullptr, *x = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr;
   float *stats0 = nullptr, *stats_a = nullptr, *stats_b = nullptr, *stats_c = nullptr;   // stats_c: [parts][chunk] of the CLS rows
-  unsigned* tickets = nullptr;                           // [1024] zeroed per pass: one ticket counter per persistent GEMM launch (gemm.h)
+  unsigned* tickets = nullptr;                           // [CE_TICKET_WORDS] zeroed per pass: eight ticket words per persistent GEMM launch (gemm.h)
   bool dynamic_tail = true;                              // (the diagnostic build reads CLIPENC_STATIC_TILES=1 to switch the tickets off)
 };
 
@@ -230,7 +231,7 @@ int ensure_workspace(clipenc_s* e) {
   const size_t Tp = align_up(T, 256);
   const size_t o_s0 = take(Tp * 8), o_sa = take(parts * Tp * 8), o_sb = take(parts * Tp * 8);
   const size_t o_sc = take(parts * align_up((size_t)c, 256) * 8);
-  const size_t o_tk = take(1024 * sizeof(unsigned));
+  const size_t o_tk = take(CE_TICKET_WORDS * sizeof(unsigned));
   const bool f8 = e->precision == CLIPENC_PREC_FP8;
   const size_t o_a8 = f8 ? take(T * (size_t)g.width) : 0, o_sa8 = f8 ? take(T * 4) : 0;
   const bool f8f = f8 && fp8_fused(g);
@@ -267,8 +268,8 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
   const double dT = (double)T, dD = (double)g.width;
   // ticket counters of this pass's persistent GEMM launches (at most 6 per block + the patch GEMM): zeroed by one fill
   int tk = 0;
-  if (e->dynamic_tail) HIP_TRY(hipMemsetAsync(e->tickets, 0, 1024 * sizeof(unsigned), st));
-  auto ticket = [&]() -> unsigned* { return (e->dynamic_tail && tk < 1024) ? e->tickets + tk++ : nullptr; };
+  if (e->dynamic_tail) HIP_TRY(hipMemsetAsync(e->tickets, 0, CE_TICKET_WORDS * sizeof(unsigned), st));
+  auto ticket = [&]() -> unsigned* { return (e->dynamic_tail && (tk + 1) * 8 <= CE_TICKET_WORDS) ? e->tickets + 8 * tk++ : nullptr; };
   pf.begin(PK_PATCHIFY, 0.0, st);
   HIP_TRY(ce_patchify(crops, in_dtype, e->a_patch, c, g.image_size, g.patch, e->kpad, e->pix_mean, e->pix_std, st));
   pf.end(st);

@@ -145,11 +145,18 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
   // tiles.  The ticket is a SCALAR atomic (s_atomic_add, counted in lgkmcnt): a vector atomic would join the in-order vmcnt
   // queue that the DMA pipeline's hand-counted waits are written against.  One wave takes it at the top of a tile, a tile
   // before it is needed, and parks it in a free word of its epilogue image; which workgroup runs a tile changes no result bit.
+  // Two forms (measured, tools/experiments/README.md): outputs of 4 tiles along N (out-proj, FC2) -- ONE counter, one full round
+  // by ticket; wider outputs (QKV, FC1: 12 / 16 tiles along N, whose XCD-aware order is worth 0.5 % on two ticketed rounds) -- one
+  // counter PER XCD (p.ticket[0..7]), two full rounds: the workgroups of XCD x take the positions of ITS strided sequence (tile
+  // index mod 8 = x) in the order they get there, so the tiles resident on an XCD stay neighbours; an XCD that has run out takes
+  // from the next one's counter (at most seven more atomics, at the very end of a launch).
 #ifndef GEMM_DYN_ROUNDS
-#define GEMM_DYN_ROUNDS 1                    // full rounds handed out by ticket in front of the partial one (0: every tile by stride)
+#define GEMM_DYN_ROUNDS 1                    // 0: every tile by stride (rounds 1-3)
 #endif
-  const int S = (GEMM_DYN_ROUNDS > 0 && EPI != EPI_THRESH && p.ticket != nullptr && nwg / G >= GEMM_DYN_ROUNDS + 2)
-                    ? (nwg / G - GEMM_DYN_ROUNDS) * G : 0x7fffffff;
+  const bool by_xcd = tiles_n > 4 && (G & 7) == 0;
+  const int dyn_rounds = GEMM_DYN_ROUNDS == 0 ? 0 : (by_xcd ? 2 : 1);
+  const int S = (dyn_rounds > 0 && EPI != EPI_THRESH && p.ticket != nullptr && nwg / G >= dyn_rounds + 2)
+                    ? (nwg / G - dyn_rounds) * G : 0x7fffffff;
   // where the ticket waits in LDS: EPI_LNFOLD -- word 0 of part 1 of the CURRENT raw-statistics buffer (dead once this tile's
   // (mean, rstd) are converted, which the ticket-taking wave has done itself by then; the next tile's statistics land in the other
   // buffer); otherwise the unused fourth quarter of AUX.  (The waves' epilogue images are NOT free during the main loop: the
@@ -369,10 +376,22 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
         *(float2*)(raw + row * 8) = float2{mean, rsqrtf(var + p.eps)};
       }
       if (EPI != EPI_THRESH && w == 4 && idx + G >= S) {
-        // the tile after this one comes from the ticket counter: take the ticket now (~1 us; this wave row waits here anyway)
-        unsigned tk = 1;
-        asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(tk) : "s"(p.ticket) : "memory");
-        if (lane == 0) *(volatile unsigned*)(smem + TICKET_SLOT) = tk;
+        // the tile after this one comes from the ticket counters: take the ticket now (~1 us; this wave row waits here anyway)
+        int cand = -1;
+        if (by_xcd) {
+          for (int j = 0; j < 8 && cand < 0; ++j) {
+            const int x = (blockIdx.x + j) & 7;
+            unsigned tk = 1;
+            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(tk) : "s"(p.ticket + x) : "memory");
+            const int id = S + (int)tk * 8 + x;
+            if ((unsigned)id < (unsigned)nwg) cand = id;
+          }
+        } else {
+          unsigned tk = 1;
+          asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(tk) : "s"(p.ticket) : "memory");
+          cand = S + (int)tk;
+        }
+        if (lane == 0) *(volatile int*)(smem + TICKET_SLOT) = cand;
       }
       BARRIER();                             // second wave row runs half a phase behind
     }
@@ -394,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
     // ---- last two stages: the DMA crosses into the next tile ----
     int nidx = idx + G;
     if (EPI != EPI_THRESH && nidx >= S)      // (wave-uniform) written at the top of this tile, many barriers ago; read before the epilogue reuses the image
-      nidx = S + (int)__builtin_amdgcn_readfirstlane(*(volatile const unsigned*)(smem + TICKET_SLOT));
+      nidx = __builtin_amdgcn_readfirstlane(*(volatile const int*)(smem + TICKET_SLOT));      // (-1: nothing left)
     const bool has_next = (unsigned)nidx < (unsigned)nwg;
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
