@@ -147,7 +147,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
 #ifndef F8_DYN_ROUNDS
 #define F8_DYN_ROUNDS 1
 #endif
-  const int S = (F8_DYN_ROUNDS > 0 && EPI != 4 && p.ticket != nullptr && nwg / G >= F8_DYN_ROUNDS + 2) ? (nwg / G - F8_DYN_ROUNDS) * G : 0x7fffffff;
+  // (outputs wider than 4 tiles: one counter per XCD + stealing, two rounds; else one counter, one round -- gemm_persist.hip)
+  const bool by_xcd = tiles_n > 4 && (G & 7) == 0;
+  const int dyn_rounds = F8_DYN_ROUNDS == 0 ? 0 : (by_xcd ? 2 : 1);
+  const int S = (dyn_rounds > 0 && EPI != 4 && p.ticket != nullptr && nwg / G >= dyn_rounds + 2) ? (nwg / G - dyn_rounds) * G : 0x7fffffff;
   constexpr int TICKET_SLOT = TR_OFF + 4 * 4096 + 2048;
   const size_t lda_b = (size_t)p.lda, ldw_b = (size_t)p.ldw;      // fp8: 1 byte per element
   const int kend = p.K;                      // bytes along K; one stage = 128 B; K % 256 == 0 (stages come in pairs)
@@ -353,9 +356,21 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
 #endif
     if (wr == 1) {
       if (EPI != 4 && w == 4 && idx + G >= S) {             // the tile after this one comes from the ticket counter
-        unsigned tk = 1;
-        asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(tk) : "s"(p.ticket) : "memory");
-        if (lane == 0) *(volatile __attribute__((address_space(3))) unsigned*)LDS_PTR(TICKET_SLOT) = tk;
+        int cand = -1;
+        if (by_xcd) {
+          for (int j = 0; j < 8 && cand < 0; ++j) {
+            const int x = (blockIdx.x + j) & 7;
+            unsigned tk = 1;
+            asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(tk) : "s"(p.ticket + x) : "memory");
+            const int id = S + (int)tk * 8 + x;
+            if ((unsigned)id < (unsigned)nwg) cand = id;
+          }
+        } else {
+          unsigned tk = 1;
+          asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(tk) : "s"(p.ticket) : "memory");
+          cand = S + (int)tk;
+        }
+        if (lane == 0) *(volatile __attribute__((address_space(3))) int*)LDS_PTR(TICKET_SLOT) = cand;
       }
       BARRIER();                             // second wave row runs half a phase behind
     }
@@ -384,7 +399,7 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
     // ---- last two stages: the DMA crosses into the next tile (or re-fetches this one into dead buffers) ----
     int nidx = idx + G;
     if (EPI != 4 && nidx >= S)               // (wave-uniform) the ticket taken at the top of this tile
-      nidx = S + (int)__builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) const unsigned*)LDS_PTR(TICKET_SLOT));
+      nidx = __builtin_amdgcn_readfirstlane(*(volatile __attribute__((address_space(3))) const int*)LDS_PTR(TICKET_SLOT));   // (-1: nothing left)
     const bool has_next = (unsigned)nidx < (unsigned)nwg;
     TileId nxt = cur;
     const char *Anext = Ablk, *Wnext = Wblk;
