@@ -35,6 +35,10 @@ def main():
             print(f"   {w:4d} {nb:7.1f}               " + " ".join(f"{v:6.0f}" for v in per) + f" {sum(per):6.0f}   | {tot[:, w].mean().item():9.0f}")
         per = (sect.sum((0, 1)) / nblk.sum()).tolist()
         print("    all                       " + " ".join(f"{v:6.0f}" for v in per) + f" {sum(per):6.0f}")
+        # how far apart do the workgroups finish?  (static task ranges: what a ticketed hand-out of the tasks could win)
+        wg = tot.max(1).values
+        print(f"    workgroup spans (cycles): min {wg.min().item():.0f}  p50 {wg.median().item():.0f}  max {wg.max().item():.0f};  "
+              f"mean idle behind the slowest workgroup {100 * (1 - wg.mean().item() / wg.max().item()):.2f} %")
 
 
 if __name__ == "__main__":
