@@ -138,6 +138,11 @@ class Feature_Dataset:
         self.gpu_decode_read_ahead_bytes = 2 << 30          # file bytes the reader pool may hold ahead of the decoder
         self.pt_writers = 1                                 # threads writing the per-image .pt files of a batch (pickling holds the GIL:
                                                             # 2 and 4 measured slower than 1 next to the stager thread, tools/ab_embed_e2e.py)
+        # where the stager's decode + crop kernels go: "priority" = a high-priority stream (they start at the next boundary
+        # between two of the encoder's kernels), "side" = an ordinary second stream, "same" = the encoder's own stream
+        self.gpu_decode_stream = "priority"
+        self.gpu_decode_queue = 6                           # encode batches the stager may be ahead of the encoder
+        self.first_chunk_div = 4                            # the first decode chunk is batch_size / this many files
         # Progressive files: the device takes them, but walks each with ONE lane (scans are serial), 0.25 - 0.5 s for a chunk
         # during which its small workgroups sit on every CU and the encoder's persistent kernels cannot be placed -- with host
         # cores to spare Pillow in the reader threads is the better deal; set True on a box without them.
@@ -281,7 +286,7 @@ class Feature_Dataset:
         import queue
         import threading
         from concurrent.futures import ThreadPoolExecutor as _Pool
-        pt_pool = _Pool(max(1, int(getattr(self, "pt_writers", 1))))
+        pt_pool = _Pool(max(1, int(self.pt_writers)))
         out_q: "queue.Queue" = queue.Queue(maxsize=4)
         writer_errors: List[BaseException] = []
 
@@ -326,15 +331,15 @@ class Feature_Dataset:
                     print(f"Error loading or processing image {path}: {e}")
                     return None, 0
 
-            # The stager enqueues its decode and crop kernels into the ENCODER's stream (HIP streams take launches from several host
-            # threads): they then run between two of the encoder's kernels with the whole GPU to themselves.  On a stream of their
-            # own they only found CUs in the encoder's tail rounds -- its persistent kernels hold every CU -- and a 10-ms entropy
-            # workgroup that got one kept the next persistent kernel waiting for that CU (rocprofv3: 0.37 s of GPU idle time and
-            # stretched kernels in a 2.66-s run).  gpu_decode_side_stream=True restores the separate stream.
-            mode = getattr(self, "gpu_decode_stream", "priority")
+            # The stager's decode and crop kernels go to a HIGH-PRIORITY stream: they are placed at the next boundary between two of the
+            # encoder's kernels and then have the GPU to themselves for their few milliseconds.  On an ordinary second stream they
+            # only found CUs in the encoder's tail rounds -- its persistent kernels hold every CU -- and a 10-ms entropy workgroup
+            # that got one kept the next persistent kernel waiting for that CU; in the encoder's own stream the decode's final
+            # synchronisation waits for the whole batch queued before it, so the stager is never more than one batch ahead.
+            mode = self.gpu_decode_stream
             side = (torch.cuda.current_stream(self.device) if mode == "same" else
                     torch.cuda.Stream(device=self.device, priority=-1 if mode == "priority" else 0))
-            in_q: "queue.Queue" = queue.Queue(maxsize=int(getattr(self, "gpu_decode_queue", 6)))
+            in_q: "queue.Queue" = queue.Queue(maxsize=int(self.gpu_decode_queue))
             stop = threading.Event()
 
             def put(item):
@@ -351,7 +356,7 @@ class Feature_Dataset:
                     with ThreadPoolExecutor(max(2, min(16, self.num_workers or 8))) as readers:
                         ahead = collections.deque()             # (path, future, file bytes) in file order
                         # the first chunk is a QUARTER of an encode batch (the encoder starts after a few milliseconds of decoding)
-                        nxt, ahead_bytes, limit, reserved = 0, 0, max(min(32, self.batch_size), self.batch_size // int(getattr(self, "first_chunk_div", 4))), False
+                        nxt, ahead_bytes, limit, reserved = 0, 0, max(min(32, self.batch_size), self.batch_size // max(1, int(self.first_chunk_div))), False
                         while (nxt < len(todo) or ahead) and not stop.is_set():
                             # chunks double up to `decode_chunk` files: the entropy decoder's parallelism is the files in flight
                             while nxt < len(todo) and len(ahead) < max(limit, self.batch_size) * 2 and ahead_bytes < self.gpu_decode_read_ahead_bytes:
