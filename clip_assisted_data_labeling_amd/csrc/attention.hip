@@ -201,6 +201,30 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
   const size_t ld = (size_t)3 * width;
   const bf16_t* base = qkv + (size_t)crop * n_tok * ld + head * 64;
 
+#ifndef ATTN_LONG_DMA
+#define ATTN_LONG_DMA 1
+#endif
+#if ATTN_LONG_DMA
+  // K and V of the head by LDS-DMA (no VGPR round trip): one instruction = 8 rows x 128 B, lane L fetches source chunk
+  // (L & 7) ^ swizzle(row) of row 8 j + (L >> 3), so the piece lands swizzled; rows beyond n_tok are clamped copies of the last
+  // token (their scores are masked to -inf below, so their weights are exactly 0).  Through registers -- a dependent load -> store
+  // per 16 bytes and thread -- this staging was ~4 us of a 42-us task.
+  {
+    const char* tb = (const char*)base;
+    const unsigned ldb = (unsigned)(ld * 2);
+    for (int j = wave; j < rows / 8; j += 8) {
+      const int row = 8 * j + (lane >> 3);
+      const unsigned rb = (unsigned)min(row, n_tok - 1) * ldb;
+      const int ck = (lane & 7) ^ ((row >> 1) & 7);
+      const int cv = (lane & 7) ^ (((row >> 1) & 1) << 2);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + (size_t)width * 2 + (rb + ck * 16)),
+                                       (__attribute__((address_space(3))) void*)(Ks + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + (size_t)width * 4 + (rb + cv * 16)),
+                                       (__attribute__((address_space(3))) void*)(Vs + j * 1024), 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+#else
   for (int idx = tid; idx < rows * 8; idx += 512) {
     const int row = idx >> 3, c = idx & 7;
     uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
@@ -212,6 +236,7 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
     *(uint4*)(Ks + k_swz(row, c)) = kv;
     *(uint4*)(Vs + v_swz(row, c)) = vv;
   }
+#endif
   __syncthreads();
 
   const int r = lane & 31, h = lane >> 5;
