@@ -177,6 +177,8 @@ struct clipenc_s {
   DevBuf ws;
   bf16_t *a_patch = nullptr, *pe = nullptr, *x = nullptr, *qkv = nullptr, *attn = nullptr, *hid = nullptr;
   float *stats0 = nullptr, *stats_a = nullptr, *stats_b = nullptr, *stats_c = nullptr;   // stats_c: [parts][chunk] of the CLS rows
+  bf16_t* w_k_t = nullptr;                               // last layer: (gamma-folded W_k)^T [D (k)][D (n)], the operand of the r_h GEMM (cls_attention.hip)
+  bool cls_shortcut = true;                              // last block's attention without K and V (the diagnostic build reads CLIPENC_CLS_KV=1 to switch it off)
   unsigned* tickets = nullptr;                           // [CE_TICKET_WORDS] zeroed per pass: eight ticket words per persistent GEMM launch (gemm.h)
   bool dynamic_tail = true;                              // (the diagnostic build reads CLIPENC_STATIC_TILES=1 to switch the tickets off)
 };
@@ -270,6 +272,37 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
   int tk = 0;
   if (e->dynamic_tail) HIP_TRY(hipMemsetAsync(e->tickets, 0, CE_TICKET_WORDS * sizeof(unsigned), st));
   auto ticket = [&]() -> unsigned* { return (e->dynamic_tail && (tk + 1) * 8 <= CE_TICKET_WORDS) ? e->tickets + 8 * tk++ : nullptr; };
+  // The LAST block's attention for the class-token query without K and V (cls_attention.hip): r_h = (Q_cls masked to head h) . W'_k
+  // and o_h = z_h . W'_v^T as two small launches of the persistent GEMM (16 x redundant -- every head's row against every column --
+  // and still ~65 us each), the scores / softmax / weighted row sums in between as one pass-twice-over-x kernel.  Scratch: four
+  // [c H][D] bf16 buffers + [c H] floats in `hid`, which is idle until the block's FC1.  `out`: the class-token rows of attn (bf16,
+  // row stride tokens * D) or of a8 (e4m3 with out_inv).  Returns false when the scratch does not fit (tiny test towers).
+  const LayerDev& LL = e->layers[g.layers - 1];
+  auto cls_attention = [&](const float* stats, int stats_parts_, int stats_ld_, void* out, const float* out_inv, bool* done) -> hipError_t {
+    const int Dw = g.width, H = g.heads;
+    const size_t n = ce_cls_attn_scratch_elems(c, Dw, H);
+    *done = false;
+    if (!e->cls_shortcut || (size_t)T * g.mlp_dim * 2 < 4 * n * 2 + (size_t)c * H * 4 + 1024) return hipSuccess;
+    bf16_t *Qm = e->hid, *R = e->hid + n, *Zp = e->hid + 2 * n, *Of = e->hid + 3 * n;
+    float* mzv = (float*)(e->hid + 4 * n);
+    const size_t q_stride = (size_t)e->tokens * 3 * Dw;
+    pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * dD, st);
+    hipError_t err = ce_cls_qmask(e->qkv, q_stride, Qm, c, Dw, H, st);
+    GemmParams a{};
+    a.A = Qm; a.lda = Dw; a.W = e->w_k_t; a.ldw = Dw; a.M = c * H; a.N = Dw; a.K = Dw; a.out = R; a.ldo = Dw; a.ticket = ticket();
+    if (err == hipSuccess) err = ce_gemm_nt(a, CE_DT_BF16, EPI_STORE_BF16, st);
+    if (err == hipSuccess)
+      err = ce_cls_attn(e->x, stats, stats_parts_, stats_ld_, e->qkv, q_stride, LL.cs_qkv + Dw, LL.b_qkv + Dw, R, Zp, mzv, c, e->tokens, Dw, H,
+                        g.ln_eps, st);
+    GemmParams b{};
+    b.A = Zp; b.lda = Dw; b.W = LL.w_qkv + (size_t)2 * Dw * Dw; b.ldw = Dw; b.M = c * H; b.N = Dw; b.K = Dw; b.out = Of; b.ldo = Dw; b.ticket = ticket();
+    if (err == hipSuccess) err = ce_gemm_nt(b, CE_DT_BF16, EPI_STORE_BF16, st);
+    if (err == hipSuccess)
+      err = ce_cls_finish(Of, mzv, LL.cs_qkv + 2 * Dw, LL.b_qkv + 2 * Dw, out, (size_t)e->tokens * Dw, out_inv, c, Dw, H, st);
+    pf.end(st);
+    *done = err == hipSuccess;
+    return err;
+  };
   pf.begin(PK_PATCHIFY, 0.0, st);
   HIP_TRY(ce_patchify(crops, in_dtype, e->a_patch, c, g.image_size, g.patch, e->kpad, e->pix_mean, e->pix_std, st));
   pf.end(st);
@@ -344,13 +377,18 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
         // attention, out-proj and the MLP on the c CLS rows, which stay where they are (row stride = tokens rows) in x, x8 and xe8
         const int stride = e->tokens;
         const int Tpc = (int)align_up((size_t)c, 256);
-        HIP_TRY(lnf(T, 1, Q.w_qkv + (size_t)Dw * Dw, Q.s_qkv + Dw, Q.cs_qkv + Dw, L.b_qkv + Dw, 2 * Dw, -1, e->qkv + Dw, 3 * Dw,
-                    EPI_STORE_BF16, nullptr, 1, PK_GEMM8_QKV));
         HIP_TRY(lnf(c, stride, Q.w_qkv, Q.s_qkv, Q.cs_qkv, L.b_qkv, Dw, -1, e->qkv, stride * 3 * Dw, EPI_STORE_BF16, nullptr, stride,
                     PK_GEMM8_QKV));
-        pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * dD, st);
-        HIP_TRY(ce_attention(e->qkv, e->a8, c, e->tokens, g.width, g.heads, Q.is_attn, 1, st));   // O of rows 0..31 of every crop, e4m3
-        pf.end(st);
+        // the class-token attention without K and V, on the bf16 residual rows and bf16 weights (cls_attention.hip), O as e4m3
+        bool short_done = false;
+        HIP_TRY(cls_attention(st_in, parts_in, Tp, e->a8, Q.is_attn, &short_done));
+        if (!short_done) {
+          HIP_TRY(lnf(T, 1, Q.w_qkv + (size_t)Dw * Dw, Q.s_qkv + Dw, Q.cs_qkv + Dw, L.b_qkv + Dw, 2 * Dw, -1, e->qkv + Dw, 3 * Dw,
+                      EPI_STORE_BF16, nullptr, 1, PK_GEMM8_QKV));
+          pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * dD, st);
+          HIP_TRY(ce_attention(e->qkv, e->a8, c, e->tokens, g.width, g.heads, Q.is_attn, 1, st));   // O of rows 0..31 of every crop, e4m3
+          pf.end(st);
+        }
         HIP_TRY(resid(e->a8, c, stride * Dw, Q.w_out, Q.s_out, L.b_out, Dw, stride, true, Tpc, PK_SUB8_OUT));
         HIP_TRY(consts(e->st8, sparts, Tpc, c));               // compact: constants of CLS row i at [i]
         HIP_TRY(lnf(c, stride, Q.w_fc, Q.s_fc, Q.cs_fc, L.b_fc, Mh, g.act, h8, Mh, EPI_STORE_FP8, Q.is_hid, 1, PK_GEMM8_FC1));
@@ -456,15 +494,6 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       // (row stride = tokens rows).  Same arithmetic per row as the full block -- the rows it leaves out are dead.
       const int Dw = g.width, stride = e->tokens;
       const int Tpc = (int)align_up((size_t)c, 256);
-      // K | V = LN1(x) . W[D:3D]^T + b, every token  -> columns D..3D of qkv
-      GemmParams kv{};
-      kv.A = e->x; kv.lda = Dw; kv.W = L.w_qkv + (size_t)Dw * Dw; kv.ldw = Dw; kv.M = T; kv.N = 2 * Dw; kv.K = Dw;
-      kv.out = e->qkv + Dw; kv.ldo = 3 * Dw; kv.bias = L.b_qkv + Dw; kv.colsum = L.cs_qkv + Dw;
-      kv.stats_in = stats_in; kv.stats_in_parts = stats_parts; kv.stats_ld = Tp; kv.inv_width = 1.0f / Dw; kv.eps = g.ln_eps; kv.act = -1;
-      kv.ticket = ticket();
-      pf.begin(PK_GEMM_QKV, 2.0 * dT * 2.0 * dD * dD, st);
-      HIP_TRY(ce_gemm_nt(kv, CE_DT_BF16, EPI_LNFOLD, st));
-      pf.end(st);
       // statistics of the CLS rows, compact (row i = crop i)
       float* stats_c = e->stats_c;
       pf.begin(PK_EMBED_LN_PRE, 0.0, st);
@@ -479,10 +508,24 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       pf.begin(PK_GEMM_QKV, 2.0 * c * dD * dD, st);
       HIP_TRY(ce_gemm_nt(qc, CE_DT_BF16, EPI_LNFOLD, st));
       pf.end(st);
-      // attention of the first 32-query block of every (crop, head); only its row 0 is a real query here
-      pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * dD, st);
-      HIP_TRY(ce_attention(e->qkv, e->attn, c, e->tokens, Dw, g.heads, nullptr, 1, st));
-      pf.end(st);
+      // the class-token attention: without K and V (cls_attention.hip) -- or, when its scratch does not fit, the standard way
+      bool short_done = false;
+      HIP_TRY(cls_attention(stats_in, stats_parts, Tp, e->attn, nullptr, &short_done));
+      if (!short_done) {
+        // K | V = LN1(x) . W[D:3D]^T + b, every token  -> columns D..3D of qkv
+        GemmParams kv{};
+        kv.A = e->x; kv.lda = Dw; kv.W = L.w_qkv + (size_t)Dw * Dw; kv.ldw = Dw; kv.M = T; kv.N = 2 * Dw; kv.K = Dw;
+        kv.out = e->qkv + Dw; kv.ldo = 3 * Dw; kv.bias = L.b_qkv + Dw; kv.colsum = L.cs_qkv + Dw;
+        kv.stats_in = stats_in; kv.stats_in_parts = stats_parts; kv.stats_ld = Tp; kv.inv_width = 1.0f / Dw; kv.eps = g.ln_eps; kv.act = -1;
+        kv.ticket = ticket();
+        pf.begin(PK_GEMM_QKV, 2.0 * dT * 2.0 * dD * dD, st);
+        HIP_TRY(ce_gemm_nt(kv, CE_DT_BF16, EPI_LNFOLD, st));
+        pf.end(st);
+        // attention of the first 32-query block of every (crop, head); only its row 0 is a real query here
+        pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * dD, st);
+        HIP_TRY(ce_attention(e->qkv, e->attn, c, e->tokens, Dw, g.heads, nullptr, 1, st));
+        pf.end(st);
+      }
       // x[cls] += attn[cls] . Wo^T + bo
       GemmParams o{};
       o.A = e->attn; o.lda = stride * Dw; o.W = L.w_out; o.ldw = Dw; o.M = c; o.N = Dw; o.K = Dw;
@@ -595,6 +638,7 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
   e->cls_only_last = getenv("CLIPENC_FULL_LAST_BLOCK") == nullptr;
   e->fp8_unfused = getenv("CLIPENC_FP8_UNFUSED") != nullptr;
   e->dynamic_tail = getenv("CLIPENC_STATIC_TILES") == nullptr;
+  e->cls_shortcut = getenv("CLIPENC_CLS_KV") == nullptr;
 #endif
   const int kreal = 3 * g.patch * g.patch;
   e->kpad = (int)align_up(kreal, 128);
@@ -615,6 +659,7 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
     lo[l].cs_qkv = take(3 * D * 4); lo[l].b_qkv = take(3 * D * 4); lo[l].b_out = take(D * 4);
     lo[l].cs_fc = take(M * 4); lo[l].b_fc = take(M * 4); lo[l].b_proj = take(D * 4);
   }
+  const size_t o_wkt = take((size_t)D * D * 2);
   std::vector<char> host(off);
   char* hb = host.data();
   {
@@ -659,6 +704,12 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
     plain(w->c_proj_w[l], D, M, (bf16_t*)(hb + lo[l].w_proj));
     memcpy(hb + lo[l].b_proj, w->c_proj_b[l], D * 4);
   }
+  {
+    // (gamma-folded W_k of the LAST layer)^T: Wt[k][n] = W'_k[n][k]  (cls_attention.hip: r_h = sum_{n in head} q_n W'_k[n, :])
+    const bf16_t* wk = (const bf16_t*)(hb + lo[L - 1].w_qkv) + (size_t)D * D;
+    bf16_t* wt = (bf16_t*)(hb + o_wkt);
+    parallel_for(D, [=](int k) { for (int n = 0; n < D; ++n) wt[(size_t)k * D + n] = wk[(size_t)n * D + k]; });
+  }
   hipError_t err = e->weights.alloc(off);
   if (err == hipSuccess) err = hipMemcpy(e->weights.p, hb, off, hipMemcpyHostToDevice);
   if (err != hipSuccess) { e->weights.release(); delete e; return fail("weight upload failed: %s", hipGetErrorString(err)); }
@@ -666,6 +717,7 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
   e->w_conv = (bf16_t*)(db + o_conv); e->cls = (float*)(db + o_cls); e->pos = (float*)(db + o_pos);
   e->ln_pre_w = (float*)(db + o_lpw); e->ln_pre_b = (float*)(db + o_lpb);
   e->ln_post_w = (float*)(db + o_low); e->ln_post_b = (float*)(db + o_lob); e->proj = (float*)(db + o_proj);
+  e->w_k_t = (bf16_t*)(db + o_wkt);
   e->layers.resize(L);
   for (int l = 0; l < L; ++l) {
     LayerDev& d = e->layers[l];

@@ -8,6 +8,15 @@
 hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int width, int heads, const float* out_inv,
                         int q_blocks, hipStream_t stream);   // out_inv != NULL: out is e4m3 [T][width] = fp8(O * out_inv[c])
 
+// cls_attention.hip: the last block's attention for the class-token query, without K and V
+size_t ce_cls_attn_scratch_elems(int n_crops, int D, int H);
+hipError_t ce_cls_qmask(const void* q, size_t q_stride, void* Qm, int n_crops, int D, int H, hipStream_t stream);
+hipError_t ce_cls_attn(const void* x, const float* stats, int parts, int stats_ld, const void* q, size_t q_stride, const float* colsum_k,
+                       const float* bias_k, const void* R, void* Zp, float* mz, int n_crops, int n_tok, int D, int H, float eps,
+                       hipStream_t stream);
+hipError_t ce_cls_finish(const void* Of, const float* mz, const float* colsum_v, const float* bias_v, void* out, size_t out_stride,
+                         const float* out_inv, int n_crops, int D, int H, hipStream_t stream);
+
 // elementwise.hip
 hipError_t ce_patchify(const void* crops, int in_dtype, void* a_patch, int n_crops, int image, int patch, int kpad,
                        const float* mean3, const float* std3, hipStream_t stream);
