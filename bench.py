@@ -389,12 +389,13 @@ def pmc_traffic(kernel_name):
 def algorithmic_bytes_per_step(cfg, crops):
     """ALGORITHMIC bytes one step moves per kernel kind (every operand read once, every result written once; bf16 activations and
     weights, fp32 row statistics left out): what `roofline.per_kernel[*].traffic_ratio` divides the measured L2-miss bytes by.
-    The tower's last block runs K | V for every token and the rest on the class-token rows only."""
+    The tower's last block runs on the class-token rows only, its attention without K and V."""
     T, D, M, L = crops * cfg.tokens, cfg.width, cfg.mlp_dim, cfg.layers
     full = L - 1
     return {
-        "qkv": full * (T * D * 2 + 3 * D * D * 2 + T * 3 * D * 2) + (T * D * 2 + 2 * D * D * 2 + T * 2 * D * 2) + (2 * crops * D * 2 + D * D * 2),
-        "attention": full * (T * 3 * D * 2 + T * D * 2) + (T * 2 * D * 2 + 2 * crops * 32 * D * 2),
+        "qkv": full * (T * D * 2 + 3 * D * D * 2 + T * 3 * D * 2) + (2 * crops * D * 2 + D * D * 2),
+        # (last block: the class-token attention reads the crop's residual rows twice, no K / V: cls_attention.hip)
+        "attention": full * (T * 3 * D * 2 + T * D * 2) + 2 * T * D * 2,
         "out_proj": full * (3 * T * D * 2 + D * D * 2) + (3 * crops * D * 2 + D * D * 2),
         "fc1": full * (T * D * 2 + M * D * 2 + T * M * 2) + (crops * D * 2 + M * D * 2 + crops * M * 2),
         "fc2": full * (T * M * 2 + D * M * 2 + 2 * T * D * 2) + (crops * M * 2 + D * M * 2 + 2 * crops * D * 2),

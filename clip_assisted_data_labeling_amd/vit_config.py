@@ -52,11 +52,13 @@ class ViTConfig:
     def macs_per_crop_executed(self) -> int:
         """MACs the bf16 encode path actually performs per crop: the LAST block runs its Q projection, attention,
         out-projection and MLP on the class-token row only (nothing downstream reads another token; capi.hip run_tower),
-        K and V are still projected for every token.  Reported next to `macs_per_crop` so that the throughput priced with
-        the reference's full-block count can be told from the arithmetic really issued."""
+        and its attention scores that one query against the raw residual rows instead of projecting K and V
+        (cls_attention.hip: Q d^2; r_h and o_h as two [heads x d] x [d x d] products per crop; scores and weighted row sums
+        2 x 16 n d).  Reported next to `macs_per_crop` so that the throughput priced with the reference's full-block count
+         can be told from the arithmetic really issued."""
         n, d, m = self.tokens, self.width, self.mlp_dim
         per_layer = n * d * 3 * d + 2 * n * n * d + n * d * d + 2 * n * d * m
-        last = n * d * 2 * d + d * d + 2 * n * d + d * d + 2 * d * m
+        last = d * d + 2 * self.heads * d * d + 32 * n * d + d * d + 2 * d * m
         return (n - 1) * self.patch_k * d + (self.layers - 1) * per_layer + last + d * self.embed_dim
 
 
