@@ -359,7 +359,9 @@ class Feature_Dataset:
                         nxt, ahead_bytes, limit, reserved = 0, 0, max(min(32, self.batch_size), self.batch_size // max(1, int(self.first_chunk_div))), False
                         while (nxt < len(todo) or ahead) and not stop.is_set():
                             # chunks double up to `decode_chunk` files: the entropy decoder's parallelism is the files in flight
-                            while nxt < len(todo) and len(ahead) < max(limit, self.batch_size) * 2 and ahead_bytes < self.gpu_decode_read_ahead_bytes:
+                            # (read ahead by two chunks of the CURRENT size: submitting 1 024 reads before the first 128-file chunk was looked
+                            #  at cost 50 ms of start-up)
+                            while nxt < len(todo) and len(ahead) < limit * 2 and ahead_bytes < self.gpu_decode_read_ahead_bytes:
                                 try:
                                     size = os.path.getsize(todo[nxt])
                                 except OSError:
