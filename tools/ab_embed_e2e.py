@@ -15,12 +15,22 @@ ap.add_argument("--size", type=int, default=512)
 ap.add_argument("--batch", type=int, default=512)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--packed", action="store_true")
+ap.add_argument("--content", default="noise", choices=["noise", "photo"],
+                help="noise: uniform noise, ~230 KB per 512x512 file, the entropy decoder's worst case; photo: low-pass structure + "
+                     "sensor-like noise, the size a camera JPEG of that many pixels has")
 a = ap.parse_args()
 tmp = tempfile.mkdtemp(prefix="ab_e2e_")
 try:
-    base = np.random.RandomState(0).randint(0, 256, (a.size, a.size, 3), dtype=np.uint8)
+    rs = np.random.RandomState(0)
+    if a.content == "noise":
+        base = rs.randint(0, 256, (a.size, a.size, 3), dtype=np.uint8)
+    else:
+        coarse = Image.fromarray(rs.randint(0, 256, (a.size // 32, a.size // 32, 3), dtype=np.uint8)).resize((a.size, a.size), Image.BICUBIC)
+        mid = Image.fromarray(rs.randint(96, 160, (a.size // 4, a.size // 4, 3), dtype=np.uint8)).resize((a.size, a.size), Image.BICUBIC)
+        base = np.clip(np.asarray(coarse, np.float32) + (np.asarray(mid, np.float32) - 128) + rs.normal(0, 3, (a.size, a.size, 3)), 0, 255).astype(np.uint8)
     with ThreadPoolExecutor(8) as ex:
         list(ex.map(lambda i: Image.fromarray(np.roll(base, i * 7, axis=1)).save(os.path.join(tmp, f"{i:06d}.jpg"), quality=90), range(a.n)))
+    print(f"{a.n} files of {a.size}x{a.size} ({a.content}), {sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp)) / a.n / 1024:.0f} KB each", flush=True)
     import torch
     from clip_assisted_data_labeling_amd import embed_driver
     from clip_assisted_data_labeling_amd.embedder import CLIP_Encoder
