@@ -11,8 +11,9 @@ from clip_assisted_data_labeling_amd.preprocess import CROP_NAMES, ClipValTransf
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("w,h", [(640, 427), (300, 500), (224, 224), (1000, 60), (97, 333), (2000, 1500), (225, 224)])
+@pytest.mark.parametrize("w,h", [(640, 427), (300, 500), (224, 224), (1000, 60), (97, 333), (2000, 1500), (225, 224), (5000, 300), (1100, 1400)])
 def test_gpu_crops_are_bit_exact_with_pillow(gpu, w, h):
+    """Sizes: down- and up-scaling, windows of 5 to 83 taps, a canvas wider than any staging buffer one might add (5000)."""
     rs = np.random.RandomState(w + h)
     arr = rs.randint(0, 256, (h, w, 3), dtype=np.uint8)
     # smooth content as well as noise: half of the image is a gradient
