@@ -396,7 +396,135 @@ __device__ __forceinline__ unsigned lds_load_u32(const char* p) {
   return __atomic_load_n((const unsigned*)p, __ATOMIC_RELAXED);
 }
 
-template <int NKT, int NCW>
+// The last block of a task of 32 b + 1 tokens holds ONE query; as a block it costs 1 / (b + 1) of the kernel, because the exponentials
+// of a block are lane-parallel over QUERIES.  Here the scores are taken the other way round, S = Q . K^T -- the Q fragment the caller
+// prefetched has that query in all 32 rows (rows past the last token are clamped to it) -- so a lane holds one KEY per tile and the
+// softmax is NKT exponentials per lane.  The weights go through 576 B of the task's K rows that no query uses (rows ROWS - 8 ..: padding
+// keys, masked in every block) back into the B-operand layout of the P.V MFMAs, which -- like the row sum -- are those of the block
+// path, key for key: the row has the bits the block path gives it.  kv_off: byte offset of the task's K | V buffer in LDS.
+// Run by the LOADER wave between two tasks' DMA bursts (inside the compute waves' block loop it cost more than it saved: its registers
+// made the allocator spill in the block path, and every reload of a spill is a wait on vmcnt behind the Q prefetch).
+template <int NKT>
+__device__ __forceinline__ void attn_tail_query(bf16x8_t q0, bf16x8_t q1, bf16x8_t q2, bf16x8_t q3, int kv_off, int n_tok,
+                                                          float scale_log2e, bf16_t* out, const float* out_inv, size_t qrow, int width,
+                                                          int head, int stop_after) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = NKT * 32, MAT = ROWS * 128;
+  int lane;                                                     // from the hardware, HERE: nothing derived from it is kept across the block path
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  const int r = lane & 31, h = lane >> 5;
+  const char* Ks = smem + kv_off;
+  const char* Vs = Ks + MAT;
+  char* ps = smem + kv_off + (ROWS - 8) * 128;
+  const bf16x8_t qf[4] = {q0, q1, q2, q3};
+  float sc[NKT];
+  float mx = -INFINITY;
+  // K fragments of tile c + 1 are read before the MFMAs of tile c are issued, and a tile's result is taken one tile later (two
+  // accumulators in turn): the four MFMAs of a tile are a dependent chain, two tiles' chains overlap
+  bf16x8_t kfa[4], kfb[4];
+  f32x16_t acc[2];
+#pragma unroll
+  for (int st = 0; st < 4; ++st) kfa[st] = *(const bf16x8_t*)(Ks + k_swz(r, st * 2 + h));
+#pragma unroll
+  for (int c = 0; c < NKT; ++c) {
+    if (c + 1 < NKT) {
+#pragma unroll
+      for (int st = 0; st < 4; ++st) kfb[st] = *(const bf16x8_t*)(Ks + k_swz((c + 1) * 32 + r, st * 2 + h));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[c & 1][e] = 0.f;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) acc[c & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf[st], kfa[st], acc[c & 1], 0, 0, 0);
+    if (c >= 1) {                                               // every row of a tile is the query: [0] = <Q, K[32 (c - 1) + r]>
+      sc[c - 1] = acc[(c - 1) & 1][0];
+      mx = fmaxf(mx, sc[c - 1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) kfa[st] = kfb[st];
+  }
+  sc[NKT - 1] = ((NKT - 1) * 32 + r < n_tok) ? acc[(NKT - 1) & 1][0] : -INFINITY;     // only the last tile has padded keys
+  mx = fmaxf(mx, sc[NKT - 1]);
+  if (stop_after == 4) { if (mx == 12345.f) out[0] = 0; return; }                       // (timing experiments: 4 = scores only, 5 = + weights)
+#pragma unroll
+  for (int d = 16; d >= 1; d >>= 1) mx = fmaxf(mx, __shfl_xor(mx, d));
+  const float moff = mx * scale_log2e;
+  if (h == 0) {
+#pragma unroll
+    for (int c = 0; c < NKT; ++c) {
+      const float pw = __builtin_amdgcn_exp2f(fmaf(sc[c], scale_log2e, -moff));
+      *(unsigned short*)(ps + (c * 32 + r) * 2) = (unsigned short)cvt_pk_bf16(pw, 0.f);
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (stop_after == 5) return;
+  // P.V and the row sum over 16-key steps; slot i of lane half h holds key 16 j + (i & 3) + 8 (i >> 2) + 4 h, as in the block path.
+  // The fragments of step j + 1 are read before the three MFMAs of step j are issued.
+  const int vi = lane & 15, vq = vi >> 2, vp = vi & 3, vg1 = (lane >> 4) & 1;
+  const char* vbase0 = Vs + v_swz(4 * h + vq, (vg1 * 16 + vp * 4) >> 3) + ((vg1 * 16 + vp * 4) & 7) * 2;
+  const char* vbase1 = Vs + v_swz(4 * h + vq, (32 + vg1 * 16 + vp * 4) >> 3) + ((vg1 * 16 + vp * 4) & 7) * 2;
+  auto v_frag = [&](int j, const char* vb) -> bf16x8_t {
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + j * 2048));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + j * 2048 + 1024));
+    s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, vv);
+  };
+  auto p_frag = [&](int j) -> bf16x8_t {
+    const uint2 plo = *(const uint2*)(ps + (16 * j + 4 * h) * 2), phi = *(const uint2*)(ps + (16 * j + 8 + 4 * h) * 2);
+    const u32x4_t pw = {plo.x, plo.y, phi.x, phi.y};
+    return __builtin_bit_cast(bf16x8_t, pw);
+  };
+  const u32x4_t ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};        // eight bf16 1.0
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_w);
+  constexpr int J = 2 * NKT - 1;                                // steps that always hold a real key; step J only if n_tok > 16 J
+  f32x16_t o[2], lacc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; lacc[e] = 0.f; }
+  bf16x8_t pf = p_frag(0), va = v_frag(0, vbase0), vb = v_frag(0, vbase1);
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    bf16x8_t pn = pf, van = va, vbn = vb;
+    if (j + 1 < J) { pn = p_frag(j + 1); van = v_frag(j + 1, vbase0); vbn = v_frag(j + 1, vbase1); }
+    __builtin_amdgcn_sched_barrier(0);
+    lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pf, o[0], 0, 0, 0);
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb, pf, o[1], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    pf = pn; va = van; vb = vbn;
+  }
+  if (n_tok > J * 16) {                                         // wave-uniform: the last 16-key step holds real keys
+    const bf16x8_t pl = p_frag(J), vl0 = v_frag(J, vbase0), vl1 = v_frag(J, vbase1);
+    lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pl, lacc, 0, 0, 0);
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl0, pl, o[0], 0, 0, 0);
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl1, pl, o[1], 0, 0, 0);
+  }
+  const float inv = 1.0f / lacc[0];
+  if (r == 0) {                                                 // lanes 0 and 32 hold the row: dims 32 dt + 8 g4 + 4 h + {0..3}
+    if (out_inv) {
+      uint8_t* ob = (uint8_t*)out + qrow * width + head * 64 + h * 4;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const f32x4_t is = *(const f32x4_t*)(out_inv + head * 64 + dt * 32 + g4 * 8 + h * 4);
+          *(int*)(ob + dt * 32 + g4 * 8) = pack_fp8x4(o[dt][g4 * 4 + 0] * inv * is[0], o[dt][g4 * 4 + 1] * inv * is[1],
+                                                      o[dt][g4 * 4 + 2] * inv * is[2], o[dt][g4 * 4 + 3] * inv * is[3]);
+        }
+    } else {
+      bf16_t* ob = out + qrow * width + head * 64 + h * 4;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+          *(uint2*)(ob + dt * 32 + g4 * 8) = uint2{cvt_pk_bf16(o[dt][g4 * 4 + 0] * inv, o[dt][g4 * 4 + 1] * inv),
+                                                   cvt_pk_bf16(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv)};
+    }
+  }
+}
+
+template <int NKT, int NCW, bool TAIL>
 __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_kernel(
     const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n_tok, int width, int heads, float scale_log2e,
     int n_tasks, int dbg_mode, const float* __restrict__ out_inv, int q_blocks) {
@@ -412,7 +540,9 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
   const int G = gridDim.x, wg = blockIdx.x;
   const int t0 = (int)(((long long)n_tasks * wg) / G), t1 = (int)(((long long)n_tasks * (wg + 1)) / G);
   const int ntask = t1 - t0;                                    // host guarantees 1 <= ntask <= 496
-  const int n_qb = min((n_tok + 31) >> 5, q_blocks);            // q_blocks: only the first 32-query blocks of every task
+  // q_blocks: only the first 32-query blocks of every task.  TAIL (n_tok = 32 b + 1, all blocks asked for): the compute waves take the
+  // b full blocks, the loader wave computes the one query left over (attn_tail_query) while the task's blocks are being computed
+  const int n_qb = TAIL ? NKT - 1 : min((n_tok + 31) >> 5, q_blocks);
   const int total_blocks = ntask * n_qb;
   const size_t ld = (size_t)3 * width;
   const unsigned ldb = (unsigned)(ld * 2);
@@ -425,6 +555,49 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
     // ------------------------------------ loader wave ------------------------------------
     if (dbg_mode == 2) {
       if (lane == 0) __atomic_store_n((unsigned*)ctrl, (unsigned)ntask, __ATOMIC_RELAXED);
+      return;
+    }
+    if constexpr (TAIL) {
+      const int h = lane >> 5;
+      // This wave goes ahead of the compute wave it shares a SIMD with (which sleeps between its polls costs that wave nothing): the
+      // sooner it is back at the counter below, the sooner the next task's K / V are requested.  At equal priority the one-query path
+      // took four times as long and this wave, not the compute waves, paced the kernel.
+      __builtin_amdgcn_s_setprio(3);
+      for (int k = 0; k < ntask; ++k) {
+        if (k >= 2 && dbg_mode != 1) {                           // buffer k&1 is free once every block of task k-2 has been computed
+          unsigned spins = 0;
+          while (lds_load_u32(ctrl + 16 + (k - 2) * 4) != (unsigned)n_qb && ++spins < SPIN_LIMIT) __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("" ::: "memory");
+        const int t = t0 + k;
+        const int crop = t / heads, head = t - crop * heads;
+        const char* tb = (const char*)(qkv + (size_t)crop * n_tok * ld + head * 64);
+        // the task's last query, the same row in every lane row (what the A operand of S = Q . K^T wants); it lands with the K / V rows
+        const size_t qrow = (size_t)crop * n_tok + (n_tok - 1);
+        bf16x8_t qf[4];
+        {
+          const bf16_t* qp = qkv + qrow * ld + head * 64 + h * 8;
+#pragma unroll
+          for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qp + st * 16);
+        }
+        const int dst = (k & 1) * BUF;
+#pragma unroll 4
+        for (int j = 0; j < ROWS / 8; ++j) {
+          const int row = 8 * j + (lane >> 3);
+          const unsigned rb = (unsigned)min(row, n_tok - 1) * ldb;
+          const int ck = (lane & 7) ^ ((row >> 1) & 7);
+          const int cv = (lane & 7) ^ (((row >> 1) & 1) << 2);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + (size_t)width * 2 + (rb + ck * 16)),
+                                           (__attribute__((address_space(3))) void*)(smem + dst + j * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + (size_t)width * 4 + (rb + cv * 16)),
+                                           (__attribute__((address_space(3))) void*)(smem + dst + MAT + j * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // task k has landed (and the row stored in the previous round has left)
+        if (lane == 0) __atomic_store_n((unsigned*)ctrl, (unsigned)(k + 1), __ATOMIC_RELAXED);
+        if (dbg_mode != 3)                                       // (3: timing experiment without this path, results invalid)
+          attn_tail_query<NKT>(qf[0], qf[1], qf[2], qf[3], dst, n_tok, scale_log2e, out, out_inv, qrow, width, head, dbg_mode);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // its K / V reads have returned before the buffer is refilled (two rounds on)
+      }
       return;
     }
     for (int k = 0; k < ntask; ++k) {
@@ -466,7 +639,6 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
   if (dbg_mode == 1) return;
   const int r = lane & 31, h = lane >> 5;
   char* tr = smem + 2 * BUF + wave * TRB;
-  const int tr_base = (lane >> 3) * 128 + (((lane & 7) ^ (lane >> 3)) << 4);
 
   // Q fragments of a block: lane (r,h) holds Q[q0+r][16*step + 8h .. +7]; loaded one block ahead
   auto q_ptr = [&](int gg) {
@@ -509,11 +681,13 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
     }
     STAMP(1);
 
+    const u32x4_t ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // eight bf16 1.0
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_w);
+
+
     f32x16_t o[2], lacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; lacc[e] = 0.f; }
-    const u32x4_t ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // eight bf16 1.0
-    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_w);
 
     // ---- S^T tiles: s[c][reg] = <K[32 c + krow(reg,h)], Q[q]>.  K fragments of tile c + 1 are read before the MFMAs of tile c are
     // issued (register double buffer; hipcc otherwise reads each fragment right in front of its MFMA and waits), and the row max of
@@ -651,30 +825,32 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
     STAMP(4);
 
     const float inv = 1.0f / lacc[0];                           // the MFMA already summed both lane halves
+    const int ol = lane, orr = r, oh = h;
+    const int otr_base = (ol >> 3) * 128 + (((ol & 7) ^ (ol >> 3)) << 4);
 
     if (out_inv) {
       // ---- O as e4m3: fragment layout -> [TR_ROWS q rows][80-B pitch] image -> whole 64-B rows ----
-      uint8_t* obase8 = (uint8_t*)out + (size_t)crop * n_tok * width + head * 64 + (lane & 3) * 16;
+      uint8_t* obase8 = (uint8_t*)out + (size_t)crop * n_tok * width + head * 64 + (ol & 3) * 16;
       int opk8[8];
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          const f32x4_t is = *(const f32x4_t*)(out_inv + head * 64 + dt * 32 + g4 * 8 + h * 4);
+          const f32x4_t is = *(const f32x4_t*)(out_inv + head * 64 + dt * 32 + g4 * 8 + oh * 4);
           opk8[dt * 4 + g4] = pack_fp8x4(o[dt][g4 * 4 + 0] * inv * is[0], o[dt][g4 * 4 + 1] * inv * is[1],
                                          o[dt][g4 * 4 + 2] * inv * is[2], o[dt][g4 * 4 + 3] * inv * is[3]);
         }
 #pragma unroll
       for (int pass = 0; pass < 32 / TR_ROWS; ++pass) {
-        if (r / TR_ROWS == pass) {
-          const int rr = r % TR_ROWS;
+        if (orr / TR_ROWS == pass) {
+          const int rr = orr % TR_ROWS;
 #pragma unroll
-          for (int c8 = 0; c8 < 8; ++c8) *(int*)(tr + rr * 80 + c8 * 8 + h * 4) = opk8[c8];
+          for (int c8 = 0; c8 < 8; ++c8) *(int*)(tr + rr * 80 + c8 * 8 + oh * 4) = opk8[c8];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const int row = lane >> 2;
+        const int row = ol >> 2;
         if (row < TR_ROWS) {
-          const uint4 v0 = *(const uint4*)(tr + row * 80 + (lane & 3) * 16);
+          const uint4 v0 = *(const uint4*)(tr + row * 80 + (ol & 3) * 16);
           const int qa = qb * 32 + pass * TR_ROWS + row;
           if (qa < n_tok) *(uint4*)(obase8 + (size_t)qa * width) = v0;
         }
@@ -683,7 +859,7 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
       continue;
     }
     // ---- O: fragment layout -> [TR_ROWS q rows][64 d] bf16 image -> whole 128-B rows ----
-    bf16_t* obase = out + (size_t)crop * n_tok * width + head * 64 + (lane & 7) * 8;
+    bf16_t* obase = out + (size_t)crop * n_tok * width + head * 64 + (ol & 7) * 8;
     uint2 opk[8];
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -693,17 +869,17 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
                                  cvt_pk_bf16(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv)};
 #pragma unroll
     for (int pass = 0; pass < 32 / TR_ROWS; ++pass) {
-      if (r / TR_ROWS == pass) {
-        const int rr = r % TR_ROWS;
+      if (orr / TR_ROWS == pass) {
+        const int rr = orr % TR_ROWS;
 #pragma unroll
-        for (int c8 = 0; c8 < 8; ++c8) *(uint2*)(tr + rr * 128 + ((c8 ^ (rr & 7)) << 4) + h * 8) = opk[c8];
+        for (int c8 = 0; c8 < 8; ++c8) *(uint2*)(tr + rr * 128 + ((c8 ^ (rr & 7)) << 4) + oh * 8) = opk[c8];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      const uint4 v0 = *(const uint4*)(tr + tr_base);
-      const int qa = qb * 32 + pass * TR_ROWS + (lane >> 3);
+      const uint4 v0 = *(const uint4*)(tr + otr_base);
+      const int qa = qb * 32 + pass * TR_ROWS + (ol >> 3);
       if (qa < n_tok) *(uint4*)(obase + (size_t)qa * width) = v0;
       if (TR_ROWS == 16) {
-        const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
+        const uint4 v1 = *(const uint4*)(tr + 1024 + otr_base);
         if (qa + 8 < n_tok) *(uint4*)(obase + (size_t)(qa + 8) * width) = v1;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -724,13 +900,13 @@ __global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_stream_ker
 #endif
 }
 
-template <int NKT, int NCW>
+template <int NKT, int NCW, bool TAIL>
 hipError_t launch_attn_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
                               const float* out_inv, int q_blocks, hipStream_t stream) {
   const int lds = 2 * 2 * NKT * 32 * 128 + NCW * (NCW <= 7 ? 2048 : 1024) + 2048;
   static DeviceKernelSetup setup;             // per device: LDS opt-in + CU count (common.h)
   int n_cu = 256;
-  if (hipError_t e = setup.ensure((const void*)attn_stream_kernel<NKT, NCW>, lds, &n_cu); e != hipSuccess) return e;
+  if (hipError_t e = setup.ensure((const void*)attn_stream_kernel<NKT, NCW, TAIL>, lds, &n_cu); e != hipSuccess) return e;
   const int n_tasks = n_crops * heads;
   int grid = n_tasks < n_cu ? n_tasks : n_cu;
   while ((n_tasks + grid - 1) / grid > 496) grid *= 2;      // per-workgroup task counters live in 2 KiB of LDS
@@ -740,7 +916,7 @@ hipError_t launch_attn_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n
 #else
   constexpr int dbg = 0;
 #endif
-  hipLaunchKernelGGL((attn_stream_kernel<NKT, NCW>), dim3(grid), dim3((NCW + 1) * 64), lds, stream, qkv, out, n_tok, width, heads,
+  hipLaunchKernelGGL((attn_stream_kernel<NKT, NCW, TAIL>), dim3(grid), dim3((NCW + 1) * 64), lds, stream, qkv, out, n_tok, width, heads,
                      scale_log2e, n_tasks, dbg, out_inv, q_blocks);
   return hipGetLastError();
 }
@@ -768,13 +944,21 @@ hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int 
   const int nkt = (n_tok + 31) / 32;
   const bf16_t* q = (const bf16_t*)qkv;
   bf16_t* o = (bf16_t*)out;
-#ifdef CLIPENC_DIAG                         // developer A/B: 0 = one workgroup per (crop, head) for every shape
+#ifdef CLIPENC_DIAG                         // developer A/B: 0 = one workgroup per (crop, head) for every shape; CLIPENC_ATTN_TAIL=0: the odd query as a block
   static const int impl = [] { const char* e = getenv("CLIPENC_ATTN_IMPL"); return e ? atoi(e) : 2; }();
+  static const bool tail_on_loader = [] { const char* e = getenv("CLIPENC_ATTN_TAIL"); return e ? atoi(e) != 0 : true; }();
+  static const int qb_cap = [] { const char* e = getenv("CLIPENC_ATTN_QB"); return e ? atoi(e) : 0; }();   // timing experiment (results invalid)
+  if (qb_cap > 0 && q_blocks > qb_cap) q_blocks = qb_cap;
 #else
   constexpr int impl = 2;
+  constexpr bool tail_on_loader = true;
 #endif
-  if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8, 7>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
-  if (impl == 2 && nkt == 9 && n_crops * heads >= 64) return launch_attn_stream<9, 7>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+  if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8, 7, false>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+  if (impl == 2 && nkt == 9 && n_crops * heads >= 64) {
+    // 32 b + 1 tokens (ViT-L/14: 257) with every block asked for: the odd query goes to the loader wave
+    if (tail_on_loader && (n_tok & 31) == 1 && q_blocks >= nkt) return launch_attn_stream<9, 7, true>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+    return launch_attn_stream<9, 7, false>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+  }
   switch (nkt) {                 // NKT must equal ceil(n_tok/32): only the last key tile is masked
     case 1: return launch_attn<1>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
     case 2: return launch_attn<2>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
