@@ -8,7 +8,7 @@ make -s -j8 -C "$C"
 for arg in "$@"; do
   sfx=${arg%%=*}; flags=${arg#*=}
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function $flags -c "$C/attention.hip" -o "$C/build/attention_$sfx.o"
-  OBJS=$(ls "$C"/build/*.o | grep -v "attention" | grep -v "__" | tr '\n' ' ')
+  OBJS=$(ls "$C"/build/*.o | grep -v "/attention\(_[^/]*\)\?\.o$" | grep -v "__" | tr '\n' ' ')
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$ROOT/clip_assisted_data_labeling_amd/libclipenc_hip_$sfx.so" $OBJS "$C/build/attention_$sfx.o"
   echo "built $sfx ($flags)"
 done
