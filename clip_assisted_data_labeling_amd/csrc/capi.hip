@@ -93,7 +93,7 @@ enum { PK_PATCHIFY = 0, PK_GEMM_PATCH, PK_EMBED_LN_PRE, PK_GEMM_QKV, PK_ATTENTIO
        PK_COUNT };
 static const char* const kProfileNames[PK_COUNT] = {
     "patchify_kernel<float, 14>", "gemm_persist_kernel<1, -1>", "embed_ln_pre_kernel<2>", "gemm_persist_kernel<2, -1>",
-    "attn_stream_kernel<9, 7>", "gemm_persist_kernel<3, -1>", "gemm_persist_kernel<2, 0>", "head_kernel", "fcreg_kernel",
+    "attn_stream_kernel<9, 7, true>", "gemm_persist_kernel<3, -1>", "gemm_persist_kernel<2, 0>", "head_kernel", "fcreg_kernel",
     "shape:out_proj(gemm_persist_kernel<3, -1>)", "shape:fc2(gemm_persist_kernel<3, -1>)",
     "quant_ln16_kernel<8>", "quant_rows_kernel<unsigned short, false, 2, 4>", "gemm_fp8_kernel<0, -1, false>",
     "gemm_fp8_kernel<2, 0, false>", "gemm_fp8_kernel<1, -1, false>", "shape:out_proj(gemm_fp8_kernel<1, -1, false>)",
@@ -924,7 +924,8 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
     if (kind == PK_ATTENTION) {                      // the instantiation ce_attention picks for this token count
       const int nkt = (e->tokens + 31) / 32;
       if (nkt > 9) *name = "attn_long_kernel<7>";
-      else if (nkt == 8) *name = "attn_stream_kernel<8, 7>";
+      else if (nkt == 9) *name = (e->tokens & 31) == 1 ? "attn_stream_kernel<9, 7, true>" : "attn_stream_kernel<9, 7, false>";
+      else if (nkt == 8) *name = "attn_stream_kernel<8, 7, false>";
       else if (nkt < 8) { static thread_local char buf[32]; snprintf(buf, sizeof buf, "attn_kernel<%d>", nkt); *name = buf; }
     }
   }
