@@ -516,7 +516,8 @@ def embed_e2e(dev, n=4096, size=512, workers=16, batch=512):
     """The real-data rate of the embed driver (/root/reference/_1_embed_with_CLIP.py:95-184 -> embed_driver.Feature_Dataset):
     `n` generated JPEG files -> decode -> GPU crop/resize front end -> ViT-L/14 encoder -> one .pt per image, start-up included.
     Two runs over the same files: JPEG decode in DataLoader workers on the host cores (a property of the box's CPU share too), and
-    JPEG decode on the GPU (embed_driver --gpu_decode: the main process only reads the bytes).  Returns (host result, gpu result)."""
+    JPEG decode on the GPU (embed_driver --gpu_decode: the main process only reads the bytes), the latter also with the e4m3 encoder
+    (--precision fp8).  Returns (host result, gpu result, gpu fp8 result)."""
     import shutil
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
@@ -535,9 +536,9 @@ def embed_e2e(dev, n=4096, size=512, workers=16, batch=512):
         import contextlib
         import io
         out = []
-        for gpu_decode in (False, True):
+        for gpu_decode, precision in ((False, "bf16"), (True, "bf16"), (True, "fp8")):
             with contextlib.redirect_stdout(io.StringIO()):
-                enc = CLIP_Encoder(f"{MODEL}/seed0", None, device=f"cuda:{dev.index}")
+                enc = CLIP_Encoder(f"{MODEL}/seed0", None, device=f"cuda:{dev.index}", precision=precision)
                 ds = embed_driver.Feature_Dataset(tmp, f"{MODEL}/seed0", batch, shuffle_filenames=False, num_workers=workers, encoder=enc,
                                                   device=f"cuda:{dev.index}", gpu_preprocess=True, force_reencode=True, gpu_decode=gpu_decode)
                 torch.cuda.synchronize()
@@ -552,7 +553,7 @@ def embed_e2e(dev, n=4096, size=512, workers=16, batch=512):
             how = ("JPEG decode on the GPU (bit-identical to Pillow), the main process reads the bytes" if gpu_decode
                    else f"host decode ({workers} DataLoader workers)")
             out.append({"workload": f"embed_driver on {n} generated {size}x{size} noise JPEG files (quality 90, 4:2:0, ~230 KB each: the entropy "
-                                    f"decoder's worst case): {how} -> GPU front end -> ViT-L/14 bf16 -> one .pt per image, start-up included",
+                                    f"decoder's worst case): {how} -> GPU front end -> ViT-L/14 {precision} -> one .pt per image, start-up included",
                         "value": round(n_emb / dt, 1), "unit": "images/s", "seconds": round(dt, 2), "images": int(n_emb), "pt_files_written": n_pt,
                         # the same run without its start-up: from the first batch in the store to the last one
                         "first_batch_stored_after_s": round(log[0][0] - t0, 3) if log else None,
@@ -909,7 +910,7 @@ def main():
                 torch.cuda.empty_cache()
             if "e2e" in want:
                 try:
-                    sec["embed_e2e"], sec["embed_e2e_gpu_decode"] = embed_e2e(dev)
+                    sec["embed_e2e"], sec["embed_e2e_gpu_decode"], sec["embed_e2e_gpu_decode_fp8"] = embed_e2e(dev)
                 except Exception as exc:                               # host-side (loader workers, /tmp): never lose the line to it
                     sec["embed_e2e"] = {"error": f"{type(exc).__name__}: {exc}"}
             line["secondary"] = sec

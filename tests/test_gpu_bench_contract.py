@@ -60,6 +60,8 @@ def test_single_gpu_line_has_the_contract_keys(gpu):
     assert sec["embed_e2e"].get("images") == 4096 and sec["embed_e2e"]["pt_files_written"] == 4096 and sec["embed_e2e"]["value"] > 0, sec["embed_e2e"]
     g = sec["embed_e2e_gpu_decode"]                                           # the same files, JPEG decode on the device
     assert g.get("images") == 4096 and g["pt_files_written"] == 4096 and g["value"] > 0 and g["workers"] == 0, g
+    g8 = sec["embed_e2e_gpu_decode_fp8"]                                      # ... and the e4m3 encoder behind it (embed_driver --precision fp8)
+    assert g8.get("images") == 4096 and g8["pt_files_written"] == 4096 and g8["value"] > g["value"] and "fp8" in g8["workload"], g8
 
 
 def test_two_ranks_report_the_whole_job(gpu):

@@ -117,6 +117,25 @@ def test_embed_predict_dedup_pipeline(gpu, tmp_path):
         new = torch.load(os.path.join(root, f), weights_only=True)
         assert all(torch.equal(new[MODEL][c], old[MODEL][c]) for c in CROP_NAMES), f
 
+    # --precision fp8: the e4m3 encoder behind the same loader (close to the bf16 store, not the same bits), then back to bf16
+    ds7 = embed_driver.Feature_Dataset(root, MODEL, 4, shuffle_filenames=False, num_workers=0, device="cuda", force_reencode=True,
+                                       gpu_decode=True, precision="fp8")
+    assert ds7.encoder.precision == "fp8" and ds7.process() == (9, 0, 0)
+    same = 0
+    for f, old in before.items():
+        if f in ("b_prog.pt", "b_png.pt"):
+            continue
+        new = torch.load(os.path.join(root, f), weights_only=True)
+        for c in CROP_NAMES:
+            cos = torch.nn.functional.cosine_similarity(new[MODEL][c].double(), old[MODEL][c].double(), dim=-1).min().item()
+            assert 1 - cos < 5e-3, (f, c, 1 - cos)
+            same += int(torch.equal(new[MODEL][c], old[MODEL][c]))
+    assert same == 0
+    with pytest.raises(ValueError):
+        embed_driver.Feature_Dataset(root, MODEL, 4, num_workers=0, device="cuda", precision="int4")
+    assert embed_driver.Feature_Dataset(root, MODEL, 4, shuffle_filenames=False, num_workers=0, device="cuda", force_reencode=True,
+                                        gpu_decode=True).process() == (9, 0, 0)
+
     # regressor checkpoint in the reference's pickle format, then the predict driver
     sizes = [2 * cfg.embed_dim, 32, 16, 8, 1]
     Ws, bs = np_fc_weights(sizes, 5)
