@@ -381,7 +381,7 @@ def test_fused_block_ops_chain_like_the_tower(gpu):
 
 
 # ------------------------------------------------------------------------------------------ attention with e4m3 output
-@pytest.mark.parametrize("n_crops,n_tok,heads", [(2, 50, 12), (3, 257, 16), (8, 257, 16), (20, 250, 4), (2, 577, 16)])
+@pytest.mark.parametrize("n_crops,n_tok,heads", [(2, 50, 12), (3, 257, 16), (8, 257, 16), (90, 257, 16), (20, 250, 4), (2, 577, 16)])
 def test_attention_e4m3_output_with_static_channel_scales(gpu, n_crops, n_tok, heads):
     lib = _lib.load()
     width = heads * 64

@@ -112,6 +112,8 @@ def test_gemm_rejects_bad_shapes(gpu):
 @pytest.mark.parametrize("n_crops,n_tok,heads", [(3, 5, 4), (2, 32, 4), (2, 50, 12), (2, 197, 4), (3, 257, 16), (1, 288, 4),
                                                   (2, 289, 4), (2, 577, 16), (1, 640, 4),
                                                   (8, 257, 16), (20, 250, 4), (70, 225, 1),        # >= 64 tasks: streaming kernel
+                                                  (90, 257, 16),                                   # ... 5-6 tasks per workgroup: both K / V buffers refilled, the
+                                                                                                   # loader's one-query path between two tasks' bursts
                                                   (16, 240, 4), (16, 241, 4), (4, 256, 16), (4, 272, 16), (4, 273, 16), (4, 288, 16),   # its last 16-key step: padding only / one real key / full
                                                   (8, 260, 8), (9, 230, 8), (64, 257, 1),        # a last block of 4 / 6 / 1 real queries
                                                   # 19 / 20 key tiles of the online-softmax kernel with 2 .. 32 real queries in the last block and a full / one-key last tile
