@@ -385,7 +385,9 @@ class Feature_Dataset:
                                 if dev_files:
                                     scale = self.decode_chunk / len(dev_files)
                                     px = min(self.gpu_decode_max_pixels, int(sum(w[1][1] for w in dev_files) * scale * 1.1))
-                                    self.jpeg.reserve(px, int(sum(len(w[1][0]) for w in dev_files) * scale * 1.1))
+                                    if not self.jpeg.reserve(px, int(sum(len(w[1][0]) for w in dev_files) * scale * 1.1)):
+                                        print(f"Warning: no device memory for the JPEG decoder's scratch ({px / 1e6:.0f} Mpx per chunk); "
+                                              "groups it cannot hold are decoded by Pillow on the host (slow)")
                             for _ in range(take):
                                 ahead_bytes -= ahead.popleft()[2]
                             limit = min(self.decode_chunk, limit * 2)
@@ -400,6 +402,10 @@ class Feature_Dataset:
                                     if isinstance(payload, torch.Tensor):   # decoded by Pillow in a reader thread
                                         img = payload
                                     elif img is None and payload is not None:   # the device flagged its entropy data: Pillow decides, as the reference
+                                        if st == self.jpeg.NO_MEMORY and not getattr(self, "_warned_no_memory", False):
+                                            self._warned_no_memory = True
+                                            print("Warning: the JPEG decoder had no device scratch for a group of files; "
+                                                  "they are decoded by Pillow on the host (slow) -- free device memory or lower --batch_size")
                                         try:
                                             img = torch.from_numpy(np.asarray(Image.open(io.BytesIO(payload)).convert("RGB"), dtype=np.uint8).copy())
                                         except Exception as e:
@@ -518,10 +524,13 @@ class Feature_Dataset:
         return n_embedded, n_skipped, n_failed
 
 
-def main(argv=None):
+def build_parser() -> argparse.ArgumentParser:
+    """The flags of /root/reference/_1_embed_with_CLIP.py:187-199 (same names, same defaults for the model) + this driver's own."""
     parser = argparse.ArgumentParser()
     parser.add_argument("--root_dir", type=str, required=True, help="Root directory of the dataset (can contain subdirectories)")
-    parser.add_argument("--models_to_use", type=str, nargs="+", default=["ViT-L-14/openai"],
+    # default = the reference's (/root/reference/_1_embed_with_CLIP.py:190): the shipped regressor checkpoint names this tower
+    # in its clip_models, so `.pt` files written without the flag carry the key that checkpoint looks for
+    parser.add_argument("--models_to_use", type=str, nargs="+", default=["ViT-L-14-336/openai"],
                         help="Which CLIP models to use, '<arch>/<pretrained>'")
     parser.add_argument("--batch_size", type=int, default=128, help="Number of images to encode at once")
     parser.add_argument("--num_workers", type=int, default=4, help="Number of workers for the dataloader")
@@ -537,10 +546,16 @@ def main(argv=None):
     parser.add_argument("--precision", type=str, default="bf16", choices=["bf16", "fp8"],
                         help="Arithmetic of the encoder's GEMMs: bf16 (embeddings within 7e-5 of the fp32 path, 1 - cos) or e4m3 block "
                              "GEMMs (within 6e-4; 1.45x the images per second)")
-    args = parser.parse_args(argv)
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
     if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) > 1:
-        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
-        torch.distributed.init_process_group("nccl")
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        # device_id binds the communicator to this rank's GPU at once (no lazy guess from the first collective's tensors)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
     device = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda"
     print(f"Embedding all imgs with {len(args.models_to_use)} models: \n--> {args.models_to_use}")
     for model_name in args.models_to_use:

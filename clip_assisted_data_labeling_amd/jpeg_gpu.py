@@ -44,11 +44,13 @@ class GpuJpegDecoder:
     NO_MEMORY = 77            # CLIPENC_JPEGDEC_NO_MEMORY (include/clipenc.h); as a per-file status: "decode it yourself"
 
     def reserve(self, pixels: int, file_bytes: int, staging: bool = False) -> bool:
-        """Sets aside device scratch for batches of up to `pixels` decoded pixels from `file_bytes` of files (about 4.5 bytes per
-        pixel + the files' bytes) and, with staging=True, the page-locked staging buffer (the files' bytes; page-locking takes
+        """Sets aside device scratch for batches of up to `pixels` decoded pixels from `file_bytes` of files (9 bytes per
+        pixel + the files' bytes: int16 coefficients + sample planes of an un-subsampled 4:4:4 file, the worst case -- 4:2:0
+        files need half of it, but an arena sized for them regrows in the middle of a run when 4:4:4 files arrive, and hipFree +
+        hipMalloc synchronise the device) and, with staging=True, the page-locked staging buffer (the files' bytes; page-locking takes
         ~0.2 s per GB, so by default it grows with the batches instead).  Call it before other work runs on the device: growing
         the device scratch later (hipFree + hipMalloc) synchronises the device.  False when the memory is not there."""
-        rc = self.lib.jpegdec_reserve(self.handle, int(pixels * 4.5) + int(file_bytes * 1.25) + (1 << 20),
+        rc = self.lib.jpegdec_reserve(self.handle, int(pixels * 9) + int(file_bytes * 1.25) + (1 << 20),
                                       int(file_bytes * 1.25) + (1 << 20) if staging else 0)
         if rc == self.NO_MEMORY:
             return False

@@ -36,9 +36,10 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None, dst: Optional[int
     """Collects the row blocks laid out by `shard_bounds` into the full `[n_total, ...]` tensor.
 
     dst=None: every rank receives the full tensor (all-gather).  Equal shards are one `all_gather_into_tensor` straight
-              into the result; ragged shards (n_total % W != 0) are W broadcasts, each into its final rows.
-    dst=r:    only rank r allocates and receives the result (point-to-point receives into the final rows); the other
-              ranks send their block and get None.
+              into the result; ragged shards (n_total % W != 0) are one batch of point-to-point sends / receives posted
+              together, each block received into its final rows.
+    dst=r:    only rank r allocates and receives the result: the receives from ALL peers are posted together (one RCCL
+              group call, every xGMI link busy at once) into the final rows; the other ranks send their block and get None.
     A single process returns `local` itself."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         if local.shape[0] != n_total:
@@ -61,20 +62,41 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None, dst: Optional[int
         if n_total % world == 0:
             dist.all_gather_into_tensor(out, local, group=group)
             return out
+        # ragged shards: every rank posts its W - 1 sends and W - 1 receives AT ONCE (one RCCL group call), each block
+        # received straight into its final rows -- all xGMI links carry traffic together, instead of W broadcasts in turn
         out[lo:hi].copy_(local)
+        ops = []
         for r in range(world):
             rlo, rhi = shard_bounds(n_total, r, world)
+            if r == rank:
+                continue
             if rhi > rlo:
-                dist.broadcast(out[rlo:rhi], src=peer(r), group=group)
+                ops.append(dist.P2POp(dist.irecv, out[rlo:rhi], peer(r), group))
+            if hi > lo:
+                ops.append(dist.P2POp(dist.isend, local, peer(r), group))
+        _run_p2p(ops)
         return out
     if rank != dst:
         if hi > lo:
-            dist.send(local, dst=peer(dst), group=group)
+            _run_p2p([dist.P2POp(dist.isend, local, peer(dst), group)])
         return None
+    # true gather: ALL peers' receives are posted together (SURVEY section 5.8 prices the gather of configs[3] at ~10 ms
+    # BECAUSE the 7 peers write at the same time, one xGMI link each; receiving them in turn used one link at a time)
     out = local.new_empty((n_total,) + tail)
     out[lo:hi].copy_(local)
+    ops = []
     for r in range(world):
         rlo, rhi = shard_bounds(n_total, r, world)
         if r != dst and rhi > rlo:
-            dist.recv(out[rlo:rhi], src=peer(r), group=group)
+            ops.append(dist.P2POp(dist.irecv, out[rlo:rhi], peer(r), group))
+    _run_p2p(ops)
     return out
+
+
+def _run_p2p(ops) -> None:
+    """Posts a list of P2POp together (`batch_isend_irecv`: one ncclGroupStart / End on RCCL, plain isend / irecv on
+    gloo) and waits for all of them."""
+    if not ops:
+        return
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()

@@ -12,7 +12,9 @@ What is pinned against what:
                          run on a planted-pair set written as <uuid>.jpg/.pt files: reported pairs+values.
   encoder_*.npz          oracle/vit_oracle.py outputs on seeded weights, after asserting agreement with
                          transformers.CLIPVisionModelWithProjection (independent implementation; the
-                         reference has no vectors at the open_clip boundary).  encoder_*-erf.npz: the erf-GELU
+                         reference has no vectors at the open_clip boundary).  encoder_ViT-L-14.npz / encoder_ViT-L-14-336.npz
+                         (`make_golden.py full`): the same at FULL size (1024 wide x 24 blocks x 257 / 577 tokens), with the
+                         transformers embeddings stored next to the oracle's.  encoder_*-erf.npz: the erf-GELU
                          tower of the non-openai tags, cross-checked with hidden_act="gelu".
   simsearch_small.npz    the reference's `compute_distance` and `topN` (/root/reference/tools/find_similar_imgs.py)
                          on a seeded embedding set: l2 and cosine distances, the top-N set it keeps.
@@ -284,9 +286,12 @@ def make_encoder(arch, n_crops, seed, in_seed, pretrained="openai"):
     back = vit_config.normalise_state_dict(hf.state_dict(), cfg)
     assert all(torch.equal(back[k], sd[k]) for k in sd)
     wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+    # emb_transformers: the INDEPENDENT implementation's embeddings themselves (round 5: the full-size fixtures are compared with
+    # both, so the 1024-wide tower is no longer checked against this repo's restatement alone)
     np.savez_compressed(os.path.join(HERE, f"encoder_{name}.npz"), arch=arch, pretrained=pretrained, weight_seed=seed, input_seed=in_seed,
                         n_crops=n_crops, weight_abs_sum=wsum, crops_abs_sum=float(crops.double().abs().sum()),
-                        emb=emb.numpy(), ln_pre_cls=taps["ln_pre"][:, 0].numpy(),
+                        emb=emb.numpy(), emb_transformers=ref.numpy(), oracle_vs_transformers_max_abs=err,
+                        ln_pre_cls=taps["ln_pre"][:, 0].numpy(),
                         block0_cls=taps["block0"][:, 0].numpy(),
                         last_block_tok1=taps[f"block{cfg.layers - 1}"][:, 1].numpy())
     print(f"encoder_{name}: oracle vs transformers max-abs {err:.2e}")
@@ -329,6 +334,10 @@ if __name__ == "__main__":
     torch.manual_seed(0)
     if sys.argv[1:] == ["erf"]:          # only the fixture added in round 4 (needs transformers, not the reference)
         make_encoder("ViT-small-test", 5, seed=1, in_seed=2, pretrained="laion2b_s32b_b82k")
+        sys.exit(0)
+    if sys.argv[1:] == ["full"]:         # round 5: the full-size towers (needs transformers, not the reference; ~1 min of CPU, 5 GB)
+        make_encoder("ViT-L-14", 4, seed=11, in_seed=12)
+        make_encoder("ViT-L-14-336", 2, seed=13, in_seed=14)
         sys.exit(0)
     make_crop_boxes()
     make_regressor()

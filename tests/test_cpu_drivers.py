@@ -163,3 +163,11 @@ def test_decode_chunks_are_cut_by_files_and_by_pixels():
         chunks.append(n)
         pos += n
     assert chunks == [4, 3, 1, 4] and sum(chunks) == len(sizes)
+
+
+def test_embed_driver_defaults_to_the_references_model():
+    """/root/reference/_1_embed_with_CLIP.py:190: `--models_to_use` defaults to ViT-L-14-336/openai, the tower the shipped
+    regressor checkpoint names in clip_models -- a run without the flag must write the key that checkpoint reads."""
+    args = embed_driver.build_parser().parse_args(["--root_dir", "x"])
+    assert args.models_to_use == ["ViT-L-14-336/openai"]
+    assert args.model_path is None and not args.force_reencode

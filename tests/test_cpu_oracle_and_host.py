@@ -62,6 +62,21 @@ def test_vit_oracle_matches_golden(golden_dir, arch):
     assert torch.allclose(emb.norm(dim=-1), torch.ones(emb.shape[0]), atol=1e-6)
 
 
+def test_vit_oracle_at_full_size_matches_the_transformers_vectors(golden_dir):
+    """The 1024-wide x 24-block x 257-token tower: the oracle on ONE crop of the fixture (a few seconds of CPU) against the
+    embedding transformers.CLIPVisionModelWithProjection produced for it in the authoring container (`make_golden.py full`)."""
+    g = np.load(os.path.join(golden_dir, "encoder_ViT-L-14.npz"))
+    cfg = golden_cfg(g)
+    assert (cfg.width, cfg.layers, cfg.tokens, cfg.mlp_dim) == (1024, 24, 257, 4096)
+    sd = vit_config.seeded_state_dict(cfg, int(g["weight_seed"]))
+    crops = synthetic_crops(int(g["n_crops"]), cfg.image_size, int(g["input_seed"]))
+    emb = vit_oracle.encode_image(sd, cfg, crops[1:2])
+    assert np.abs(emb.numpy()[0] - g["emb_transformers"][1]).max() < 1e-5
+    assert np.abs(g["emb"] - g["emb_transformers"]).max() < 1e-5 and float(g["oracle_vs_transformers_max_abs"]) < 1e-5
+    g336 = np.load(os.path.join(golden_dir, "encoder_ViT-L-14-336.npz"))
+    assert golden_cfg(g336).tokens == 577 and np.abs(g336["emb"] - g336["emb_transformers"]).max() < 1e-5
+
+
 def test_dedup_oracle_matches_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "dedup_planted.npz"))
     pairs, vals = dedup_oracle.near_duplicates(torch.from_numpy(g["emb_fp16"]), float(g["threshold"]))

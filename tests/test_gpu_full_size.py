@@ -108,3 +108,45 @@ def test_vit_l_width_erf_gelu_tower_matches_fp32_oracle(gpu, precision):
         assert one_minus_cos(out["erf"], ref).max().item() < one_minus_cos(out["erf"], ref_q).min().item()
         assert one_minus_cos(out["quick"], ref_q).max().item() < one_minus_cos(out["quick"], ref).min().item()
         assert one_minus_cos(x2.flatten(1), taps["block1"].flatten(1)).max().item() < 5e-4
+
+
+@pytest.mark.parametrize("arch", ["ViT-L-14", "ViT-L-14-336"])
+def test_full_size_tower_matches_the_independent_implementation(gpu, golden_dir, arch):
+    """tests/golden/encoder_ViT-L-14.npz / _336.npz (`make_golden.py full`): the embeddings of
+    transformers.CLIPVisionModelWithProjection -- an implementation that shares no code with oracle/vit_oracle.py -- on the seeded
+    FULL-SIZE towers (1024 wide x 24 blocks, 257 / 577 tokens), generated in the authoring container with the oracle asserted within
+    1e-5 of them.  The HIP tower, bf16 and e4m3 block GEMMs, is held to the north_star tolerance against THOSE vectors, and the
+    taps pin the front end (ln_pre) and the first block separately."""
+    import os
+    g = np.load(os.path.join(golden_dir, f"encoder_{arch}.npz"))
+    cfg = vit_config.ARCHS[arch]
+    sd = vit_config.seeded_state_dict(cfg, int(g["weight_seed"]))
+    wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(wsum - float(g["weight_abs_sum"])) <= 1e-9 * wsum, "the seeded weights are not the ones the fixture was made with"
+    crops = synthetic_crops(int(g["n_crops"]), cfg.image_size, int(g["input_seed"]))
+    assert abs(float(crops.double().abs().sum()) - float(g["crops_abs_sum"])) <= 1e-9 * float(g["crops_abs_sum"])
+    hf, ora = torch.from_numpy(g["emb_transformers"]), torch.from_numpy(g["emb"])
+    assert float(g["oracle_vs_transformers_max_abs"]) < 1e-5 and (hf - ora).abs().max().item() < 1e-5
+    vit = HipViT(cfg, sd, gpu)
+    try:
+        got = vit.encode(crops.to(gpu)).cpu()
+        omc = one_minus_cos(got, hf)
+        print(f"{arch} bf16 1-cos vs transformers:", omc.max().item())
+        assert omc.max().item() < 1e-3, omc
+        assert (got - hf).abs().max().item() < 0.02
+        # stage taps (class-token rows of ln_pre and of the first block, token 1 of the last block): the front end, the first
+        # block and the full depth are pinned separately, so compensating errors cannot hide behind the final embedding
+        x0 = vit.debug_run_layers(crops.to(gpu), 0).float().cpu()
+        assert one_minus_cos(x0[:, 0], torch.from_numpy(g["ln_pre_cls"])).max().item() < 1e-4
+        x1 = vit.debug_run_layers(crops.to(gpu), 1).float().cpu()
+        assert one_minus_cos(x1[:, 0], torch.from_numpy(g["block0_cls"])).max().item() < 1e-4
+        # (the product's last block runs on the class-token rows only, section 3.0 of DESIGN.md; forward_tokens runs it in full)
+        xl = vit.debug_run_layers(crops.to(gpu), cfg.layers).float().cpu()
+        assert one_minus_cos(xl[:, 1], torch.from_numpy(g["last_block_tok1"])).max().item() < 5e-4
+        vit.set_precision("fp8")
+        got8 = vit.encode(crops.to(gpu)).cpu()
+        omc8 = one_minus_cos(got8, hf)
+        print(f"{arch} fp8 1-cos vs transformers:", omc8.max().item())
+        assert omc8.max().item() < 1e-3, omc8
+    finally:
+        vit.close()
