@@ -346,7 +346,7 @@ def cpu_baseline(cfg, sd, Ws, bs):
     return out
 
 
-KERNEL_SOURCES = (("gemm_fp8", ("gemm_fp8.hip",)), ("gemm_persist", ("gemm_persist.hip", "gemm_tri.hip")), ("attn_", ("attention.hip",)),
+KERNEL_SOURCES = (("cls_attn", ("cls_attention.hip",)), ("gemm_fp8", ("gemm_fp8.hip",)), ("gemm_persist", ("gemm_persist.hip", "gemm_tri.hip")), ("attn_", ("attention.hip",)),
                   ("quant_", ("quant_fp8.hip",)), ("row_norm_consts", ("quant_fp8.hip",)), ("fcreg", ("fcreg.hip",)),
                   ("", ("elementwise.hip",)))
 
@@ -382,8 +382,18 @@ def pmc_traffic(kernel_name):
                 recorded = doc.get("_meta", {}).get("source_sha", {}).get(base)
                 if recorded != kernel_source_sha(base):
                     return None                       # taken with other sources (or before shas were recorded)
+                PMC_SOURCE[kernel_name] = os.path.relpath(os.path.dirname(path), ROOT)
                 return round(float(v.get("bytes_per_launch", v.get("hbm_bytes", 0.0))), 1)
     return None
+
+
+PMC_SOURCE = {}       # kernel name -> the profiles/ directory its committed traffic constant was read from (pmc_traffic)
+
+
+def traffic_source(kernel_name):
+    """Where `traffic` of a kernel comes from: a COMMITTED rocprofv3 PMC summary (another box, another run -- PMC passes cannot run
+    inside the bench), named so that the line says so itself."""
+    return PMC_SOURCE.get(kernel_name)
 
 
 def algorithmic_bytes_per_step(cfg, crops):
@@ -394,8 +404,9 @@ def algorithmic_bytes_per_step(cfg, crops):
     full = L - 1
     return {
         "qkv": full * (T * D * 2 + 3 * D * D * 2 + T * 3 * D * 2) + (2 * crops * D * 2 + D * D * 2),
-        # (last block: the class-token attention reads the crop's residual rows twice, no K / V: cls_attention.hip)
-        "attention": full * (T * 3 * D * 2 + T * D * 2) + 2 * T * D * 2,
+        # (the L - 1 streaming launches alone; the last block's class-token attention -- five small launches, cls_attention.hip --
+        #  is profiled as its own kind, `cls_attn_kernel`, and is not part of this row)
+        "attention": full * (T * 3 * D * 2 + T * D * 2),
         "out_proj": full * (3 * T * D * 2 + D * D * 2) + (3 * crops * D * 2 + D * D * 2),
         "fc1": full * (T * D * 2 + M * D * 2 + T * M * 2) + (crops * D * 2 + M * D * 2 + crops * M * 2),
         "fc2": full * (T * M * 2 + D * M * 2 + 2 * T * D * 2) + (crops * M * 2 + D * M * 2 + 2 * crops * D * 2),
@@ -416,7 +427,7 @@ def per_kernel_table(prof, prof_steps, cfg, crops, fp8=False):
                 return k
         return None
     rows = {"qkv": find("gemm_fp8_kernel<0") if fp8 else find("gemm_persist_kernel<2, -1>"),
-            "attention": find("attn_"),
+            "attention": find("attn_stream") or find("attn_long") or find("attn_kernel"),   # (not cls_attn_kernel: its own kind)
             "out_proj": find(shape="out_proj"), "fc2": find(shape="fc2"),
             "fc1": (find("gemm_fp8_kernel<2") if fp8 else (find("gemm_persist_kernel<2, 0>") or find("gemm_persist_kernel<2, 1>")))}
     alg = algorithmic_bytes_per_step(cfg, crops)
@@ -432,7 +443,7 @@ def per_kernel_table(prof, prof_steps, cfg, crops, fp8=False):
         tr = pmc_traffic(k)
         out[key] = {"kernel": k.replace("shape:", ""), "ms_per_step": round(ms / prof_steps, 3), "launches_per_step": round(launches, 2),
                     "tflops": round(tf, 1), "peak": peak, "frac": round(tf / peak, 4),
-                    "algorithmic_bytes_per_launch": round(alg_b, 1), "traffic": tr,
+                    "algorithmic_bytes_per_launch": round(alg_b, 1), "traffic": tr, "traffic_source": traffic_source(k),
                     "traffic_ratio": round(tr / alg_b, 3) if tr else None}
     return out
 
@@ -477,39 +488,46 @@ def fp8_step(vit, reg, crops, cfg, n_img):
 
 
 def vit_l14_336_step(dev, Ws, bs):
-    """The reference's DEFAULT model (/root/reference/_1_embed_with_CLIP.py:190: ViT-L-14-336, 577 tokens) at full size: 120 images
-    x 4 crops of 336 x 336 per step, bf16, fused regressor; images/s and the attention kernel's share of the step."""
+    """The reference's DEFAULT model (/root/reference/_1_embed_with_CLIP.py:190: ViT-L-14-336, 577 tokens) at full size, bf16, fused
+    regressor: the headline batch -- 512 images x 4 crops of 336 x 336 = 1 181 696 token rows, 26 GB of workspace -- and, under
+    `tile_friendly_120_images`, 120 images (480 crops = 1 082 row tiles: 16.9 / 50.7 / 67.6 full rounds of 256 workgroups for the three
+    GEMM widths; the measurement of rounds 3-4).  images/s, per-kernel table and the attention kernel's share of the step."""
     from clip_assisted_data_labeling_amd import vit_config
     from clip_assisted_data_labeling_amd.embedder import HipViT
     from clip_assisted_data_labeling_amd.nn_model import HipRegressor
     cfg = vit_config.ARCHS["ViT-L-14-336"]
-    # 120 images = 480 crops x 577 tokens = 1 082 row tiles: 16.9 / 50.7 / 67.6 rounds of 256 workgroups for the three GEMM widths
-    # (128 images are 1 154 tiles = 18.03 rounds for the residual GEMMs: a nineteenth round with 8 busy CUs)
-    n_img = 120
-    vit = HipViT(cfg, vit_config.seeded_state_dict(cfg, 0), dev, chunk_crops=n_img * CROPS_PER_IMAGE)
-    reg = HipRegressor([torch.from_numpy(w) for w in Ws], [torch.from_numpy(b) for b in bs], 0.01, dev)
-    try:
-        crops = synthetic_crops(n_img * CROPS_PER_IMAGE, cfg.image_size, 336, dev)
-        sel = list(range(CROPS_PER_IMAGE))
-        dt = timed_steps(lambda: vit.encode_score(crops, reg, CROPS_PER_IMAGE, sel), 3)
-        vit.profile_enable(True)
-        vit.encode_score(crops, reg, CROPS_PER_IMAGE, sel)
-        torch.cuda.synchronize()
-        prof = vit.profile_read()
-    finally:
-        vit.close()
-        reg.close()
-    total = sum(v[0] for k, v in prof.items() if not k.startswith("shape:"))
-    attn = sum(v[0] for k, v in prof.items() if k.startswith("attn_"))
-    attn_fl = sum(v[2] for k, v in prof.items() if k.startswith("attn_"))
-    value = n_img / dt
     flop = 2.0 * cfg.macs_per_crop() * CROPS_PER_IMAGE
-    return {"workload": f"ViT-L-14-336 (the reference's default model, 577 tokens) bf16 encode + score of {n_img} images x 4 crops of 336 x 336, 3 steps",
-            "value": round(value, 2), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3),
-            "end_to_end_tflops": round(value * flop / 1e12, 1), "frac_of_bf16_peak": round(value * flop / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "attention_share_of_step": round(attn / total, 4) if total > 0 else None,
-            "attention_tflops": round(attn_fl / (attn * 1e-3) / 1e12, 1) if attn > 0 else None,
-            "kernels_ms_per_step": {k: round(v[0], 3) for k, v in prof.items() if v[0] > 0 and not k.startswith("shape:")}}
+    sel = list(range(CROPS_PER_IMAGE))
+
+    def one(n_img, steps):
+        vit = HipViT(cfg, vit_config.seeded_state_dict(cfg, 0), dev, chunk_crops=n_img * CROPS_PER_IMAGE)
+        reg = HipRegressor([torch.from_numpy(w) for w in Ws], [torch.from_numpy(b) for b in bs], 0.01, dev)
+        try:
+            crops = synthetic_crops(n_img * CROPS_PER_IMAGE, cfg.image_size, 336, dev)
+            dt = timed_steps(lambda: vit.encode_score(crops, reg, CROPS_PER_IMAGE, sel), steps)
+            vit.profile_enable(True)
+            vit.encode_score(crops, reg, CROPS_PER_IMAGE, sel)
+            torch.cuda.synchronize()
+            prof = vit.profile_read()
+        finally:
+            vit.close()
+            reg.close()
+            torch.cuda.empty_cache()
+        total = sum(v[0] for k, v in prof.items() if not k.startswith("shape:"))
+        attn = sum(v[0] for k, v in prof.items() if k.startswith("attn_"))
+        attn_fl = sum(v[2] for k, v in prof.items() if k.startswith("attn_"))
+        value = n_img / dt
+        return {"workload": f"ViT-L-14-336 (the reference's default model, 577 tokens) bf16 encode + score of {n_img} images x 4 crops of "
+                            f"336 x 336, {steps} steps",
+                "value": round(value, 2), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3),
+                "end_to_end_tflops": round(value * flop / 1e12, 1), "frac_of_bf16_peak": round(value * flop / 1e12 / PEAK_BF16_TFLOPS, 4),
+                "attention_share_of_step": round(attn / total, 4) if total > 0 else None,
+                "attention_tflops": round(attn_fl / (attn * 1e-3) / 1e12, 1) if attn > 0 else None,
+                "per_kernel": per_kernel_table(prof, 1, cfg, n_img * CROPS_PER_IMAGE),
+                "kernels_ms_per_step": {k: round(v[0], 3) for k, v in prof.items() if v[0] > 0 and not k.startswith("shape:")}}
+    out = one(512, 2)
+    out["tile_friendly_120_images"] = one(120, 3)
+    return out
 
 
 def embed_e2e(dev, n=4096, size=512, workers=16, batch=512):
@@ -869,6 +887,9 @@ def main():
                            "flop_per_image": flop_per_image, "flop_per_image_executed": flop_exec_per_image},
             "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": d_peak,
                          "unit": "TFLOP/s", "frac": round(achieved / d_peak, 4), "traffic": pmc_traffic(DOMINANT),
+                         # `traffic` is a COMMITTED constant (rocprofv3 PMC passes of the named directory: another run, possibly
+                         # another box), guarded by the sha of the kernel's sources -- not a measurement of this run
+                         "traffic_source": traffic_source(DOMINANT),
                          "launches": d_n, "avg_launch_ms": round(d_ms / max(d_n, 1), 4),
                          "algorithmic_flop_per_launch": d_fl / max(d_n, 1),
                          # the same achieved rate priced against the peak at the clock the board actually held:
@@ -895,6 +916,11 @@ def main():
             ceil = mfma_stream_ceiling(dev, "fp8" in DOMINANT)
             ceil["frac"] = round(achieved / ceil["value"], 4) if ceil["value"] else None     # dominant kernel / that ceiling
             line["roofline"]["power_capped_mfma_stream"] = ceil
+            # the one number that describes THIS board: what its power cap grants the matrix pipes alone (a pure MFMA stream,
+            # no LDS, no memory) is the ceiling a kernel can be held to here -- nominal x 0.78-0.83 on the boxes seen so far
+            line["roofline"]["frac_of_power_capped_stream"] = ceil["frac"]
+            line["end_to_end"]["frac_of_power_capped_stream"] = (round(value * flop_per_image / 1e12 / ceil["value"], 4)
+                                                                  if ceil["value"] else None)
         if world == 1 and not args.no_secondary and not fp8:
             want = set(args.secondary.split(","))
             sec = {}

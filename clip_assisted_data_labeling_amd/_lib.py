@@ -46,6 +46,7 @@ SIGNATURES = {
     "clipenc_create": (c_int, [POINTER(clipenc_config), POINTER(clipenc_weights), c_int, POINTER(c_void_p)]),
     "clipenc_destroy": (c_int, [c_void_p]),
     "clipenc_set_chunk": (c_int, [c_void_p, c_int]),
+    "clipenc_set_cu_budget": (c_int, [c_void_p, c_int]),
     "clipenc_set_precision": (c_int, [c_void_p, c_int]),
     "clipenc_set_pixel_norm": (c_int, [c_void_p, c_float_p, c_float_p]),
     "clipenc_get_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]),
@@ -114,6 +115,7 @@ DIAG_SIGNATURES = {
     "clipenc_op_gemm_lnfold": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                        c_void_p, c_void_p, c_void_p]),
     "clipenc_op_gemm_nt_stamps": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "clipenc_op_gemm_nt_ld": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "clipenc_op_gemm_resid": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "clipenc_diag_fp8_stamps": (c_int, [c_void_p]),
 }

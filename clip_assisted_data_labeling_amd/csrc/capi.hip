@@ -90,6 +90,7 @@ struct LayerDev8 {                                       // CLIPENC_PREC_FP8: e4
 enum { PK_PATCHIFY = 0, PK_GEMM_PATCH, PK_EMBED_LN_PRE, PK_GEMM_QKV, PK_ATTENTION, PK_GEMM_RESID, PK_GEMM_FC1, PK_HEAD, PK_FCREG,
        PK_SUB_OUT, PK_SUB_FC2,                // PK_SUB_*: the EPI_RESID launches split by shape
        PK_QUANT_LN, PK_QUANT, PK_GEMM8_QKV, PK_GEMM8_FC1, PK_GEMM8_RESID, PK_SUB8_OUT, PK_SUB8_FC2, PK_QUANT_BLOCK, PK_ROW_CONSTS,
+       PK_CLS_ATTENTION,                      // the last block's class-token attention: qmask + r_h GEMM + cls_attn_kernel + o_h GEMM + finish
        PK_COUNT };
 static const char* const kProfileNames[PK_COUNT] = {
     "patchify_kernel<float, 14>", "gemm_persist_kernel<1, -1>", "embed_ln_pre_kernel<2>", "gemm_persist_kernel<2, -1>",
@@ -97,7 +98,8 @@ static const char* const kProfileNames[PK_COUNT] = {
     "shape:out_proj(gemm_persist_kernel<3, -1>)", "shape:fc2(gemm_persist_kernel<3, -1>)",
     "quant_ln16_kernel<8>", "quant_rows_kernel<unsigned short, false, 2, 4>", "gemm_fp8_kernel<0, -1, false>",
     "gemm_fp8_kernel<2, 0, false>", "gemm_fp8_kernel<1, -1, false>", "shape:out_proj(gemm_fp8_kernel<1, -1, false>)",
-    "shape:fc2(gemm_fp8_kernel<1, -1, false>)", "quant_block_kernel<8>", "row_norm_consts_kernel"};
+    "shape:fc2(gemm_fp8_kernel<1, -1, false>)", "quant_block_kernel<8>", "row_norm_consts_kernel",
+    "cls_attn_kernel"};
 // (template arguments: <EPI, ACT> and, fp8, <EPI, ACT, LNF>; FC1 is <2, 0> with QuickGELU and <2, 1> with erf-GELU; the fp8
 //  names above are the unfused tower's (widths over 1024), clipenc_profile_read substitutes the fused tower's; the attention
 //  name is the ViT-L/14 instantiation, other token counts use attn_kernel<NKT> / attn_long_kernel<7>; quant_ln16_kernel<width / 128>)
@@ -181,6 +183,7 @@ struct clipenc_s {
   bool cls_shortcut = true;                              // last block's attention without K and V (the diagnostic build reads CLIPENC_CLS_KV=1 to switch it off)
   unsigned* tickets = nullptr;                           // [CE_TICKET_WORDS] zeroed per pass: eight ticket words per persistent GEMM launch (gemm.h)
   bool dynamic_tail = true;                              // (the diagnostic build reads CLIPENC_STATIC_TILES=1 to switch the tickets off)
+  int cu_budget = 0;                                     // clipenc_set_cu_budget: CUs the persistent kernels may hold (0 = all)
 };
 
 struct preproc_s {
@@ -262,6 +265,7 @@ int ensure_workspace(clipenc_s* e) {
 // runs patch-embed + ln_pre + `n_layers` blocks on `c` crops; leaves the residual stream in e->x
 // cls_only_last: the caller only needs token 0 of the last block (clipenc_encode); false keeps every token (forward_tokens)
 int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers, hipStream_t st, bool cls_only_last = false) {
+  const CuBudgetScope cu_scope(e->cu_budget);              // the persistent launchers of this thread size their grids by it (common.h)
   const clipenc_config& g = e->cfg;
   const int T = c * e->tokens, P = c * (e->tokens - 1);
   const int parts = g.width / 256;
@@ -282,11 +286,15 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     const int Dw = g.width, H = g.heads;
     const size_t n = ce_cls_attn_scratch_elems(c, Dw, H);
     *done = false;
-    if (!e->cls_shortcut || (size_t)T * g.mlp_dim * 2 < 4 * n * 2 + (size_t)c * H * 4 + 1024) return hipSuccess;
-    bf16_t *Qm = e->hid, *R = e->hid + n, *Zp = e->hid + 2 * n, *Of = e->hid + 3 * n;
-    float* mzv = (float*)(e->hid + 4 * n);
+    // one predicate for "can this shape take the shortcut" (ce_cls_attn_supported, cls_attention.hip), tested BEFORE anything is
+    // launched: an unsupported shape returns done = false and the caller runs the projected K | V path
+    if (!e->cls_shortcut || !ce_cls_attn_supported(c, e->tokens, Dw, H) ||
+        (size_t)T * g.mlp_dim * 2 < 5 * n * 2 + (size_t)c * H * 4 + 1024) return hipSuccess;
+    bf16_t *Qm = e->hid, *R = e->hid + n, *Zp = e->hid + 2 * n;
+    float* Of = (float*)(e->hid + 3 * n);                       // fp32: rounded once, after the mean term is subtracted (cls_finish)
+    float* mzv = (float*)(e->hid + 5 * n);
     const size_t q_stride = (size_t)e->tokens * 3 * Dw;
-    pf.begin(PK_ATTENTION, 4.0 * c * (double)e->tokens * dD, st);
+    pf.begin(PK_CLS_ATTENTION, 4.0 * c * (double)e->tokens * dD, st);   // its own kind: PK_ATTENTION is the streaming kernel's launches alone
     hipError_t err = ce_cls_qmask(e->qkv, q_stride, Qm, c, Dw, H, st);
     GemmParams a{};
     a.A = Qm; a.lda = Dw; a.W = e->w_k_t; a.ldw = Dw; a.M = c * H; a.N = Dw; a.K = Dw; a.out = R; a.ldo = Dw; a.ticket = ticket();
@@ -296,7 +304,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
                         g.ln_eps, st);
     GemmParams b{};
     b.A = Zp; b.lda = Dw; b.W = LL.w_qkv + (size_t)2 * Dw * Dw; b.ldw = Dw; b.M = c * H; b.N = Dw; b.K = Dw; b.out = Of; b.ldo = Dw; b.ticket = ticket();
-    if (err == hipSuccess) err = ce_gemm_nt(b, CE_DT_BF16, EPI_STORE_BF16, st);
+    if (err == hipSuccess) err = ce_gemm_nt(b, CE_DT_BF16, EPI_STORE_F32, st);
     if (err == hipSuccess)
       err = ce_cls_finish(Of, mzv, LL.cs_qkv + 2 * Dw, LL.b_qkv + 2 * Dw, out, (size_t)e->tokens * Dw, out_inv, c, Dw, H, st);
     pf.end(st);
@@ -831,6 +839,14 @@ int clipenc_set_chunk(clipenc_t e, int chunk_crops) {
   const int old_chunk = e->chunk;
   e->chunk = chunk_crops;
   if (int rc = ensure_workspace(e)) { e->chunk = old_chunk; return rc; }
+  return 0;
+}
+
+int clipenc_set_cu_budget(clipenc_t e, int n_cu) {
+  if (!e) return fail("NULL handle");
+  if (n_cu < 0) return fail("cu budget %d < 0", n_cu);
+  if (n_cu != 0 && (n_cu < 8 || n_cu % 8 != 0)) return fail("cu budget %d: 0 (all) or a multiple of 8 (one CU per XCD at a time)", n_cu);
+  e->cu_budget = n_cu;
   return 0;
 }
 
@@ -1463,6 +1479,15 @@ int clipenc_op_gemm_resid(const void* a_dev, const void* w_dev, int m, int n, in
   p.bias = bias_dev; p.resid = x_inout_dev; p.stats_out = stats_out_dev; p.stats_ld = stats_ld; p.dbg = stamps_dev;
   hipError_t err = ce_gemm_nt(p, CE_DT_BF16, EPI_RESID, (hipStream_t)stream);
   if (err != hipSuccess) return fail("gemm_resid failed: %s", hipGetErrorString(err));
+  return 0;
+}
+
+// the bf16-store GEMM with explicit leading dimensions (elements): the row-pitch experiment of tools/gemm_pitch_probe.py
+int clipenc_op_gemm_nt_ld(const void* a_dev, int lda, const void* w_dev, int ldw, int m, int n, int k, void* out_dev, int ldo, void* stream) {
+  GemmParams p{};
+  p.A = a_dev; p.lda = lda; p.W = w_dev; p.ldw = ldw; p.M = m; p.N = n; p.K = k; p.out = out_dev; p.ldo = ldo;
+  hipError_t err = ce_gemm_nt(p, CE_DT_BF16, EPI_STORE_BF16, (hipStream_t)stream);
+  if (err != hipSuccess) return fail("gemm_nt_ld failed: %s", hipGetErrorString(err));
   return 0;
 }
 

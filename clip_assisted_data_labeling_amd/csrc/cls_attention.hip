@@ -232,13 +232,16 @@ __global__ void cls_qmask_kernel(const bf16_t* __restrict__ q, size_t q_stride, 
 }
 
 // o_c[h * 64 + d] = Of[(c * H + h)][h * 64 + d] - m_h colsum_v[..] + bias_v[..] -> the class-token row of crop c (bf16, or e4m3 with inv)
-__global__ void cls_finish_kernel(const bf16_t* __restrict__ Of, const float* __restrict__ mz, const float* __restrict__ colsum_v,
+__global__ void cls_finish_kernel(const float* __restrict__ Of, const float* __restrict__ mz, const float* __restrict__ colsum_v,
                                   const float* __restrict__ bias_v, void* __restrict__ out, size_t out_stride, const float* __restrict__ out_inv,
                                   int n_crops, int D, int H) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)n_crops * D) return;
   const int crop = (int)(i / D), n = (int)(i - (size_t)crop * D), hh = n >> 6;
-  const float v = bf16_to_f32(Of[((size_t)crop * H + hh) * D + n]) - mz[(size_t)crop * H + hh] * colsum_v[n] + bias_v[n];
+  // Of is fp32: the mean term is subtracted BEFORE the one rounding of o (as the projected path's fp32 epilogue does); with real
+  // checkpoints |z . W'_v| can be far larger than |v| (non-zero token means, outlier channels), and a bf16 Of put an error of
+  // 2^-9 |Of| on o
+  const float v = Of[((size_t)crop * H + hh) * D + n] - mz[(size_t)crop * H + hh] * colsum_v[n] + bias_v[n];
   if (out_inv) {
     const float s = __builtin_amdgcn_fmed3f(v * out_inv[n], -448.0f, 448.0f);
     const int pk = __builtin_amdgcn_cvt_pk_fp8_f32(s, s, 0, false);
@@ -250,7 +253,15 @@ __global__ void cls_finish_kernel(const bf16_t* __restrict__ Of, const float* __
 
 }  // namespace
 
-size_t ce_cls_attn_scratch_elems(int n_crops, int D, int H) { return (size_t)n_crops * H * D; }   // per bf16 buffer (Qm, R, Zp, Of)
+size_t ce_cls_attn_scratch_elems(int n_crops, int D, int H) { return (size_t)n_crops * H * D; }   // per buffer: Qm, R, Zp (bf16), Of (fp32)
+
+// The shapes cls_attn_kernel is written for -- THE predicate: run_tower (capi.hip) asks it before it launches anything of the
+// shortcut, ce_cls_attn refuses on it.
+bool ce_cls_attn_supported(int n_crops, int n_tok, int D, int H) {
+  if (n_crops < 1 || n_tok < 1 || n_tok > 640 || D < 256 || D > 1024 || D % 256 != 0 || H * 64 != D) return false;
+  const int ntp = (n_tok + 15) / 16 * 16;
+  return SC_OFF + 16 * (ntp * 4 + 16) <= 160 * 1024;
+}
 
 hipError_t ce_cls_qmask(const void* q, size_t q_stride, void* Qm, int n_crops, int D, int H, hipStream_t stream) {
   const size_t pieces = (size_t)n_crops * H * (D / 8);
@@ -261,10 +272,9 @@ hipError_t ce_cls_qmask(const void* q, size_t q_stride, void* Qm, int n_crops, i
 hipError_t ce_cls_attn(const void* x, const float* stats, int parts, int stats_ld, const void* q, size_t q_stride, const float* colsum_k,
                        const float* bias_k, const void* R, void* Zp, float* mz, int n_crops, int n_tok, int D, int H, float eps,
                        hipStream_t stream) {
-  if (n_crops < 1 || n_tok < 1 || n_tok > 640 || D < 256 || D > 1024 || D % 256 != 0 || H * 64 != D) return hipErrorInvalidValue;
+  if (!ce_cls_attn_supported(n_crops, n_tok, D, H)) return hipErrorInvalidValue;
   const int ntp = (n_tok + 15) / 16 * 16;
   const int lds = SC_OFF + 16 * (ntp * 4 + 16);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
   static DeviceKernelSetup setup;
   if (hipError_t e = setup.ensure((const void*)cls_attn_kernel, 160 * 1024, nullptr); e != hipSuccess) return e;
   hipLaunchKernelGGL(cls_attn_kernel, dim3(n_crops), dim3(512), lds, stream, (const bf16_t*)x, stats, parts, stats_ld, (const bf16_t*)q, q_stride,
@@ -275,7 +285,7 @@ hipError_t ce_cls_attn(const void* x, const float* stats, int parts, int stats_l
 hipError_t ce_cls_finish(const void* Of, const float* mz, const float* colsum_v, const float* bias_v, void* out, size_t out_stride,
                          const float* out_inv, int n_crops, int D, int H, hipStream_t stream) {
   const size_t n = (size_t)n_crops * D;
-  hipLaunchKernelGGL(cls_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const bf16_t*)Of, mz, colsum_v, bias_v, out,
+  hipLaunchKernelGGL(cls_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, (const float*)Of, mz, colsum_v, bias_v, out,
                      out_stride, out_inv, n_crops, D, H);
   return hipGetLastError();
 }

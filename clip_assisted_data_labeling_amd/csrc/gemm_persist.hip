@@ -155,7 +155,9 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 #endif
   const bool by_xcd = tiles_n > 4 && (G & 7) == 0;
   const int dyn_rounds = GEMM_DYN_ROUNDS == 0 ? 0 : (by_xcd ? 2 : 1);
-  const int S = (dyn_rounds > 0 && EPI != EPI_THRESH && p.ticket != nullptr && nwg / G >= dyn_rounds + 2)
+  // (K = 128: the tile is ONE stage pair and no STAGE barrier lies between wave 4's write of the ticket slot and the first wave
+  //  row's read of it -- such launches walk by stride)
+  const int S = (dyn_rounds > 0 && EPI != EPI_THRESH && p.ticket != nullptr && nwg / G >= dyn_rounds + 2 && p.K > 128)
                     ? (nwg / G - dyn_rounds) * G : 0x7fffffff;
   // where the ticket waits in LDS: EPI_LNFOLD -- word 0 of part 1 of the CURRENT raw-statistics buffer (dead once this tile's
   // (mean, rstd) are converted, which the ticket-taking wave has done itself by then; the next tile's statistics land in the other

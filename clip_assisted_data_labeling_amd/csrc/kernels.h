@@ -10,6 +10,7 @@ hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int 
 
 // cls_attention.hip: the last block's attention for the class-token query, without K and V
 size_t ce_cls_attn_scratch_elems(int n_crops, int D, int H);
+bool ce_cls_attn_supported(int n_crops, int n_tok, int D, int H);   // the one shape predicate of the class-token shortcut
 hipError_t ce_cls_qmask(const void* q, size_t q_stride, void* Qm, int n_crops, int D, int H, hipStream_t stream);
 hipError_t ce_cls_attn(const void* x, const float* stats, int parts, int stats_ld, const void* q, size_t q_stride, const float* colsum_k,
                        const float* bias_k, const void* R, void* Zp, float* mz, int n_crops, int n_tok, int D, int H, float eps,

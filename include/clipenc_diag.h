@@ -24,6 +24,8 @@ int clipenc_op_gemm_lnfold(const void* a_dev, const void* w_dev, int m, int n, i
  * rounded rows to stats_out_dev [n / 256][stats_ld][2]; stamps_dev may be NULL. */
 int clipenc_op_gemm_resid(const void* a_dev, const void* w_dev, int m, int n, int k, const float* bias_dev, void* x_inout_dev,
                           float* stats_out_dev, int stats_ld, unsigned long long* stamps_dev, void* stream);
+/* The bf16-store GEMM with explicit leading dimensions in elements (multiples of 8, >= k / n): row-pitch experiments. */
+int clipenc_op_gemm_nt_ld(const void* a_dev, int lda, const void* w_dev, int ldw, int m, int n, int k, void* out_dev, int ldo, void* stream);
 /* The fp8 GEMM ops of clipenc.h (clipenc_op_gemm_fp8, _q, _lnf, _resid_q) write the same [tiles][8] stamps into stamps_dev
  * from the next call on (NULL: off again; tools/gemm_fp8_stamps.py). */
 int clipenc_diag_fp8_stamps(unsigned long long* stamps_dev);
