@@ -170,7 +170,7 @@ struct clipenc_s {
   // fused fp8 tower (width <= 1024): the residual stream's e4m3 block-exponent copy, written by the GEMM that produces the rows
   uint8_t* x8 = nullptr;                                 // [T][width]
   uint8_t* xe8 = nullptr;                                // [T][4] exponent bytes
-  float* st8 = nullptr;                                  // [width / 64][Tp][2] partial row statistics
+  float* st8 = nullptr;                                  // [width / 256][Tp][2] partial row statistics (one pair per row and 256 columns)
   float *rr8 = nullptr, *rd8 = nullptr;                  // [Tp] rstd, -mean * rstd
   int ws_precision = -1;
   bool fp8_unfused = false;                              // diagnostic build: CLIPENC_FP8_UNFUSED=1 runs the separate LayerNorm-quantise pass at every width
@@ -241,7 +241,7 @@ int ensure_workspace(clipenc_s* e) {
   const size_t o_a8 = f8 ? take(T * (size_t)g.width) : 0, o_sa8 = f8 ? take(T * 4) : 0;
   const bool f8f = f8 && fp8_fused(g);
   const size_t o_x8 = f8f ? take(T * (size_t)g.width) : 0, o_xe8 = f8f ? take(Tp * 4) : 0;
-  const size_t o_st8 = f8f ? take((size_t)(g.width / 64) * Tp * 8) : 0, o_rr8 = f8f ? take(Tp * 4) : 0, o_rd8 = f8f ? take(Tp * 4) : 0;
+  const size_t o_st8 = f8f ? take((size_t)(g.width / 256) * Tp * 8) : 0, o_rr8 = f8f ? take(Tp * 4) : 0, o_rd8 = f8f ? take(Tp * 4) : 0;
   HIP_TRY(hipSetDevice(e->device));
   // allocate the new slab FIRST and swap it in on success: on failure the handle keeps its old, still valid workspace
   // (and the chunk / precision it was sized for), so no pointer ever refers to freed memory
@@ -333,7 +333,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     // in the fp8 weights and beta in the bias, as for bf16.  No pass over the residual stream between the GEMMs; only the
     // tower's first block is quantised by a kernel of its own, and a one-thread-per-row kernel turns the statistics into
     // (rstd, -mean * rstd) in front of each consumer.
-    const int Dw = g.width, Mh = g.mlp_dim, sparts = g.width / 64;
+    const int Dw = g.width, Mh = g.mlp_dim, sparts = g.width / 256;
     uint8_t* h8 = (uint8_t*)e->hid;
     auto run8 = [&](GemmParams& q, int epi, int kind, int sub) -> hipError_t {
       q.ticket = ticket();

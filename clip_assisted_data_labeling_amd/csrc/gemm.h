@@ -52,7 +52,7 @@ struct GemmParams {
   void* out8; int ld8;           // EPI_RESID_Q: e4m3 copy of the new rows [M][ld8] bytes
   unsigned char* out_exp;        //              exponent byte of (row m, block n0 / 256) at out_exp[m * ld_oexp + n0 / 256]
   int ld_oexp;
-                                 //              stats_out [N / 64][stats_ld][2]: (sum, sum of squares) of the stored bf16 row over 64 columns
+                                 //              stats_out [N / 256][stats_ld][2]: (sum, sum of squares) of the stored bf16 row over 256 columns (the tile's width)
 #ifdef CLIPENC_DIAG                // diagnostic build only (make diag -> libclipenc_hip_diag.so, used by tools/): the product
   unsigned long long* dbg;       // kernels carry no stamp hooks.  Optional [tiles][8] timing stamps.
 #endif

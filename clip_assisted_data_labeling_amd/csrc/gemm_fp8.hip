@@ -263,14 +263,19 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   // First two waits after an epilogue: what they need was issued before the epilogue's stores and vmcnt retires in order,
   // so they may leave the NST row stores of a complete tile outstanding as well (see gemm_persist.hip); one opaque
   // instruction for the compiler.
-  constexpr int NST = EPI == 2 ? 8 : EPI == 3 ? (F8_EPI3_PARTS >= 3 ? 28 : F8_EPI3_PARTS >= 1 ? 20 : 16) : 16;     // stores per wave and tile (EPI 3: 16 bf16 rows, 8 e4m3 rows, 4 statistics; the
-                                                             // exponent bytes, written by one wave column only, are not counted)
+  // stores per wave and tile.  EPI 3: 16 bf16 rows + 8 e4m3 rows in every wave; the 4 row-statistics stores (one (sum, sum of squares)
+  // per row and 256 columns, reduced over the four wave columns through LDS) and the 4 exponent-byte stores are issued by wave
+  // column 0 alone, so its count is NST + NST_WC0 (the relaxed wait must name the count of THIS wave: one too many lets a DMA piece
+  // of the new tile be read before it has landed)
+  constexpr int NST = EPI == 2 ? 8 : EPI == 3 ? (F8_EPI3_PARTS >= 3 ? 24 : 16) : 16;
+  constexpr int NST_WC0 = (EPI == 3 && F8_EPI3_PARTS >= 2) ? 8 : 0;
 #define VM_RELAX                                                                            \
   do {                                                                                      \
-    const int sel_ = __builtin_amdgcn_readfirstlane(relax > 0 ? 1 : 0);                     \
+    const int sel_ = __builtin_amdgcn_readfirstlane(relax > 0 ? ((NST_WC0 > 0 && wc == 0) ? 2 : 1) : 0);   \
     relax = relax > 0 ? relax - 1 : 0;                                                      \
-    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm8_%=\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lf8end_%=\n"               \
-                 ".Lf8vm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lf8end_%=:" : : "s"(sel_), "n"(8 + NST + CB_PIECES) : "memory", "scc");    \
+    asm volatile("s_cmp_eq_u32 %0, 0\n\ts_cbranch_scc1 .Lf8vm8_%=\n\ts_cmp_eq_u32 %0, 1\n\ts_cbranch_scc1 .Lf8vma_%=\n\t"       \
+                 "s_waitcnt vmcnt(%2)\n\ts_branch .Lf8end_%=\n.Lf8vma_%=:\n\ts_waitcnt vmcnt(%1)\n\ts_branch .Lf8end_%=\n"       \
+                 ".Lf8vm8_%=:\n\ts_waitcnt vmcnt(8)\n.Lf8end_%=:" : : "s"(sel_), "n"(8 + NST + CB_PIECES), "n"(8 + NST + NST_WC0 + CB_PIECES) : "memory", "scc");    \
   } while (0)
   // the column constants (weight scales, biases, EPI 2: inverse output scales) of the tile are staged into the wave's image at
   // the top of the tile (below): those pieces sit between the previous tile's stores and the first waits (the per-row
@@ -582,8 +587,10 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       }
 #undef NL
     }
-    // EPI 3: per 32-row block the row's max |x| over the wave's 64 columns (before the bf16 rounding)
+    // EPI 3: per 32-row block the row's max |x| over the wave's 64 columns (before the bf16 rounding), and the (sum, sum of squares)
+    // of the row's 64 ROUNDED values -- kept until the four wave columns exchange them below
     [[maybe_unused]] float amax[4] = {0.f, 0.f, 0.f, 0.f};
+    [[maybe_unused]] float rs4[4] = {0.f, 0.f, 0.f, 0.f}, rss4[4] = {0.f, 0.f, 0.f, 0.f};
 
     if constexpr (EPI == 2) {
       // fp8 image: [32 rows][80 B pitch] per wave (64 data bytes; the pitch keeps the dword writes 2-way conflicted at most),
@@ -678,11 +685,9 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       }
       if constexpr (EPI == 3) {
         // the other 32 of the wave's 64 columns sit in lane_e ^ 32
-        rs += __shfl_xor(rs, 32);
-        rss += __shfl_xor(rss, 32);
+        rs4[mt] = rs + __shfl_xor(rs, 32);
+        rss4[mt] = rss + __shfl_xor(rss, 32);
         amax[mt] = __builtin_fmaxf(amax[mt], __shfl_xor(amax[mt], 32));
-        const int m = mw0 + mt * 32 + r32e;
-        if (he == 0 && m < p.M) *(float2*)(p.stats_out + ((size_t)((cur.n0 >> 6) + wc) * p.stats_ld + m) * 2) = float2{rs, rss};
       }
       if constexpr (RES) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // fragment reads done before the image is rewritten
 #pragma unroll
@@ -703,11 +708,30 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       // ---- the e4m3 copy of the tile's new rows.  One exponent per (row, this tile's 256 columns): the four waves of a wave
       // row exchange their row maxima through their images ([3584, 4096): untouched by the tile-top DMA of this variant), then
       // x * 2^-e with |x * 2^-e| < 256 goes through the image as e4m3, 64 B per row and wave.
+      // (the row statistics travel with the maxima: [2560, 3584) of the image holds (sum, sum of squares) of the wave's 64 columns
+      //  per row; wave column 0 adds the four in a fixed order and stores ONE pair per row and 256 columns -- a quarter of the
+      //  bytes the consumers' row-constant pass reads, and no partial store per 64 columns)
       if (he == 0) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) *(float*)(tr + 3584 + (mt * 32 + r32e) * 4) = amax[mt];
+        for (int mt = 0; mt < 4; ++mt) {
+          *(float*)(tr + 3584 + (mt * 32 + r32e) * 4) = amax[mt];
+          *(float2*)(tr + 2560 + (mt * 32 + r32e) * 8) = float2{rs4[mt], rss4[mt]};
+        }
       }
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (not __syncthreads: its vmcnt(0) would drain the tile's stores)
+      if (wc == 0 && he == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          float s_ = 0.f, ss_ = 0.f;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float2 t = *(const float2*)(smem + TR_OFF + (wr * 4 + q) * 4096 + 2560 + (mt * 32 + r32e) * 8);
+            s_ += t.x; ss_ += t.y;
+          }
+          const int m = mw0 + mt * 32 + r32e;
+          if (m < p.M) *(float2*)(p.stats_out + ((size_t)(cur.n0 >> 8) * p.stats_ld + m) * 2) = float2{s_, ss_};
+        }
+      }
       float mul[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {

@@ -346,7 +346,7 @@ int clipenc_op_gemm_fp8_lnf(const void* a8_dev, const void* exp_dev, const void*
 /* The residual fp8 GEMM that also quantises what it produces (out-projection / FC2 of the fused tower):
  *   x[m][n] = bf16(x[m][n] + (A8 . W8^T)[m][n] * scale_w[n] + bias[n])   in place, and for the new rows their block-exponent
  *   copy (out8_dev [m][n], exp_dev [m][4]: the fp32 value before the bf16 rounding is what gets quantised) and
- *   stats_dev [n / 64][stats_ld][2]: (sum, sum of squares) of the stored bf16 row over each 64 columns.  N = 256 .. 1024;
+ *   stats_dev [n / 256][stats_ld][2]: (sum, sum of squares) of the stored bf16 row over each 256 columns.  N = 256 .. 1024;
  *   scale_w: powers of two, as for clipenc_op_gemm_fp8_lnf */
 int clipenc_op_gemm_fp8_resid_q(const void* a8_dev, const void* w8_dev, int m, int n, int k, const float* scale_w_dev,
                                 const float* bias_dev, void* x_inout_dev, void* out8_dev, void* exp_dev, float* stats_dev,

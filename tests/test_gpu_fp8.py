@@ -315,7 +315,7 @@ def test_gemm_fp8_resid_q_writes_rows_copy_exponents_and_statistics(gpu, m, n, k
     q = torch.full((m, n), 0x7f, dtype=torch.uint8, device=gpu)
     eb = torch.full((m, 4), 0xff, dtype=torch.uint8, device=gpu)
     ld = (m + 255) // 256 * 256
-    st = torch.full((n // 64, ld, 2), float("nan"), device=gpu)
+    st = torch.full((n // 256, ld, 2), float("nan"), device=gpu)
     dev = [t.to(gpu) for t in (a8, w8, sw, bias)]
     _lib.check(lib.clipenc_op_gemm_fp8_resid_q(dev[0].data_ptr(), dev[1].data_ptr(), m, n, k, dev[2].data_ptr(), dev[3].data_ptr(),
                                                x.data_ptr(), q.data_ptr(), eb.data_ptr(), st.data_ptr(), ld, _stream(gpu)), "resid_q")
@@ -331,7 +331,7 @@ def test_gemm_fp8_resid_q_writes_rows_copy_exponents_and_statistics(gpu, m, n, k
     blockmax = xf.abs().view(m, n // 256, 256).amax(2, keepdim=True).expand(m, n // 256, 256).reshape(m, n).double()
     # e4m3 of the unrounded value: 2^-4 relative (+ the bf16 step between the two), subnormal floor 2^-10 * 2^e <= blockmax 2^-17
     assert ((deq - xf.double()).abs() <= xf.double().abs() * (2.0 ** -4 + 2.0 ** -7) + blockmax * 2.0 ** -16 + 1e-30).all()
-    parts = xf.double().view(m, n // 64, 64)
+    parts = xf.double().view(m, n // 256, 256)
     assert torch.allclose(st.cpu()[:, :m, 0].t().double(), parts.sum(2), rtol=1e-5, atol=1e-4 * xf.abs().max().item())
     assert torch.allclose(st.cpu()[:, :m, 1].t().double(), (parts ** 2).sum(2), rtol=1e-5, atol=1e-30)
 

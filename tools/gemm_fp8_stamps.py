@@ -34,7 +34,7 @@ for name, N, K, kind in SHAPES:
     elif kind == "resid_q":
         out = torch.randn(M, N, device=dev).to(torch.bfloat16)
         q8 = torch.empty(M, N, device=dev, dtype=torch.uint8); eb = torch.empty(M, 4, device=dev, dtype=torch.uint8)
-        stt = torch.empty(N // 64, Mp, 2, device=dev)
+        stt = torch.empty(N // 256, Mp, 2, device=dev)
         run = lambda: lib.clipenc_op_gemm_fp8_resid_q(a.data_ptr(), w.data_ptr(), M, N, K, sw.data_ptr(), bias.data_ptr(), out.data_ptr(),
                                                       q8.data_ptr(), eb.data_ptr(), stt.data_ptr(), Mp, st)
     elif kind == "q":
