@@ -129,6 +129,20 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
   // tile's last two stages), [3584,4096) this tile's exponent dwords (read by every phase)
   constexpr int E_NEXT = 3072, E_CUR = 3584;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // EPI 2 writes e4m3 with a static per-column scale.  v_cvt_pk_fp8_f32 turns a finite value beyond +-448 into NaN by default; with
+  // MODE.FP16_OVFL set it SATURATES to +-448 instead (tools/probes/fp8_ovfl_probe.hip: 470, 1000, 1e9 -> 0x7e; NaN stays NaN,
+  // +-inf -> NaN), which is what the v_med3_f32 in front of every conversion was for -- one VALU instruction per element of an
+  // epilogue that is bound by VALU issue (F8_OVFL_MODE 0: the explicit clamp).  The MODE register is per wave and set up anew for
+  // every launch; nothing else in this kernel converts to a 16-bit float type that the bit would touch.
+#ifndef F8_OVFL_MODE
+#define F8_OVFL_MODE 1
+#endif
+#if F8_OVFL_MODE
+  if constexpr (EPI == 2) asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 23, 1), 1");
+#define F8_SAT(x) (x)
+#else
+#define F8_SAT(x) __builtin_amdgcn_fmed3f((x), -448.0f, 448.0f)
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -620,9 +634,9 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
             if constexpr (ACT == CE_ACT_QUICK_GELU) {
               const float a = acc[mt][nt][g * 4 + e] * sa[mt];
               const float den = __builtin_fmaf(__builtin_amdgcn_exp2f(a), is[e], is[e]);
-              v[e] = __builtin_amdgcn_fmed3f(a * __builtin_amdgcn_rcpf(den), -448.0f, 448.0f);
+              v[e] = F8_SAT(a * __builtin_amdgcn_rcpf(den));
             } else {
-              v[e] = __builtin_amdgcn_fmed3f(act_apply_t<ACT>(acc[mt][nt][g * 4 + e] * sa[mt]) * is[e], -448.0f, 448.0f);
+              v[e] = F8_SAT(act_apply_t<ACT>(acc[mt][nt][g * 4 + e] * sa[mt]) * is[e]);
             }
           }
           int wd = 0;
