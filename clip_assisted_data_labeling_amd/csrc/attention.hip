@@ -1,6 +1,6 @@
 // Multi-head self-attention of the ViT tower (K4 of SURVEY.md §2.2): per (crop, head)
 //   O = softmax(Q K^T / sqrt(64)) V,  no mask, head dim 64; n_tok <= 288 in one pass (attn_kernel),
-//   up to 640 tokens with key chunks + online softmax (attn_long_kernel).
+//   up to 640 tokens with a single pass over the keys (attn_long_kernel).
 // This is the nn.MultiheadAttention step of the open_clip forward the reference reaches through
 // /root/reference/utils/embedder.py:98.
 //
@@ -181,16 +181,26 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__
 
 
 // ---------------------------------------------------------------------------------------------
-// Long-sequence variant (n_tok > 288, e.g. ViT-L-14-336: 577 tokens — the reference's default model,
-// /root/reference/_1_embed_with_CLIP.py:190).  Same LDS images and MFMA orientation; the keys are walked
-// in chunks of CT tiles with an online softmax (running max m, running sum l, O rescaled when m grows),
-// because 19 x 16 score registers no longer fit the register file.  8 waves, one workgroup per CU
-// (K and V of one head take up to 152 KiB of LDS).
+// Long-sequence kernel (289..640 tokens, e.g. ViT-L-14-336: 577 -- the reference's default model,
+// /root/reference/_1_embed_with_CLIP.py:190).  One workgroup of NW waves per (crop, head); K and V of that head take up to 160 KiB of LDS
+// (the same images, fragments and MFMA orientation as attn_kernel); 19 x 16 score registers do not fit the register file, so the keys are
+// walked ONCE and in order with a single-pass softmax: a row's reference m is the maximum of its FIRST key tile, every weight is
+// exp2((s - m) c) -- not <= 1 any more, but bf16 and fp32 have the exponent range -- and only a score more than 64 / c above m (a weight
+// beyond 2^64, looked for among the weights themselves) rescales the row's state to the new maximum: a wave-uniform branch that multiplies in place (through asm "+v": as plain
+// C++ the conditional writes to the accumulators became ~50 register copies per tile) and that ordinary inputs never take.  The softmax
+// is the same function of the scores; sums and O stay in fp32.  (Rounds 1-4 walked the keys in chunks of 7 tiles with a two-pass softmax
+// per chunk and a rescale of O between chunks: 112 score registers, 8 waves.  Round 5, 480 crops x 577 tokens, same box, interleaved:
+// that kernel 1.108-1.146 ms per layer, this one with 8 waves 1.028-1.071, with 12 waves -- three per SIMD, 152 registers -- 0.999-1.035:
+// -10 %; with 16 waves it spills.)  Row sums are fp32 adds of the weights (not an MFMA against ones: two of ten MFMAs per tile); the
+// next block's Q is loaded a block ahead; the K fragments of the next tile are read behind the score MFMAs of this one.
 // ---------------------------------------------------------------------------------------------
-template <int CT>
-__global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                           int n_tok, int width, int heads, float scale_log2e, int nkt,
-                                                           const float* __restrict__ out_inv, int q_blocks) {
+#ifndef LP_THR                   // the weight beyond which a row's state is moved to a new reference (developer builds lower it to force the path)
+#define LP_THR 0x1p64f
+#endif
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void attn_long_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                  int n_tok, int width, int heads, float scale_log2e, int nkt,
+                                                                  const float* __restrict__ out_inv, int q_blocks) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int rows = nkt * 32;
   char* Ks = smem;
@@ -200,19 +210,19 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
   const int crop = blockIdx.x / heads, head = blockIdx.x % heads;
   const size_t ld = (size_t)3 * width;
   const bf16_t* base = qkv + (size_t)crop * n_tok * ld + head * 64;
-
-#ifndef ATTN_LONG_DMA
-#define ATTN_LONG_DMA 1
-#endif
-#if ATTN_LONG_DMA
-  // K and V of the head by LDS-DMA (no VGPR round trip): one instruction = 8 rows x 128 B, lane L fetches source chunk
-  // (L & 7) ^ swizzle(row) of row 8 j + (L >> 3), so the piece lands swizzled; rows beyond n_tok are clamped copies of the last
-  // token (their scores are masked to -inf below, so their weights are exactly 0).  Through registers -- a dependent load -> store
-  // per 16 bytes and thread -- this staging was ~4 us of a 42-us task.
+  const int r = lane & 31, h = lane >> 5;
+  const int n_qb = min((n_tok + 31) >> 5, q_blocks);
+  auto q_load = [&](int qb, bf16x8_t (&qf)[4]) {
+    const bf16_t* qrow = base + (size_t)min(qb * 32 + r, n_tok - 1) * ld;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qrow + st * 16 + h * 8);
+  };
+  bf16x8_t qn[4];
+  if (wave < n_qb) q_load(wave, qn);                             // (in flight beside the K / V pieces)
   {
     const char* tb = (const char*)base;
     const unsigned ldb = (unsigned)(ld * 2);
-    for (int j = wave; j < rows / 8; j += 8) {
+    for (int j = wave; j < rows / 8; j += NW) {
       const int row = 8 * j + (lane >> 3);
       const unsigned rb = (unsigned)min(row, n_tok - 1) * ldb;
       const int ck = (lane & 7) ^ ((row >> 1) & 7);
@@ -224,151 +234,150 @@ __global__ __launch_bounds__(512, 2) void attn_long_kernel(const bf16_t* __restr
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-#else
-  for (int idx = tid; idx < rows * 8; idx += 512) {
-    const int row = idx >> 3, c = idx & 7;
-    uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
-    if (row < n_tok) {
-      const bf16_t* g = base + (size_t)row * ld + c * 8;
-      kv = *(const uint4*)(g + width);
-      vv = *(const uint4*)(g + 2 * width);
-    }
-    *(uint4*)(Ks + k_swz(row, c)) = kv;
-    *(uint4*)(Vs + v_swz(row, c)) = vv;
-  }
-#endif
   __syncthreads();
 
-  const int r = lane & 31, h = lane >> 5;
-  const int n_qb = min((n_tok + 31) >> 5, q_blocks);
-  for (int qb = wave; qb < n_qb; qb += 8) {
-    const int q = qb * 32 + r;
-    const bf16_t* qrow = base + (size_t)min(q, n_tok - 1) * ld;
-    bf16x8_t qf[4];
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // K fragment of key tile c, k step st: row 32 c + r, chunk 2 st + h -- the swizzle term (row >> 1) & 7 does not depend on c
+  const char* kb0 = Ks + k_swz(r, 0 + h); const char* kb1 = Ks + k_swz(r, 2 + h);
+  const char* kb2 = Ks + k_swz(r, 4 + h); const char* kb3 = Ks + k_swz(r, 6 + h);
+  // V^T fragment addresses (attn_stream_kernel): rows 16 j + 4 h + q and + 8 of key step j, a constant 2 KiB per step
+  const int vi = lane & 15, vq = vi >> 2, vp = vi & 3, vg1 = (lane >> 4) & 1;
+  const char* vbase0 = Vs + v_swz(4 * h + vq, (vg1 * 16 + vp * 4) >> 3) + ((vg1 * 16 + vp * 4) & 7) * 2;
+  const char* vbase1 = Vs + v_swz(4 * h + vq, (32 + vg1 * 16 + vp * 4) >> 3) + ((vg1 * 16 + vp * 4) & 7) * 2;
+  auto v_frag = [&](int j, const char* vb) -> bf16x8_t {
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + j * 2048));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + j * 2048 + 1024));
+    s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, vv);
+  };
+  auto row_max = [&](const f32x16_t& s) -> float {              // compiler-visible (hipcc places the MFMA -> VALU wait states); tile 0 and the rare path only
+    float a = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
 #pragma unroll
-    for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qrow + st * 16 + h * 8);
+    for (int e = 4; e < 16; e += 4) a = fmaxf(a, fmaxf(fmaxf(s[e], s[e + 1]), fmaxf(s[e + 2], s[e + 3])));
+    return a;
+  };
+  // largest weight of a tile as an INTEGER maximum of the bit patterns (exp2 results are >= 0 or +inf, where the unsigned order is the float
+  // order): compiler-visible v_max3_u32 -- fmaxf would put a canonicalising v_max in front of every value, and an asm statement on the
+  // v_exp_f32 results would read them without the wait state hipcc places between a transcendental and its first reader
+  auto weight_max_bits = [&](const float (&pv)[16]) -> unsigned {
+    unsigned m = __float_as_uint(pv[0]);
+#pragma unroll
+    for (int j = 1; j < 16; ++j) m = max(m, __float_as_uint(pv[j]));
+    return m;
+  };
+  const bool two_last = (nkt - 1) * 32 + 16 < n_tok;             // the last key tile's second 16-key step holds real keys
 
-    f32x16_t o[2];
+  for (int qb = wave; qb < n_qb; qb += NW) {
+    bf16x8_t qf[4], kf[4], pf[2];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int st = 0; st < 4; ++st) qf[st] = qn[st];
+    if (qb + NW < n_qb) q_load(qb + NW, qn);                     // the next block's queries: in flight for the whole of this block
+    f32x16_t o0 = zero16, o1 = zero16, s;
+    float lsum = 0.f, m_ref = 0.f, moff = 0.f;
+    kf[0] = *(const bf16x8_t*)kb0; kf[1] = *(const bf16x8_t*)kb1; kf[2] = *(const bf16x8_t*)kb2; kf[3] = *(const bf16x8_t*)kb3;
+    for (int c = 0; c < nkt; ++c) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], zero16, 0, 0, 0);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) o[dt][e] = 0.f;
-    float m_run = -INFINITY;
-    f32x16_t lacc;
+      for (int st = 1; st < 4; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s, 0, 0, 0);
+      // behind the MFMAs: V^T of this tile, K of the next one (past the end: a re-read of the last tile)
+      const bf16x8_t va0 = v_frag(2 * c, vbase0), vb0 = v_frag(2 * c, vbase1);
+      const bf16x8_t va1 = v_frag(2 * c + 1, vbase0), vb1 = v_frag(2 * c + 1, vbase1);
+      {
+        const int ko = min(c + 1, nkt - 1) * 4096;
+        kf[0] = *(const bf16x8_t*)(kb0 + ko); kf[1] = *(const bf16x8_t*)(kb1 + ko);
+        kf[2] = *(const bf16x8_t*)(kb2 + ko); kf[3] = *(const bf16x8_t*)(kb3 + ko);
+      }
+      if (c == nkt - 1) {                                        // the last key tile may be partial
 #pragma unroll
-    for (int e = 0; e < 16; ++e) lacc[e] = 0.f;
-    const u32x4_t ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};      // eight bf16 1.0
-    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_w);
-
-    for (int kt0 = 0; kt0 < nkt; kt0 += CT) {
-      // ---- scores of this chunk ----
-      f32x16_t s[CT];
-#pragma unroll
-      for (int c = 0; c < CT; ++c) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) s[c][e] = -INFINITY;
-        if (kt0 + c < nkt) {                                  // wave-uniform
-#pragma unroll
-          for (int e = 0; e < 16; ++e) s[c][e] = 0.f;
-#pragma unroll
-          for (int st = 0; st < 4; ++st) {
-            bf16x8_t kf = *(const bf16x8_t*)(Ks + k_swz((kt0 + c) * 32 + r, st * 2 + h));
-            s[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[c], 0, 0, 0);
-          }
-          if (kt0 + c == nkt - 1) {                           // the last key tile may be partial
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int key = (kt0 + c) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-              if (key >= n_tok) s[c][e] = -INFINITY;
-            }
-          }
+        for (int e = 0; e < 16; ++e) {
+          const int key = c * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= n_tok) s[e] = -INFINITY;
         }
       }
-      float mx = m_run;
+      if (c == 0) {
+        m_ref = row_max(s);                                      // tile 0 holds 32 real keys (n_tok > 288)
+        m_ref = fmaxf(m_ref, __shfl_xor(m_ref, 32));
+        moff = m_ref * scale_log2e;
+      }
+      float pv[16];
 #pragma unroll
-      for (int c = 0; c < CT; ++c)
+      for (int j = 0; j < 16; ++j) pv[j] = __builtin_amdgcn_exp2f(fmaf(s[j], scale_log2e, -moff));
+      // The overflow guard looks at the WEIGHTS (VALU results; an asm statement on the score registers themselves would read them
+      // without the wait states hipcc inserts between an MFMA and the first compiler-visible reader of its result).
+      if (c > 0 && __builtin_amdgcn_ballot_w64(weight_max_bits(pv) > __float_as_uint(LP_THR)) != 0ull) {
+        // (rare) a score of this tile towers over the reference: move the row's state to the new maximum, in place, and take this
+        // tile's weights again.  Every weight at the old reference has been multiplied into o / lsum already.
+        float mx = row_max(s);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_ref, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_ref - m_new) * scale_log2e);
+        // (in place through asm; the s_nop: alpha comes out of v_exp_f32, and hipcc does not place the transcendental -> VALU wait
+        //  state in front of an asm statement -- without it the first product read a stale alpha in some lanes)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) mx = fmaxf(mx, s[c][e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));                     // finite: every chunk holds >= 1 valid key
-      const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * scale_log2e);   // 0 on the first chunk
-      m_run = mx;
-      const float moff = mx * scale_log2e;
-      lacc[0] *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) o[dt][e] *= alpha;
-
-      // ---- P of this chunk and O^T += V^T . P^T ----
-#pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        if (kt0 + c < nkt) {
-#pragma unroll
-          for (int s2 = 0; s2 < 2; ++s2) {
-            if (kt0 + c < nkt - 1 || s2 == 0 || (kt0 + c) * 32 + 16 < n_tok) {
-              float pv[8];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(fmaf(s[c][s2 * 8 + j], scale_log2e, -moff));
-              const u32x4_t pw = {cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]), cvt_pk_bf16(pv[6], pv[7])};
-              const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
-              lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);   // row sums of the rounded weights
-              const int key0 = (kt0 + c) * 32 + s2 * 16 + 4 * h;
-#pragma unroll
-              for (int dt = 0; dt < 2; ++dt) {
-                const int i = lane & 15, qq = i >> 2, pp = i & 3, g1 = (lane >> 4) & 1;
-                const int dcol = dt * 32 + g1 * 16 + pp * 4;
-                const int ra = key0 + qq, rb = key0 + 8 + qq;
-                s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(ra, dcol >> 3) + (dcol & 7) * 2));
-                s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (__attribute__((address_space(3))) s16x4_t*)(Vs + v_swz(rb, dcol >> 3) + (dcol & 7) * 2));
-                typedef __attribute__((ext_vector_type(8))) short s16x8_t;
-                s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, o[dt], 0, 0, 0);
-              }
-            }
-          }
+        for (int e = 0; e < 16; ++e) {
+          asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %0" : "+v"(o0[e]) : "v"(alpha));
+          asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %0" : "+v"(o1[e]) : "v"(alpha));
         }
-        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %0" : "+v"(lsum) : "v"(alpha));
+        m_ref = m_new;
+        moff = m_ref * scale_log2e;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) pv[j] = __builtin_amdgcn_exp2f(fmaf(s[j], scale_log2e, -moff));
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) lsum += pv[j];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const u32x4_t pw = {cvt_pk_bf16(pv[s2 * 8 + 0], pv[s2 * 8 + 1]), cvt_pk_bf16(pv[s2 * 8 + 2], pv[s2 * 8 + 3]),
+                            cvt_pk_bf16(pv[s2 * 8 + 4], pv[s2 * 8 + 5]), cvt_pk_bf16(pv[s2 * 8 + 6], pv[s2 * 8 + 7])};
+        pf[s2] = __builtin_bit_cast(bf16x8_t, pw);
+      }
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, pf[0], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb0, pf[0], o1, 0, 0, 0);
+      if (c < nkt - 1 || two_last) {
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, pf[1], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb1, pf[1], o1, 0, 0, 0);
       }
     }
-    const float inv = 1.0f / lacc[0];
+    lsum += __shfl_xor(lsum, 32);                                // the row's other 16 keys of every tile sit in lane ^ 32
+    const float inv = __builtin_amdgcn_rcpf(lsum);
+    const int q = qb * 32 + r;
     if (q < n_tok && out_inv) {
       uint8_t* orow = (uint8_t*)out + ((size_t)crop * n_tok + q) * width + head * 64;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const int col = dt * 32 + g4 * 8 + h * 4;
-          const f32x4_t is = *(const f32x4_t*)(out_inv + head * 64 + col);
-          *(int*)(orow + col) = pack_fp8x4(o[dt][g4 * 4 + 0] * inv * is[0], o[dt][g4 * 4 + 1] * inv * is[1],
-                                           o[dt][g4 * 4 + 2] * inv * is[2], o[dt][g4 * 4 + 3] * inv * is[3]);
-        }
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int col = g4 * 8 + h * 4;
+        const f32x4_t is0 = *(const f32x4_t*)(out_inv + head * 64 + col), is1 = *(const f32x4_t*)(out_inv + head * 64 + 32 + col);
+        *(int*)(orow + col) = pack_fp8x4(o0[g4 * 4 + 0] * inv * is0[0], o0[g4 * 4 + 1] * inv * is0[1],
+                                         o0[g4 * 4 + 2] * inv * is0[2], o0[g4 * 4 + 3] * inv * is0[3]);
+        *(int*)(orow + 32 + col) = pack_fp8x4(o1[g4 * 4 + 0] * inv * is1[0], o1[g4 * 4 + 1] * inv * is1[1],
+                                              o1[g4 * 4 + 2] * inv * is1[2], o1[g4 * 4 + 3] * inv * is1[3]);
+      }
     } else if (q < n_tok) {
       bf16_t* orow = out + ((size_t)crop * n_tok + q) * width + head * 64;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          uint2 pk = {pack_bf16x2(o[dt][g4 * 4 + 0] * inv, o[dt][g4 * 4 + 1] * inv),
-                      pack_bf16x2(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv)};
-          *(uint2*)(orow + dt * 32 + g4 * 8 + h * 4) = pk;
-        }
+      for (int g4 = 0; g4 < 4; ++g4) {
+        *(uint2*)(orow + g4 * 8 + h * 4) = uint2{pack_bf16x2(o0[g4 * 4 + 0] * inv, o0[g4 * 4 + 1] * inv),
+                                                 pack_bf16x2(o0[g4 * 4 + 2] * inv, o0[g4 * 4 + 3] * inv)};
+        *(uint2*)(orow + 32 + g4 * 8 + h * 4) = uint2{pack_bf16x2(o1[g4 * 4 + 0] * inv, o1[g4 * 4 + 1] * inv),
+                                                      pack_bf16x2(o1[g4 * 4 + 2] * inv, o1[g4 * 4 + 3] * inv)};
+      }
     }
   }
 }
 
 hipError_t launch_attn_long(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
                             const float* out_inv, int q_blocks, hipStream_t stream) {
-  constexpr int CT = 7;
+  constexpr int NW = 12;                                         // three waves per SIMD
   const int nkt = (n_tok + 31) / 32;
   const int lds = nkt * 32 * 128 * 2;
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  hipError_t e = hipFuncSetAttribute((const void*)attn_long_kernel<CT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return e;
+  if (lds > 160 * 1024 || n_tok <= 288) return hipErrorInvalidValue;   // (tile 0 must hold 32 real keys; shorter sequences have their own kernels)
+  static DeviceKernelSetup setup;                                // per device: LDS opt-in (common.h)
+  if (hipError_t e = setup.ensure((const void*)attn_long_kernel<NW>, 160 * 1024, nullptr); e != hipSuccess) return e;
   const float scale_log2e = 0.125f * 1.44269504088896340736f;
-  hipLaunchKernelGGL((attn_long_kernel<CT>), dim3(n_crops * heads), dim3(512), lds, stream, qkv, out, n_tok, width,
-                     heads, scale_log2e, nkt, out_inv, q_blocks);
+  hipLaunchKernelGGL((attn_long_kernel<NW>), dim3(n_crops * heads), dim3(NW * 64), lds, stream, qkv, out, n_tok, width, heads,
+                     scale_log2e, nkt, out_inv, q_blocks);
   return hipGetLastError();
 }
 

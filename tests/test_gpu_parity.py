@@ -174,6 +174,52 @@ def test_attention_streaming_kernel_takes_the_maximum_only_where_it_must(gpu, ca
     assert one_minus_cos(got, ref).max().item() < 3e-4
 
 
+@pytest.mark.parametrize("case", ["small", "large", "very_negative", "rising", "dominant_key_tile0", "dominant_key_late", "dominant_key_last",
+                                  "dominant_then_larger"])
+@pytest.mark.parametrize("n_tok", [577, 640])
+def test_long_attention_single_pass_softmax_rescales_where_it_must(gpu, case, n_tok):
+    """The long kernel (289..640 tokens) walks the keys once: a row's reference is the maximum of its FIRST 32 keys and the row's state
+    is rescaled only when a later score exceeds it by more than 64 / c (attention.hip).  Cases that never take the branch (small), that
+    take it in most rows (large: logits ~ N(0, 25^2) nats), whose scores all lie far below zero, whose maximum rises tile after tile by
+    ~60 nats (a rescale at nearly every tile), and one key that dominates every row by thousands of nats -- among the first 32 keys (every
+    other weight underflows to 0), in the middle, as the very last key of the partial tile, and twice (a second, larger one later)."""
+    lib = _lib.load()
+    n_crops, heads = 3, 4
+    width = heads * 64
+    g = torch.Generator().manual_seed(13)
+    qkv = torch.randn(n_crops * n_tok, 3 * width, generator=g)
+    q, k = qkv[:, :width], qkv[:, width:2 * width]
+    if case == "small":
+        q *= 0.5
+    elif case == "large":
+        q *= 5.0; k *= 5.0
+    elif case == "very_negative":
+        q.mul_(0.3).add_(5.0); k.mul_(0.3).sub_(5.0)
+    elif case == "rising":
+        q.mul_(0.05).add_(1.0)                                  # q ~ 1: the logit of key j is ~ sum(k_j) / 8
+        tile = (torch.arange(n_crops * n_tok) % n_tok) // 32
+        k.mul_(0.05).add_((tile.float() * 7.5).view(-1, 1))     # + 7.5 per tile and channel: + 60 nats per tile
+    else:
+        q.fill_(30.0); k.zero_()
+        pos = {"dominant_key_tile0": [7], "dominant_key_late": [300], "dominant_key_last": [n_tok - 1], "dominant_then_larger": [40, 500]}[case]
+        for i, p_ in enumerate(pos):
+            k[p_::n_tok] = 30.0 * (i + 1)                       # logit 7200 (and 14400 for the second one)
+    qkv = qkv.to(torch.bfloat16)
+    out = torch.full((n_crops * n_tok, width), float("nan"), dtype=torch.bfloat16, device=gpu)
+    _lib.check(lib.clipenc_op_attention(qkv.to(gpu).data_ptr(), out.data_ptr(), n_crops, n_tok, width, heads, _stream(gpu)), "attention")
+    torch.cuda.synchronize()
+    qf, kf, vf = qkv.float().view(n_crops, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = torch.softmax((qf.double() @ kf.double().transpose(-1, -2)) * 0.125, -1).float() @ vf
+    ref = ref.permute(0, 2, 1, 3).reshape(n_crops * n_tok, width)
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max().item() < 0.04, (got - ref).abs().max().item()
+    assert one_minus_cos(got, ref).max().item() < 3e-4
+    again = torch.empty_like(out)
+    _lib.check(lib.clipenc_op_attention(qkv.to(gpu).data_ptr(), again.data_ptr(), n_crops, n_tok, width, heads, _stream(gpu)), "attention")
+    assert torch.equal(out, again)
+
+
 def test_attention_large_logits_do_not_overflow(gpu):
     # one key dominates every row: exercises the true-max subtraction
     lib = _lib.load()

@@ -1,7 +1,7 @@
 """ViT-L-14-336 at FULL size (1024 wide x 24 blocks x 577 tokens): the reference's DEFAULT model
 (/root/reference/_1_embed_with_CLIP.py:190) and the tower its only shipped checkpoint was trained on
 (`clip_models=['ViT-L-14-336/openai']`, so `AestheticRegressor`, /root/reference/utils/embedder.py:277-311, runs THIS tower).
-577 tokens take the online-softmax attention kernel (attn_long_kernel) and a different tile count in every GEMM, so the
+577 tokens take the single-pass long attention kernel (attn_long_kernel) and a different tile count in every GEMM, so the
 2-layer `ViT-long-test` of test_gpu_parity.py does not stand in for it.
 
 Tolerances: north_star -- embeddings 1 - cos < 1e-3 against the fp32 CPU oracle, scores within 1e-4 abs."""
