@@ -388,7 +388,11 @@ class Feature_Dataset:
                                 if dev_files:
                                     scale = self.decode_chunk / len(dev_files)
                                     px = min(self.gpu_decode_max_pixels, int(sum(w[1][1] for w in dev_files) * scale * 1.1))
-                                    if not self.jpeg.reserve(px, int(sum(len(w[1][0]) for w in dev_files) * scale * 1.1)):
+                                    # bytes per pixel from the files' own sampling factors (the largest of the window: a 4:2:0 set reserves
+                                    # 4.5, one 4:4:4 file makes it 9 -- a 9 GB arena where 4.6 GB do costs ~0.3 s of start-up in hipMalloc)
+                                    from .jpeg_gpu import scratch_bytes_per_pixel
+                                    bpp = max(scratch_bytes_per_pixel(w[1][0]) for w in dev_files[:64])
+                                    if not self.jpeg.reserve(px, int(sum(len(w[1][0]) for w in dev_files) * scale * 1.1), bytes_per_pixel=bpp):
                                         print(f"Warning: no device memory for the JPEG decoder's scratch ({px / 1e6:.0f} Mpx per chunk); "
                                               "groups it cannot hold are decoded by Pillow on the host (slow)")
                             for _ in range(take):

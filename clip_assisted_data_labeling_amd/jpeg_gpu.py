@@ -17,6 +17,37 @@ import torch
 from . import _lib
 
 
+def scratch_bytes_per_pixel(data: bytes) -> float:
+    """Device scratch one decoded pixel of this file needs -- int16 coefficients + one sample byte per component sample:
+    3 x sum_c(h_c v_c) / (h_max v_max) -- from the frame header's sampling factors (host only, a few hundred bytes walked):
+    4:2:0 -> 4.5, 4:2:2 -> 6, 4:4:4 -> 9, grey -> 3.  9.0 when the header cannot be read."""
+    try:
+        i, n = 2, len(data)
+        while i + 4 <= n:
+            if data[i] != 0xFF:
+                i += 1
+                continue
+            m = data[i + 1]
+            if m == 0xFF:                                           # fill byte
+                i += 1
+                continue
+            if m == 0xD8 or m == 0x01 or 0xD0 <= m <= 0xD7:          # markers without a length
+                i += 2
+                continue
+            seg = (data[i + 2] << 8) | data[i + 3]
+            if m in (0xC0, 0xC1, 0xC2):
+                nc = data[i + 9]
+                hv = [(data[i + 11 + 3 * c] >> 4, data[i + 11 + 3 * c] & 15) for c in range(nc)]
+                hmax, vmax = max(h for h, _ in hv), max(v for _, v in hv)
+                return 3.0 * sum(h * v for h, v in hv) / float(hmax * vmax)
+            if m == 0xDA or m == 0xD9:
+                break
+            i += 2 + seg
+    except Exception:
+        pass
+    return 9.0
+
+
 class GpuJpegDecoder:
     def __init__(self, device="cuda"):
         self.lib = _lib.load()
@@ -43,14 +74,14 @@ class GpuJpegDecoder:
 
     NO_MEMORY = 77            # CLIPENC_JPEGDEC_NO_MEMORY (include/clipenc.h); as a per-file status: "decode it yourself"
 
-    def reserve(self, pixels: int, file_bytes: int, staging: bool = False) -> bool:
-        """Sets aside device scratch for batches of up to `pixels` decoded pixels from `file_bytes` of files (9 bytes per
-        pixel + the files' bytes: int16 coefficients + sample planes of an un-subsampled 4:4:4 file, the worst case -- 4:2:0
-        files need half of it, but an arena sized for them regrows in the middle of a run when 4:4:4 files arrive, and hipFree +
-        hipMalloc synchronise the device) and, with staging=True, the page-locked staging buffer (the files' bytes; page-locking takes
+    def reserve(self, pixels: int, file_bytes: int, staging: bool = False, bytes_per_pixel: float = 9.0) -> bool:
+        """Sets aside device scratch for batches of up to `pixels` decoded pixels from `file_bytes` of files (`bytes_per_pixel`
+        per pixel + the files' bytes: int16 coefficients + sample planes; `scratch_bytes_per_pixel(file)` gives a file's own figure
+        from its sampling factors -- 4.5 for 4:2:0, 9 for 4:4:4, the default: an arena sized short regrows in the middle of a run,
+        and hipFree + hipMalloc synchronise the device) and, with staging=True, the page-locked staging buffer (the files' bytes; page-locking takes
         ~0.2 s per GB, so by default it grows with the batches instead).  Call it before other work runs on the device: growing
         the device scratch later (hipFree + hipMalloc) synchronises the device.  False when the memory is not there."""
-        rc = self.lib.jpegdec_reserve(self.handle, int(pixels * 9) + int(file_bytes * 1.25) + (1 << 20),
+        rc = self.lib.jpegdec_reserve(self.handle, int(pixels * max(3.0, min(9.0, float(bytes_per_pixel)))) + int(file_bytes * 1.25) + (1 << 20),
                                       int(file_bytes * 1.25) + (1 << 20) if staging else 0)
         if rc == self.NO_MEMORY:
             return False

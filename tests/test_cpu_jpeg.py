@@ -347,3 +347,21 @@ def test_header_claiming_a_huge_image_is_refused():
     assert jpeg_oracle.info(bytes(data))[0] == 10
     data[i + 5:i + 9] = bytes([0x30, 0x00, 0x30, 0x00])            # 12288 x 12288 = 151 M pixels: parsed (and then found truncated)
     assert jpeg_oracle.info(bytes(data))[0] == 0
+
+
+def test_scratch_bytes_per_pixel_follows_the_sampling_factors():
+    """What the embed driver reserves the device decoder's scratch by (jpeg_gpu.scratch_bytes_per_pixel): int16 coefficients + sample
+    planes per decoded pixel, from the frame header alone."""
+    import io
+    import numpy as np
+    from PIL import Image
+    from clip_assisted_data_labeling_amd.jpeg_gpu import scratch_bytes_per_pixel
+    im = Image.fromarray(np.random.RandomState(0).randint(0, 256, (64, 80, 3), dtype=np.uint8))
+    for subsampling, want in ((2, 4.5), (1, 6.0), (0, 9.0)):
+        b = io.BytesIO(); im.save(b, "JPEG", quality=90, subsampling=subsampling)
+        assert scratch_bytes_per_pixel(b.getvalue()) == want
+    b = io.BytesIO(); im.convert("L").save(b, "JPEG")
+    assert scratch_bytes_per_pixel(b.getvalue()) == 3.0
+    b = io.BytesIO(); im.save(b, "JPEG", progressive=True)
+    assert scratch_bytes_per_pixel(b.getvalue()) == 4.5
+    assert scratch_bytes_per_pixel(b"not a jpeg") == 9.0 and scratch_bytes_per_pixel(b"") == 9.0
