@@ -10,7 +10,9 @@ Parity pinning: the reference holds no test, golden vector or fixture for this b
 ("parity unpinned" at the open_clip call). The restatement is instead pinned against an
 independent implementation of the same tower, `transformers.CLIPVisionModelWithProjection`
 (tests/golden/make_golden.py asserts max-abs < 1e-5 on seeded weights through the key mapping of
-SURVEY.md Appendix A.3), and the resulting vectors are committed under tests/golden/.
+SURVEY.md Appendix A.3), and the resulting vectors are committed under tests/golden/ -- since round 5
+also at FULL size (ViT-L-14 and ViT-L-14-336: 1024 wide x 24 blocks x 257 / 577 tokens, measured
+8.2e-8), with the transformers embeddings stored next to this restatement's (`emb_transformers`).
 """
 from __future__ import annotations
 
