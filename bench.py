@@ -329,7 +329,8 @@ def cpu_baseline(cfg, sd, Ws, bs):
     med = float(np.median(times))
     out = {"value": round(n_img / med, 4), "unit": "images/s", "cores": cores, "kind": "port",
            "sample": f"median of 3 x {n_img} images x 4 crops ({n_img * 4} crops) after 1 warm-up, fp32 torch CPU restatement "
-                     f"(oracle/), {sum(times):.1f} s; reps {[round(t, 2) for t in times]} s",
+                     f"(oracle/), {sum(times):.1f} s; reps {[round(t, 2) for t in times]} s"
+                     + ("" if n_img == 32 else f" (BASELINE.md section 4 plans 32 images: halved until one repetition fits 20 s on this box's {cores} threads)"),
            "cpu_model": info["model"], "physical_cores": info["physical_cores"], "logical_cores": info["logical_cores"],
            "usable_cpus": info["usable_cpus"], "cgroup_cpus": info["cgroup_cpus"], "threads": cores,
            "threads_tried": cand}
@@ -342,7 +343,9 @@ def cpu_baseline(cfg, sd, Ws, bs):
     vit_oracle.encode_image(sd_b, cfg_b, crops_b)
     tb = time.perf_counter() - t0
     out["vit_b32_cfg0"] = {"images_per_s": round(64 / tb, 3), "seconds": round(tb, 2),
-                           "sample": "BASELINE.json configs[0]: ViT-B/32, 64 images x 4 crops, one pass, same threads"}
+                           "sample": "BASELINE.json configs[0]: ViT-B/32, 64 images x 4 crops, one pass, same threads; the crops are uint8-valued noise "
+                                     "pixels of the final 224 x 224 shape through the CLIP normalisation (the encoder's cost does not depend on pixel values; the "
+                                     "reference's crop geometry + bicubic resize in front of it is not part of this number)"}
     return out
 
 
@@ -363,37 +366,48 @@ def kernel_source_sha(kernel_name):
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_name):
-    """L2-miss (HBM-side) bytes per launch of `kernel_name` from the newest committed rocprofv3 PMC passes that contain it
-    (profiles/*/pmc_hbm_traffic_per_kernel.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction, written by
-    tools/summarize_profiles.py together with the sha of the kernel's sources).  None when no profile has been committed,
-    or when the profile PREDATES the kernel (its recorded source sha differs from today's sources): a stale number is not
-    quoted."""
+LEGACY_PROBLEM = "rows=526336,width=1024,mlp=4096"   # what every profile directory without `_meta.problem` was taken on (ViT-L/14, 2 048 crops)
+
+
+def problem_key(cfg, crops):
+    """The problem a kernel's traffic constant belongs to: token rows of the batch and the tower's GEMM widths (M, N, K of every block
+    GEMM follow from them).  A constant taken on another problem is not quoted."""
+    return f"rows={crops * cfg.tokens},width={cfg.width},mlp={cfg.mlp_dim}"
+
+
+def pmc_traffic(kernel_name, problem=LEGACY_PROBLEM):
+    """L2-miss (HBM-side) bytes per launch of `kernel_name` ON `problem` from the newest committed rocprofv3 PMC passes that contain
+    both (profiles/*/pmc_hbm_traffic_per_kernel.json: separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 read correction, written by
+    tools/summarize_profiles.py together with the sha of the kernel's sources and the problem of the profiled run).  None when no
+    such profile has been committed, or when the profile PREDATES the kernel (its recorded source sha differs from today's sources):
+    a stale number, or one of another problem shape, is not quoted."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_traffic_per_kernel.json")))
-    for path in reversed(files):                      # newest round first; bf16 and fp8 runs are summarised separately
+    for path in reversed(files):                      # newest round first; bf16 / fp8 / 336-px runs are summarised separately
         try:
             doc = json.load(open(path))
         except Exception:
             continue
+        if doc.get("_meta", {}).get("problem", LEGACY_PROBLEM) != problem:
+            continue                                  # another batch or another tower: its bytes per launch describe other launches
         base = kernel_name[kernel_name.index("(") + 1:-1] if kernel_name.startswith("shape:") else kernel_name
         for k, v in doc.items():
             if k != "_meta" and (k == kernel_name if kernel_name.startswith("shape:") else (kernel_name in k and not k.startswith("shape:"))):
                 recorded = doc.get("_meta", {}).get("source_sha", {}).get(base)
                 if recorded != kernel_source_sha(base):
                     return None                       # taken with other sources (or before shas were recorded)
-                PMC_SOURCE[kernel_name] = os.path.relpath(os.path.dirname(path), ROOT)
+                PMC_SOURCE[(kernel_name, problem)] = os.path.relpath(os.path.dirname(path), ROOT)
                 return round(float(v.get("bytes_per_launch", v.get("hbm_bytes", 0.0))), 1)
     return None
 
 
-PMC_SOURCE = {}       # kernel name -> the profiles/ directory its committed traffic constant was read from (pmc_traffic)
+PMC_SOURCE = {}       # (kernel name, problem) -> the profiles/ directory its committed traffic constant was read from (pmc_traffic)
 
 
-def traffic_source(kernel_name):
+def traffic_source(kernel_name, problem=LEGACY_PROBLEM):
     """Where `traffic` of a kernel comes from: a COMMITTED rocprofv3 PMC summary (another box, another run -- PMC passes cannot run
     inside the bench), named so that the line says so itself."""
-    return PMC_SOURCE.get(kernel_name)
+    return PMC_SOURCE.get((kernel_name, problem))
 
 
 def algorithmic_bytes_per_step(cfg, crops):
@@ -417,6 +431,7 @@ def per_kernel_table(prof, prof_steps, cfg, crops, fp8=False):
     """roofline.per_kernel: for QKV / attention / out-proj / FC1 / FC2 the launches of the profiled pass priced against the dense MFMA
     peak of their arithmetic type, and the committed L2-miss traffic of that kernel over its algorithmic bytes."""
     names = list(prof)
+    problem = problem_key(cfg, crops)
 
     def find(*subs, shape=None):
         for k in names:
@@ -427,7 +442,8 @@ def per_kernel_table(prof, prof_steps, cfg, crops, fp8=False):
                 return k
         return None
     rows = {"qkv": find("gemm_fp8_kernel<0") if fp8 else find("gemm_persist_kernel<2, -1>"),
-            "attention": find("attn_stream") or find("attn_long") or find("attn_kernel"),   # (not cls_attn_kernel: its own kind)
+            # (names that START with attn_: `"attn_kernel" in "cls_attn_kernel"` -- the class-token kernel is its own kind)
+            "attention": next((k for k in names if k.startswith("attn_") and prof[k][1] > 0), None),
             "out_proj": find(shape="out_proj"), "fc2": find(shape="fc2"),
             "fc1": (find("gemm_fp8_kernel<2") if fp8 else (find("gemm_persist_kernel<2, 0>") or find("gemm_persist_kernel<2, 1>")))}
     alg = algorithmic_bytes_per_step(cfg, crops)
@@ -440,10 +456,10 @@ def per_kernel_table(prof, prof_steps, cfg, crops, fp8=False):
         tf = fl / (ms * 1e-3) / 1e12
         launches = n / prof_steps
         alg_b = alg[key] / launches
-        tr = pmc_traffic(k)
+        tr = pmc_traffic(k, problem)
         out[key] = {"kernel": k.replace("shape:", ""), "ms_per_step": round(ms / prof_steps, 3), "launches_per_step": round(launches, 2),
                     "tflops": round(tf, 1), "peak": peak, "frac": round(tf / peak, 4),
-                    "algorithmic_bytes_per_launch": round(alg_b, 1), "traffic": tr, "traffic_source": traffic_source(k),
+                    "algorithmic_bytes_per_launch": round(alg_b, 1), "traffic": tr, "traffic_source": traffic_source(k, problem),
                     "traffic_ratio": round(tr / alg_b, 3) if tr else None}
     return out
 
@@ -728,6 +744,9 @@ def main():
                     help="BASELINE.json configs[3]: run a whole N-image job (sharded over the ranks, crops generated on the device "
                          "per batch, one gather at the end) instead of the resident-batch step loop; use with --dtype fp8")
     ap.add_argument("--job-seed", type=int, default=20240, help="base seed of the job's per-rank counter-based generators")
+    ap.add_argument("--model", default=MODEL, choices=["ViT-L-14", "ViT-L-14-336"],
+                    help="the tower of the timed step: ViT-L-14 = the headline (BASELINE.json metric); ViT-L-14-336 = the reference's default "
+                         "model as the PRIMARY workload (tools/profile_round.sh takes its rocprofv3 passes this way; secondary block skipped)")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
                     help="arithmetic of the block GEMMs: bf16 = the headline (configs[1]+[2]); fp8 = configs[3] (e4m3 MFMA)")
     args = ap.parse_args()
@@ -761,7 +780,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    cfg = vit_config.ARCHS[MODEL]
+    cfg = vit_config.ARCHS[args.model]
+    headline = args.model == MODEL
     sd = vit_config.seeded_state_dict(cfg, 0)               # random-init weights of the named architecture
     Ws, bs = fc_weights(1)
     vit = HipViT(cfg, sd, dev, chunk_crops=args.chunk or None, precision=args.dtype)
@@ -865,8 +885,11 @@ def main():
         workload = ("BASELINE.json configs[3] on one GPU's shard: ViT-L/14 @224 encode with e4m3 MFMA block GEMMs "
                     "(per-token x per-channel scales), bf16 attention/residual" if fp8 else
                     "BASELINE.json configs[1]+[2]: ViT-L/14 @224 bf16 encode")
+        if not headline:
+            workload = f"NOT the headline: {args.model} ({cfg.tokens} tokens, the reference's default model) {args.dtype} encode"
+        problem = problem_key(cfg, n_img * CROPS_PER_IMAGE)
         line = {
-            "metric": "images/sec (4 crops each) ViT-L/14 encode+score @ bs512",
+            "metric": "images/sec (4 crops each) ViT-L/14 encode+score @ bs512" if headline else f"images/sec (4 crops each) {args.model} encode+score @ bs{n_img}",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
@@ -877,7 +900,7 @@ def main():
             "config": {"workload": f"{workload} of {n_img} images x 4 crops per GPU "
                                    "+ fused fp32 regressor 3072-264-128-64-1, seeded random-init weights, crops resident in HBM",
                        "images_per_gpu": n_img, "crops_per_image": CROPS_PER_IMAGE, "parallelism": f"image-sharded x{world}",
-                       "chunk_crops": args.chunk or 2048},
+                       "chunk_crops": args.chunk or n_img * CROPS_PER_IMAGE, "problem": problem},
             "end_to_end": {"tflops": round(value * flop_per_image / 1e12, 1),
                            "frac_of_bf16_peak": round(value * flop_per_image / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
                            # the LAST block's Q / attention / out-proj / MLP run on the class-token row only
@@ -886,10 +909,10 @@ def main():
                            "frac_executed": round(value * flop_exec_per_image / 1e12 / (PEAK_BF16_TFLOPS * world), 4),
                            "flop_per_image": flop_per_image, "flop_per_image_executed": flop_exec_per_image},
             "roofline": {"bound": "mfma", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": d_peak,
-                         "unit": "TFLOP/s", "frac": round(achieved / d_peak, 4), "traffic": pmc_traffic(DOMINANT),
+                         "unit": "TFLOP/s", "frac": round(achieved / d_peak, 4), "traffic": pmc_traffic(DOMINANT, problem),
                          # `traffic` is a COMMITTED constant (rocprofv3 PMC passes of the named directory: another run, possibly
                          # another box), guarded by the sha of the kernel's sources -- not a measurement of this run
-                         "traffic_source": traffic_source(DOMINANT),
+                         "traffic_source": traffic_source(DOMINANT, problem),
                          "launches": d_n, "avg_launch_ms": round(d_ms / max(d_n, 1), 4),
                          "algorithmic_flop_per_launch": d_fl / max(d_n, 1),
                          # the same achieved rate priced against the peak at the clock the board actually held:
@@ -921,7 +944,7 @@ def main():
             line["roofline"]["frac_of_power_capped_stream"] = ceil["frac"]
             line["end_to_end"]["frac_of_power_capped_stream"] = (round(value * flop_per_image / 1e12 / ceil["value"], 4)
                                                                   if ceil["value"] else None)
-        if world == 1 and not args.no_secondary and not fp8:
+        if world == 1 and not args.no_secondary and not fp8 and headline:
             want = set(args.secondary.split(","))
             sec = {}
             if "fp8" in want:
@@ -940,7 +963,12 @@ def main():
                 except Exception as exc:                               # host-side (loader workers, /tmp): never lose the line to it
                     sec["embed_e2e"] = {"error": f"{type(exc).__name__}: {exc}"}
             line["secondary"] = sec
-        if world == 1 and not args.no_cpu_baseline:
+            # the secondary rates once more at the HEAD of the line (a truncated tail still carries them)
+            head = {k: line[k] for k in ("metric", "value", "unit")}
+            head["secondary_head"] = {k: v.get("value") for k, v in sec.items() if isinstance(v, dict) and "value" in v}
+            head.update(line)
+            line = head
+        if world == 1 and not args.no_cpu_baseline and headline:
             line["cpu_baseline"] = cpu_baseline(cfg, sd, Ws, bs)
         print(json.dumps(line), flush=True)
     if use_dist:

@@ -46,7 +46,6 @@ SIGNATURES = {
     "clipenc_create": (c_int, [POINTER(clipenc_config), POINTER(clipenc_weights), c_int, POINTER(c_void_p)]),
     "clipenc_destroy": (c_int, [c_void_p]),
     "clipenc_set_chunk": (c_int, [c_void_p, c_int]),
-    "clipenc_set_cu_budget": (c_int, [c_void_p, c_int]),
     "clipenc_set_precision": (c_int, [c_void_p, c_int]),
     "clipenc_set_pixel_norm": (c_int, [c_void_p, c_float_p, c_float_p]),
     "clipenc_get_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_size_t)]),

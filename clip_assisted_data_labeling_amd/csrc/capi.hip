@@ -183,7 +183,6 @@ struct clipenc_s {
   bool cls_shortcut = true;                              // last block's attention without K and V (the diagnostic build reads CLIPENC_CLS_KV=1 to switch it off)
   unsigned* tickets = nullptr;                           // [CE_TICKET_WORDS] zeroed per pass: eight ticket words per persistent GEMM launch (gemm.h)
   bool dynamic_tail = true;                              // (the diagnostic build reads CLIPENC_STATIC_TILES=1 to switch the tickets off)
-  int cu_budget = 0;                                     // clipenc_set_cu_budget: CUs the persistent kernels may hold (0 = all)
 };
 
 struct preproc_s {
@@ -265,7 +264,6 @@ int ensure_workspace(clipenc_s* e) {
 // runs patch-embed + ln_pre + `n_layers` blocks on `c` crops; leaves the residual stream in e->x
 // cls_only_last: the caller only needs token 0 of the last block (clipenc_encode); false keeps every token (forward_tokens)
 int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers, hipStream_t st, bool cls_only_last = false) {
-  const CuBudgetScope cu_scope(e->cu_budget);              // the persistent launchers of this thread size their grids by it (common.h)
   const clipenc_config& g = e->cfg;
   const int T = c * e->tokens, P = c * (e->tokens - 1);
   const int parts = g.width / 256;
@@ -839,14 +837,6 @@ int clipenc_set_chunk(clipenc_t e, int chunk_crops) {
   const int old_chunk = e->chunk;
   e->chunk = chunk_crops;
   if (int rc = ensure_workspace(e)) { e->chunk = old_chunk; return rc; }
-  return 0;
-}
-
-int clipenc_set_cu_budget(clipenc_t e, int n_cu) {
-  if (!e) return fail("NULL handle");
-  if (n_cu < 0) return fail("cu budget %d < 0", n_cu);
-  if (n_cu != 0 && (n_cu < 8 || n_cu % 8 != 0)) return fail("cu budget %d: 0 (all) or a multiple of 8 (one CU per XCD at a time)", n_cu);
-  e->cu_budget = n_cu;
   return 0;
 }
 

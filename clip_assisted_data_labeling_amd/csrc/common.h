@@ -42,16 +42,6 @@ static inline float host_bf16_to_f32(uint16_t h) {
 // GPUs: a single function-local `static bool` would set the attribute on the first device only and reuse its grid size.
 // Thread-safe: plain atomics on a small table, the (idempotent) setup may run twice under a race.
 #include <atomic>
-// CU budget of the calling thread's current encode call (0 = the whole chip): the persistent launchers -- one workgroup per CU --
-// size their grids by it, so that the CUs left over stay free for kernels on other streams (clipenc_set_cu_budget: the embed
-// driver's JPEG decode / crop front end beside the encoder).  Thread-local because the ABI is one caller thread per handle
-// (INTEGRATION.md); set by CuBudgetScope in capi.hip for the duration of a call.
-inline thread_local int ce_tls_cu_budget = 0;
-struct CuBudgetScope {
-  int saved;
-  explicit CuBudgetScope(int budget) : saved(ce_tls_cu_budget) { ce_tls_cu_budget = budget; }
-  ~CuBudgetScope() { ce_tls_cu_budget = saved; }
-};
 struct DeviceKernelSetup {
   static constexpr int kMaxDevices = 64;
   std::atomic<int> cu[kMaxDevices];
@@ -67,7 +57,7 @@ struct DeviceKernelSetup {
       if (c <= 0) c = 256;
       cu[dev].store(c, std::memory_order_release);
     }
-    if (n_cu) *n_cu = (ce_tls_cu_budget > 0 && ce_tls_cu_budget < c) ? ce_tls_cu_budget : c;
+    if (n_cu) *n_cu = c;
     return hipSuccess;
   }
 };

@@ -143,9 +143,6 @@ class Feature_Dataset:
         # between two of the encoder's kernels), "side" = an ordinary second stream, "same" = the encoder's own stream
         self.gpu_decode_stream = "priority"
         self.gpu_decode_queue = 6                           # encode batches the stager may be ahead of the encoder
-        # CUs the encoder's persistent kernels hold while the stager still has files to decode (clipenc_set_cu_budget; 0 = all):
-        # the CUs left over run the decode / crop kernels BESIDE the encoder instead of between two of its kernels
-        self.cu_budget = 0
         self.first_chunk_div = 4                            # the first decode chunk is batch_size / this many files
         # Progressive files: the device takes them, but walks each with ONE lane (scans are serial), 0.25 - 0.5 s for a chunk
         # during which its small workgroups sit on every CU and the encoder's persistent kernels cannot be placed -- with host
@@ -391,7 +388,9 @@ class Feature_Dataset:
                                     # bytes per pixel from the files' own sampling factors (the largest of the window: a 4:2:0 set reserves
                                     # 4.5, one 4:4:4 file makes it 9 -- a 9 GB arena where 4.6 GB do costs ~0.3 s of start-up in hipMalloc)
                                     from .jpeg_gpu import scratch_bytes_per_pixel
-                                    bpp = max(scratch_bytes_per_pixel(w[1][0]) for w in dev_files[:64])
+                                    # (over the WHOLE first window -- the header walk is microseconds per file; a directory that starts with
+                                    #  4:2:0 files and holds 4:4:4 ones later in the window would otherwise under-reserve by 2x and regrow mid-run)
+                                    bpp = max(scratch_bytes_per_pixel(w[1][0]) for w in dev_files)
                                     if not self.jpeg.reserve(px, int(sum(len(w[1][0]) for w in dev_files) * scale * 1.1), bytes_per_pixel=bpp):
                                         print(f"Warning: no device memory for the JPEG decoder's scratch ({px / 1e6:.0f} Mpx per chunk); "
                                               "groups it cannot hold are decoded by Pillow on the host (slow)")
@@ -441,13 +440,10 @@ class Feature_Dataset:
                                 tl["crop_and_queue_s"] = _time.perf_counter() - t_dec - tl["decode_s"]
                                 self.stager_log.append({k: round(v, 4) if isinstance(v, float) else v for k, v in tl.items()})
                                 del acc                          # the chunk's decoded images: their crops are cut (stream-ordered free)
-                    self._stager_active = False
                     put(("end",))
                 except BaseException as e:                      # noqa: BLE001 -- re-raised in the main thread
-                    self._stager_active = False
                     put(("error", e))
 
-            self._stager_active = True
             th = threading.Thread(target=stager, name="embed-stager", daemon=True)
             th.start()
             try:
@@ -493,7 +489,6 @@ class Feature_Dataset:
         def run():
             wt = threading.Thread(target=writer_loop, name="embed-writer", daemon=True)
             wt.start()
-            cur_budget = 0
             try:
                 for meta, stacked, ev in encode_batches():
                     self.marks.setdefault("first_batch_ready", _time.perf_counter())
@@ -503,10 +498,6 @@ class Feature_Dataset:
                         cur = torch.cuda.current_stream(stacked.device)
                         cur.wait_event(ev)
                         stacked.record_stream(cur)
-                    budget = int(self.cu_budget) if getattr(self, "_stager_active", False) else 0
-                    if budget != cur_budget and hasattr(getattr(self.encoder, "model", None), "set_cu_budget"):
-                        self.encoder.model.set_cu_budget(budget)    # (a field of the handle, read by the next encode call)
-                        cur_budget = budget
                     features = self.encoder.encode_image(stacked).float()                        # :130
                     if on_gpu:
                         host = torch.empty(features.shape, dtype=torch.float32, pin_memory=True)
@@ -519,8 +510,6 @@ class Feature_Dataset:
                     self.marks.setdefault("first_encode_issued", _time.perf_counter())
                     self.marks["last_encode_issued"] = _time.perf_counter()
             finally:
-                if cur_budget and hasattr(getattr(self.encoder, "model", None), "set_cu_budget"):
-                    self.encoder.model.set_cu_budget(0)
                 out_q.put(None)
                 wt.join()
                 self.marks["done"] = _time.perf_counter()

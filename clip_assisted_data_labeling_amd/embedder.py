@@ -94,10 +94,6 @@ class HipViT:
         _lib.check(self.lib.clipenc_set_precision(self.handle, self.PRECISIONS[precision]), "clipenc_set_precision")
         self.precision = precision
 
-    def set_cu_budget(self, n_cu: int) -> None:
-        """CUs the persistent kernels may hold (0 = all, else a multiple of 8): the rest stay free for other streams' kernels."""
-        _lib.check(self.lib.clipenc_set_cu_budget(self.handle, int(n_cu)), "clipenc_set_cu_budget")
-
     def set_chunk(self, chunk_crops: int) -> None:
         _lib.check(self.lib.clipenc_set_chunk(self.handle, int(chunk_crops)), "clipenc_set_chunk")
 

@@ -73,8 +73,9 @@ def run_embed_job(n_images: int, batch_images: int, crops_per_image: int, embed_
     t1 = time.perf_counter()
     out = {"n_local": n_local, "lo": lo, "hi": hi, "batches": batches, "t_encode": t1 - t0, "t_gather": 0.0,
            "emb_local": emb, "score_local": score}            # this rank's own rows, whatever the gather does
-    if gather and world > 1:
-        if not (dist.is_available() and dist.is_initialized()):
+    in_group = dist.is_available() and dist.is_initialized()
+    if gather and (world > 1 or in_group):                    # (a group of ONE rank gathers through the backend too)
+        if not in_group:
             raise RuntimeError("world > 1 needs an initialised torch.distributed process group")
         ge, gs = (emb, score) if gather_device is None else (emb.to(gather_device), score.to(gather_device))
         full_e = gather_rows(ge, n_images, dst=gather_dst)    # the one exchange of the path

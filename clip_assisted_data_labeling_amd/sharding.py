@@ -40,12 +40,24 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None, dst: Optional[int
               together, each block received into its final rows.
     dst=r:    only rank r allocates and receives the result: the receives from ALL peers are posted together (one RCCL
               group call, every xGMI link busy at once) into the final rows; the other ranks send their block and get None.
-    A single process returns `local` itself."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    A single process WITHOUT a process group returns `local` itself; a group of one rank (a launcher with one GPU) takes the
+    collective path like any other group -- one `all_gather_into_tensor` through the backend into a fresh result.
+
+    Every call on a group starts with one tiny all-rank collective (`_warm_group`): the exchanges below are subsets of
+    point-to-point operations, and on NCCL / RCCL a lazily initialised group (no `device_id=` at `init_process_group`) requires
+    EVERY rank to take part in its first collective -- ranks with an empty shard post nothing in the ragged and `dst=` forms."""
+    if not (dist.is_available() and dist.is_initialized()):
         if local.shape[0] != n_total:
             raise ValueError(f"single process holds {local.shape[0]} rows, expected {n_total}")
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    _warm_group(group, local.device)
+    if world == 1:
+        if local.shape[0] != n_total:
+            raise ValueError(f"single process holds {local.shape[0]} rows, expected {n_total}")
+        out = torch.empty_like(local, memory_format=torch.contiguous_format)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
     lo, hi = shard_bounds(n_total, rank, world)
     if local.shape[0] != hi - lo:
         raise ValueError(f"rank {rank} holds {local.shape[0]} rows, its shard is {hi - lo}")
@@ -91,6 +103,13 @@ def gather_rows(local: torch.Tensor, n_total: int, group=None, dst: Optional[int
             ops.append(dist.P2POp(dist.irecv, out[rlo:rhi], peer(r), group))
     _run_p2p(ops)
     return out
+
+
+def _warm_group(group, device) -> None:
+    """One all-reduce of a single element on `device` in front of every exchange (tens of microseconds; gather_rows runs twice
+    per job): every rank calls gather_rows, so every rank takes part -- after it the backend's communicator exists on all of
+    them and subset point-to-point batches are well defined, whether or not the group was initialised eagerly."""
+    dist.all_reduce(torch.zeros(1, device=device), group=group)
 
 
 def _run_p2p(ops) -> None:

@@ -82,15 +82,6 @@ int clipenc_set_precision(clipenc_t enc, int precision);
 int clipenc_set_chunk(clipenc_t enc, int chunk_crops);
 int clipenc_get_info(clipenc_t enc, int* tokens, int* embed_dim, int* chunk_crops, size_t* workspace_bytes);
 
-/* CUs the encoder's PERSISTENT kernels (the block GEMMs and the streaming attention: one workgroup per CU for the whole
- * launch) may hold from the next encode call on: 0 = every CU (default), otherwise a multiple of 8 (the 8 XCDs are dealt
- * workgroups in turn, so 8 fewer workgroups leave one CU per XCD free).  The CUs left over take the workgroups of kernels
- * on OTHER streams while the encoder runs -- the embed driver's JPEG decode and crop / resize front end, which otherwise wait
- * for a kernel boundary of a grid that holds the whole chip (the loader of /root/reference/_1_embed_with_CLIP.py:81-90 runs in
- * CPU worker processes beside the GPU; this is its device-side counterpart).  No reallocation, no synchronisation; the
- * results do not depend on the budget (which workgroup runs a tile changes no bit). */
-int clipenc_set_cu_budget(clipenc_t enc, int n_cu);
-
 /* Replaces CLIP_Encoder.encode_image (/root/reference/utils/embedder.py:94-100):
  *   crops_dev  [n_crops][3][R][R], contiguous NCHW, dtype `in_dtype`, row = image*4 + crop
  *   emb_dev    float32 [n_crops][embed_dim]; L2-normalised rows when `normalize` != 0 (:99). */

@@ -113,7 +113,6 @@ def test_library_argument_errors_without_gpu():
     assert lib.clipenc_encode(None, None, 4, 0, None, 1, None) != 0
     assert lib.fcreg_forward(None, None, 4, 8, 1, 8, None, None, None) != 0
     assert lib.clipenc_destroy(None) == 0 and lib.fcreg_destroy(None) == 0
-    assert lib.clipenc_set_cu_budget(None, 248) != 0 and b"NULL" in lib.clipenc_last_error()
 
 
 def test_product_has_no_cpu_path():

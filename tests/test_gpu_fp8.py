@@ -506,3 +506,34 @@ def test_encoder_fp8_with_outlier_channels(gpu):
     print("fp8 outlier 1-cos:", omc)
     assert omc.max().item() < COS_TOL, omc
     vit.close()
+
+
+def test_gemm_fp8_e4m3_output_of_huge_and_non_finite_values(gpu):
+    """What the static-scale e4m3 epilogue (EPI 2) does beyond the representable range, pinned byte for byte: a FINITE value of any
+    size saturates to +-448 (0x7e / 0xfe: MODE.FP16_OVFL, gemm_fp8.hip), a non-finite one (+-inf from an overflowing row scale, or
+    0 x inf) becomes the e4m3 NaN code and poisons what consumes it -- it is not clamped (the hardware conversion's rule, established
+    by tools/probes/fp8_ovfl_probe.hip; accepted: a non-finite pre-activation means the tower has already diverged)."""
+    lib = _lib.load()
+    m, n, k = 256, 256, 256
+    a8 = torch.full((m, k), 0x38, dtype=torch.uint8)                          # 1.0
+    w8 = torch.where((torch.arange(n) % 2 == 0).view(n, 1).expand(n, k), torch.tensor(0x38, dtype=torch.uint8),
+                     torch.tensor(0xb8, dtype=torch.uint8)).contiguous()      # +1.0 / -1.0 rows: acc = +-256
+    sa = torch.ones(m)
+    sa[1], sa[2], sa[3] = 1e30, float("inf"), 3.0e38                          # 256 * 3e38 overflows fp32 in the epilogue's multiply
+    sw, bias, inv_s = torch.ones(n), torch.zeros(n), torch.ones(n)
+    for act in (-1, 0):
+        out = torch.full((m, n), 0x55, dtype=torch.uint8, device=gpu)
+        dev = [t.to(gpu) for t in (a8, w8, sa, sw, bias, inv_s)]
+        _lib.check(lib.clipenc_op_gemm_fp8_q(dev[0].data_ptr(), dev[1].data_ptr(), m, n, k, dev[2].data_ptr(), dev[3].data_ptr(),
+                                             dev[4].data_ptr(), act, dev[5].data_ptr(), out.data_ptr(), _stream(gpu)), "gemm_fp8_q")
+        torch.cuda.synchronize()
+        o = out.cpu()
+        pos = torch.arange(n) % 2 == 0
+        if act == -1:
+            assert (o[0][pos] == 0x7c).all() and (o[0][~pos] == 0xfc).all()   # +-256 exactly
+            assert (o[1][pos] == 0x7e).all() and (o[1][~pos] == 0xfe).all()   # 2.56e32: saturated
+            assert ((o[2] & 0x7f) == 0x7f).all() and ((o[3] & 0x7f) == 0x7f).all()   # +-inf: NaN code, not +-448
+        else:                                                                 # QuickGELU: u sigmoid(1.702 u) -> u for u >> 0, -> -0 for u << 0
+            assert (o[0][pos] == 0x7c).all() and ((o[0][~pos] & 0x7f) == 0).all()
+            assert (o[1][pos] == 0x7e).all() and ((o[1][~pos] & 0x7f) == 0).all()
+            assert ((o[2][pos] & 0x7f) == 0x7f).all() and ((o[3][pos] & 0x7f) == 0x7f).all()

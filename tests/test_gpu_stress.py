@@ -126,28 +126,3 @@ def test_fused_fp8_chain_is_stable_over_repeats_and_row_prefixes(gpu, m, k2):
     head = run(5000)
     for t0, t1, name in zip(first, head, ("x", "x8", "exponents", "consumer output")):
         assert torch.equal(t0[:5000], t1), f"{name}: the first 5000 rows depend on the rows behind them"
-
-
-def test_cu_budget_changes_no_bit_and_refuses_odd_budgets(gpu):
-    """clipenc_set_cu_budget: the persistent kernels' grids shrink to the budget (the CUs left over stay free for other streams'
-    kernels: the embed driver's loader); WHICH workgroup runs a tile or an attention task changes no result bit, bf16 and fp8."""
-    from clip_assisted_data_labeling_amd import _lib, vit_config
-    from clip_assisted_data_labeling_amd.embedder import HipViT
-    cfg = vit_config.ARCHS["ViT-L-14"]
-    vit = HipViT(cfg, vit_config.seeded_state_dict(cfg, 0), gpu)
-    try:
-        g = torch.Generator(device=gpu).manual_seed(21)
-        crops = torch.randint(0, 256, (300, 3, 224, 224), device=gpu, generator=g, dtype=torch.int32).to(torch.uint8)
-        for prec in ("bf16", "fp8"):
-            vit.set_precision(prec)
-            vit.set_cu_budget(0)
-            ref = vit.encode(crops)
-            for budget in (248, 192, 64, 8):
-                vit.set_cu_budget(budget)
-                assert torch.equal(vit.encode(crops), ref), (prec, budget)
-        for bad in (-8, 4, 250):
-            with pytest.raises(_lib.ClipencError):
-                vit.set_cu_budget(bad)
-        vit.set_cu_budget(0)
-    finally:
-        vit.close()

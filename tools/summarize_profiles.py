@@ -64,16 +64,20 @@ for k in traffic:
     m = re.search(r"(\w+_kernel(<[^>]*>)?)", k)
     if m:
         short[m.group(1)] = bench.kernel_source_sha(m.group(1))
-# the bench run this profile sits next to: which box, and what its matrix pipes get alone
+# the bench run this profile sits next to: which box, what its matrix pipes get alone, and the PROBLEM the launches were profiled on
+problem = None
 try:
     bl = json.loads([l for l in open(os.path.join(src, "bench_n1.json")) if l.startswith("{")][-1])
+    problem = bl.get("config", {}).get("problem")
     box = {"value": bl.get("value"), "ms_per_step": bl.get("ms_per_step"), "env": bl.get("env"),
            "power_capped_mfma_stream": bl.get("roofline", {}).get("power_capped_mfma_stream")}
     json.dump(box, open(os.path.join(dst, "box.json"), "w"), indent=1)
     print("box:", box["value"], "images/s;", (box["power_capped_mfma_stream"] or {}).get("value"), "TFLOP/s pure MFMA stream")
 except Exception as exc:
     print("no box record:", exc)
-traffic["_meta"] = {"source_sha": short, "note": "sha256[:16] of the kernel's .hip sources + common.h + gemm.h at profile time"}
+traffic["_meta"] = {"source_sha": short, "note": "sha256[:16] of the kernel's .hip sources + common.h + gemm.h at profile time",
+                    # bench.py quotes a constant only for launches of the same problem (token rows, GEMM widths)
+                    "problem": problem or bench.LEGACY_PROBLEM}
 json.dump(traffic, open(os.path.join(dst, "pmc_hbm_traffic_per_kernel.json"), "w"), indent=1)
 del traffic["_meta"]
 sq_names = {"SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
