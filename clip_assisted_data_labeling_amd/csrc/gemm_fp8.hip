@@ -621,23 +621,38 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) sa[mt] *= QK;
       }
+      // the lane's 32 column constants, once per tile (the same for its four 32-row blocks; the fragment registers are dead here)
+      f32x4_t isr[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) isr[c] = *(const f32x4_t*)(isc + (c >> 2) * 32 + (c & 3) * 8 + he * 4);   // (the LDS serves one wave's accesses in order: the values written above)
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
           const int nt = c >> 2, g = c & 3;
           const int col = nt * 32 + g * 8 + he * 4;
-          const f32x4_t is = *(const f32x4_t*)(isc + col);      // (the LDS serves one wave's accesses in order: the values written above)
+          const f32x4_t is = isr[c];
           float v[4];
+          if constexpr (ACT == CE_ACT_QUICK_GELU) {
+            // the four elements stage by stage (4 x exp2, 4 x fma, 4 x rcp, 4 x mul): written element by element hipcc issues
+            // the four dependent chains one after the other, each transcendental followed by the wait state its consumer needs
+            // (s_nop 0) -- 38 issue cycles per element instead of 30, in an epilogue that both waves of a SIMD spend in VALU issue
+            float a[4], ex[4], den[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if constexpr (ACT == CE_ACT_QUICK_GELU) {
-              const float a = acc[mt][nt][g * 4 + e] * sa[mt];
-              const float den = __builtin_fmaf(__builtin_amdgcn_exp2f(a), is[e], is[e]);
-              v[e] = F8_SAT(a * __builtin_amdgcn_rcpf(den));
-            } else {
-              v[e] = F8_SAT(act_apply_t<ACT>(acc[mt][nt][g * 4 + e] * sa[mt]) * is[e]);
-            }
+            for (int e = 0; e < 4; ++e) a[e] = acc[mt][nt][g * 4 + e] * sa[mt];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ex[e] = __builtin_amdgcn_exp2f(a[e]);
+            asm volatile("" : "+v"(ex[0]), "+v"(ex[1]), "+v"(ex[2]), "+v"(ex[3]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) den[e] = __builtin_fmaf(ex[e], is[e], is[e]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) den[e] = __builtin_amdgcn_rcpf(den[e]);
+            asm volatile("" : "+v"(den[0]), "+v"(den[1]), "+v"(den[2]), "+v"(den[3]));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = F8_SAT(a[e] * den[e]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = F8_SAT(act_apply_t<ACT>(acc[mt][nt][g * 4 + e] * sa[mt]) * is[e]);
           }
           int wd = 0;
           wd = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], wd, false);
