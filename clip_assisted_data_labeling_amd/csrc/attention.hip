@@ -15,6 +15,8 @@
 // two-pass (true row max), not an online rescale.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -35,6 +37,11 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
 // two fp32 -> one packed bf16 pair (a single v_cvt_pk_bf16_f32)
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+
+constexpr unsigned SPIN_LIMIT = 1u << 24;                       // every spin of the persistent kernels below is bounded
+__device__ __forceinline__ unsigned lds_load_u32(const char* p) {
+  return __atomic_load_n((const unsigned*)p, __ATOMIC_RELAXED);
 }
 
 __device__ __forceinline__ int k_swz(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -382,6 +389,392 @@ hipError_t launch_attn_long(const bf16_t* qkv, bf16_t* out, int n_crops, int n_t
 }
 
 // ---------------------------------------------------------------------------------------------
+// Long sequences, streaming form (289..608 tokens, >= 64 tasks, every query block asked for: ViT-L-14-336 in the tower).
+// attn_long_kernel above loads a head's K | V (148 KB at 577 tokens) and only then starts: a fifth of its time nothing is computed, and
+// a second task's K | V do not fit beside the first's.  Here ONE persistent workgroup per CU (NCW compute waves + 1 loader wave) walks a
+// contiguous range of (crop, head) tasks and the next task's key tiles REPLACE the current task's IN PLACE, tile by tile, as they die:
+//   * the 32-query blocks of consecutive tasks form one stream handed out in order from an LDS counter (as in attn_stream_kernel); a
+//     block sweeps the key tiles 0 .. nkt-1 once (the single-pass softmax of attn_long_kernel, the same arithmetic in the same order);
+//   * done[c] counts the block sweeps that have passed tile c (monotonic over tasks; the count is taken after the sweep's last read of
+//     the tile -- the LDS executes a wave's instructions in order, so the add lands behind the reads); when all n_qb blocks of task k
+//     have passed tile c the loader fetches tile c of task k + 1 into the same 8 KiB by LDS-DMA, and publishes `landed`, the number of
+//     tiles of the stream that are readable, behind a counted vmcnt wait (four tiles stay in flight);
+//   * a block of task k + 1 waits for `landed` tile by tile: a wave that runs out of blocks of task k starts on task k + 1 behind the
+//     sweeps still going on -- the load of a task hides behind the last sweeps of the task before, and HBM sees a steady stream.
+//   Every spin is bounded; no s_barrier in the steady state.  Deadlock-free: blocks are grabbed in stream order, every grabbed block of
+//   task k is being swept by a wave, and tile c of task k stays put until all of them have passed it.
+// The overflow guard of the single-pass softmax (a weight beyond 2^64 moves the row's reference: attn_long_kernel looks for one in every
+// tile, 6 % of its time) is taken ONCE per block here: a row sum that is not inside [2^-100, 2^100] -- a weight overflowed, or every weight
+// underflowed -- flags the block in an LDS bitmap instead of storing it, and when the stream has drained the workgroup loads each flagged
+// task's K | V whole and sweeps the flagged blocks again WITH the per-tile guard (the exact path, the code of attn_long_kernel).  Ordinary
+// inputs never flag; tests/test_gpu_parity.py::test_long_attention_single_pass_softmax_rescales_where_it_must forces it.
+// ---------------------------------------------------------------------------------------------
+template <int NCW>
+__global__ __launch_bounds__((NCW + 1) * 64, (NCW + 1) / 4) void attn_long_stream_kernel(
+    const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int n_tok, int width, int heads, float scale_log2e, int nkt, int n_tasks,
+    const float* __restrict__ out_inv) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NW = NCW + 1;
+#ifndef LS_DFLIGHT
+#define LS_DFLIGHT 2
+#endif
+#ifndef LS_PRIO
+#define LS_PRIO 3
+#endif
+#ifndef LS_EARLY_MARK
+#define LS_EARLY_MARK 1
+#endif
+  constexpr int D_FLIGHT = LS_DFLIGHT;                           // key tiles (8 pieces each) the loader keeps in flight at most
+  const int rows = nkt * 32;
+  char* Ks = smem;
+  char* Vs = smem + rows * 128;
+  char* ctrl = smem + 2 * rows * 128;                            // [0] landed, [4] next block, [64 + 4 c] done[c], [256 + 4 k] redo bits of task k
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int G = gridDim.x, wg = blockIdx.x;
+  const int t0 = (int)(((long long)n_tasks * wg) / G), t1 = (int)(((long long)n_tasks * (wg + 1)) / G);
+  const int ntask = t1 - t0;                                     // host guarantees 1 <= ntask <= 496
+  const int n_qb = nkt;                                          // every query block (the host routes other requests to attn_long_kernel)
+  const int total_blocks = ntask * n_qb;
+  const size_t ld = (size_t)3 * width;
+  const unsigned ldb = (unsigned)(ld * 2);
+  const int r = lane & 31, h = lane >> 5;
+
+  for (int i = tid; i < 1024; i += NW * 64) ((unsigned*)ctrl)[i] = 0u;
+  __syncthreads();
+
+  // K / V pieces j0 .. j0 + n - 1 (8 rows x 128 B each) of the task at `tb` into their places (rows beyond n_tok: the last row again, masked)
+  auto issue_pieces = [&](const char* tb, int j0, int n) {
+    for (int j = j0; j < j0 + n; ++j) {
+      const int row = 8 * j + (lane >> 3);
+      const unsigned rb = (unsigned)min(row, n_tok - 1) * ldb;
+      const int ck = (lane & 7) ^ ((row >> 1) & 7);
+      const int cv = (lane & 7) ^ (((row >> 1) & 1) << 2);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + (size_t)width * 2 + (rb + ck * 16)),
+                                       (__attribute__((address_space(3))) void*)(Ks + j * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tb + (size_t)width * 4 + (rb + cv * 16)),
+                                       (__attribute__((address_space(3))) void*)(Vs + j * 1024), 16, 0, 0);
+    }
+  };
+
+  const f32x16_t zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const char* kb0 = Ks + k_swz(r, 0 + h); const char* kb1 = Ks + k_swz(r, 2 + h);
+  const char* kb2 = Ks + k_swz(r, 4 + h); const char* kb3 = Ks + k_swz(r, 6 + h);
+  const int vi = lane & 15, vq = vi >> 2, vp = vi & 3, vg1 = (lane >> 4) & 1;
+  const char* vbase0 = Vs + v_swz(4 * h + vq, (vg1 * 16 + vp * 4) >> 3) + ((vg1 * 16 + vp * 4) & 7) * 2;
+  const char* vbase1 = Vs + v_swz(4 * h + vq, (32 + vg1 * 16 + vp * 4) >> 3) + ((vg1 * 16 + vp * 4) & 7) * 2;
+  auto v_frag = [&](int j, const char* vb) -> bf16x8_t {
+    typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + j * 2048));
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + j * 2048 + 1024));
+    s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, vv);
+  };
+  auto row_max = [&](const f32x16_t& s) -> float {
+    float a = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+    for (int e = 4; e < 16; e += 4) a = fmaxf(a, fmaxf(fmaxf(s[e], s[e + 1]), fmaxf(s[e + 2], s[e + 3])));
+    return a;
+  };
+  auto weight_max_bits = [&](const float (&pv)[16]) -> unsigned {
+    unsigned m = __float_as_uint(pv[0]);
+#pragma unroll
+    for (int j = 1; j < 16; ++j) m = max(m, __float_as_uint(pv[j]));
+    return m;
+  };
+  const bool two_last = (nkt - 1) * 32 + 16 < n_tok;
+  unsigned seen = 0;                                             // the last value of `landed` this wave has read (wave-uniform)
+#ifdef LS_COUNT
+  unsigned long long cnt_wait = 0, cnt_w0 = 0, cnt_w2 = 0, cnt_t0 = __builtin_amdgcn_s_memtime();
+#endif
+  auto wait_landed = [&](unsigned need) {
+#ifdef LS_DBG
+    return;
+#endif
+    if (seen < need) {
+#ifdef LS_COUNT
+      const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+      unsigned spins = 0;
+      do {
+        seen = __builtin_amdgcn_readfirstlane(lds_load_u32(ctrl));
+        if (seen >= need) break;
+        __builtin_amdgcn_s_sleep(1);
+      } while (++spins < SPIN_LIMIT);
+#ifdef LS_COUNT
+      { const unsigned long long dw = __builtin_amdgcn_s_memtime() - w0; cnt_wait += dw; const unsigned cc = (need - 1) % (unsigned)nkt; if (cc < 2) cnt_w0 += dw; else if (cc >= (unsigned)nkt - 4) cnt_w2 += dw; }
+#endif
+    }
+    asm volatile("" ::: "memory");
+  };
+
+  // One 32-query block of (crop, head) over all key tiles.  STREAM: the tiles are waited for and released one by one, the overflow guard is the
+  // caller's look at the returned row sum.  !STREAM: the task's K | V are resident, per-tile guard (the body of attn_long_kernel).
+  auto sweep = [&](auto stream_tag, const bf16x8_t (&qf)[4], unsigned gi0, int crop, int head, int qb) -> float {
+    constexpr bool STREAM = decltype(stream_tag)::value;
+    bf16x8_t kf[4], pf[2];
+    f32x16_t o0 = zero16, o1 = zero16, s;
+    float lsum = 0.f, m_ref = 0.f, moff = 0.f;
+    if constexpr (STREAM) wait_landed(gi0 + 1);
+    kf[0] = *(const bf16x8_t*)kb0; kf[1] = *(const bf16x8_t*)kb1; kf[2] = *(const bf16x8_t*)kb2; kf[3] = *(const bf16x8_t*)kb3;
+    for (int c = 0; c < nkt; ++c) {
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], zero16, 0, 0, 0);
+#pragma unroll
+      for (int st = 1; st < 4; ++st) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[st], qf[st], s, 0, 0, 0);
+      const bf16x8_t va0 = v_frag(2 * c, vbase0), vb0 = v_frag(2 * c, vbase1);
+      const bf16x8_t va1 = v_frag(2 * c + 1, vbase0), vb1 = v_frag(2 * c + 1, vbase1);
+      if constexpr (STREAM && LS_EARLY_MARK) {
+        // the sweep's last reads of tile c are in this wave's LDS queue: an add issued behind them executes behind them
+        asm volatile("" ::: "memory");
+        if (lane == 0) __atomic_fetch_add((unsigned*)(ctrl + 64 + 4 * c), 1u, __ATOMIC_RELAXED);
+        asm volatile("" ::: "memory");
+      }
+      {
+        const int cn = min(c + 1, nkt - 1);
+        if constexpr (STREAM) wait_landed(gi0 + cn + 1);
+        const int ko = cn * 4096;
+        kf[0] = *(const bf16x8_t*)(kb0 + ko); kf[1] = *(const bf16x8_t*)(kb1 + ko);
+        kf[2] = *(const bf16x8_t*)(kb2 + ko); kf[3] = *(const bf16x8_t*)(kb3 + ko);
+      }
+      if (c == nkt - 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int key = c * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= n_tok) s[e] = -INFINITY;
+        }
+      }
+      if (c == 0) {
+        m_ref = row_max(s);
+        m_ref = fmaxf(m_ref, __shfl_xor(m_ref, 32));
+        moff = m_ref * scale_log2e;
+      }
+      float pv[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) pv[j] = __builtin_amdgcn_exp2f(fmaf(s[j], scale_log2e, -moff));
+      if constexpr (!STREAM) {
+        if (c > 0 && __builtin_amdgcn_ballot_w64(weight_max_bits(pv) > __float_as_uint(LP_THR)) != 0ull) {
+          float mx = row_max(s);
+          mx = fmaxf(mx, __shfl_xor(mx, 32));
+          const float m_new = fmaxf(m_ref, mx);
+          const float alpha = __builtin_amdgcn_exp2f((m_ref - m_new) * scale_log2e);
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %0" : "+v"(o0[e]) : "v"(alpha));
+            asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %0" : "+v"(o1[e]) : "v"(alpha));
+          }
+          asm volatile("s_nop 1\n\tv_mul_f32 %0, %1, %0" : "+v"(lsum) : "v"(alpha));
+          m_ref = m_new;
+          moff = m_ref * scale_log2e;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) pv[j] = __builtin_amdgcn_exp2f(fmaf(s[j], scale_log2e, -moff));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) lsum += pv[j];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const u32x4_t pw = {cvt_pk_bf16(pv[s2 * 8 + 0], pv[s2 * 8 + 1]), cvt_pk_bf16(pv[s2 * 8 + 2], pv[s2 * 8 + 3]),
+                            cvt_pk_bf16(pv[s2 * 8 + 4], pv[s2 * 8 + 5]), cvt_pk_bf16(pv[s2 * 8 + 6], pv[s2 * 8 + 7])};
+        pf[s2] = __builtin_bit_cast(bf16x8_t, pw);
+      }
+      o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va0, pf[0], o0, 0, 0, 0);
+      o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb0, pf[0], o1, 0, 0, 0);
+      if (c < nkt - 1 || two_last) {
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va1, pf[1], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb1, pf[1], o1, 0, 0, 0);
+      }
+      if constexpr (STREAM && !LS_EARLY_MARK) {
+        // this sweep's reads of tile c (its K fragments an iteration ago, its V fragments above) are in the LDS queue ahead of the add
+#ifndef LS_DBG
+        asm volatile("" ::: "memory");
+        if (lane == 0) __atomic_fetch_add((unsigned*)(ctrl + 64 + 4 * c), 1u, __ATOMIC_RELAXED);
+#endif
+      }
+    }
+    lsum += __shfl_xor(lsum, 32);
+    if constexpr (STREAM) {
+      // the single-pass weights are trustworthy while no weight overflowed and not all of them underflowed; otherwise: the exact path later
+      if (__builtin_amdgcn_ballot_w64(!(lsum >= 0x1p-100f && lsum <= 0x1p100f)) != 0ull) return -1.0f;
+    }
+    const float inv = __builtin_amdgcn_rcpf(lsum);
+    const int q = qb * 32 + r;
+    if (q < n_tok && out_inv) {
+      uint8_t* orow = (uint8_t*)out + ((size_t)crop * n_tok + q) * width + head * 64;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const int col = g4 * 8 + h * 4;
+        const f32x4_t is0 = *(const f32x4_t*)(out_inv + head * 64 + col), is1 = *(const f32x4_t*)(out_inv + head * 64 + 32 + col);
+        *(int*)(orow + col) = pack_fp8x4(o0[g4 * 4 + 0] * inv * is0[0], o0[g4 * 4 + 1] * inv * is0[1],
+                                         o0[g4 * 4 + 2] * inv * is0[2], o0[g4 * 4 + 3] * inv * is0[3]);
+        *(int*)(orow + 32 + col) = pack_fp8x4(o1[g4 * 4 + 0] * inv * is1[0], o1[g4 * 4 + 1] * inv * is1[1],
+                                              o1[g4 * 4 + 2] * inv * is1[2], o1[g4 * 4 + 3] * inv * is1[3]);
+      }
+    } else if (q < n_tok) {
+      bf16_t* orow = out + ((size_t)crop * n_tok + q) * width + head * 64;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        *(uint2*)(orow + g4 * 8 + h * 4) = uint2{pack_bf16x2(o0[g4 * 4 + 0] * inv, o0[g4 * 4 + 1] * inv),
+                                                 pack_bf16x2(o0[g4 * 4 + 2] * inv, o0[g4 * 4 + 3] * inv)};
+        *(uint2*)(orow + 32 + g4 * 8 + h * 4) = uint2{pack_bf16x2(o1[g4 * 4 + 0] * inv, o1[g4 * 4 + 1] * inv),
+                                                      pack_bf16x2(o1[g4 * 4 + 2] * inv, o1[g4 * 4 + 3] * inv)};
+      }
+    }
+    return 1.0f;
+  };
+  auto q_load = [&](int crop, int head, int qb, bf16x8_t (&qf)[4]) {
+    const bf16_t* qrow = qkv + (size_t)crop * n_tok * ld + head * 64 + (size_t)min(qb * 32 + r, n_tok - 1) * ld;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) qf[st] = *(const bf16x8_t*)(qrow + st * 16 + h * 8);
+  };
+
+  if (wave == NCW) {
+    // ------------------------------------ loader wave ------------------------------------
+    // Up to D_FLIGHT tiles in flight.  The wave never sits in a wait for its newest tile while an older one could be published or a
+    // freed tile refilled: when the next tile of the stream is not free yet it retires the OLDEST tile in flight (vmcnt retires in
+    // order: a counted wait for all but the younger ones), publishes it and looks again.  (Waiting for everything in flight before
+    // looking at done[] again made the stream one tile per memory latency, slower than the sweeps free them.)
+    if (LS_PRIO) __builtin_amdgcn_s_setprio(LS_PRIO);
+    unsigned issued = 0, published = 0;
+#ifdef LS_COUNT
+    unsigned long long l_issue = 0, l_block = 0, l_idle = 0, l_t;
+#define LS_T0() l_t = __builtin_amdgcn_s_memtime()
+#define LS_ACC(x) x += __builtin_amdgcn_s_memtime() - l_t
+#else
+#define LS_T0()
+#define LS_ACC(x)
+#endif
+    int k = 0, c = 0;                                            // the next tile of the stream: tile c of task k
+    const char* tb = nullptr;
+    unsigned idle = 0;
+    while (k < ntask || published < issued) {
+      bool can_issue = false;
+      if (k < ntask && issued - published < (unsigned)D_FLIGHT) {
+#ifdef LS_DBG
+        can_issue = LS_DBG < 2 || k == 0;
+        if (!can_issue) { if (++c == nkt) { c = 0; ++k; } continue; }
+#else
+        can_issue = k == 0 || lds_load_u32(ctrl + 64 + 4 * c) >= (unsigned)(n_qb * k);   // every block of task k - 1 has passed tile c
+#endif
+      }
+      if (can_issue) {
+        if (c == 0) {
+          const int t = t0 + k;
+          const int crop = t / heads, head = t - crop * heads;
+          tb = (const char*)(qkv + (size_t)crop * n_tok * ld + head * 64);
+        }
+        asm volatile("" ::: "memory");
+        LS_T0();
+        issue_pieces(tb, 4 * c, 4);
+        LS_ACC(l_issue);
+        ++issued;
+        if (++c == nkt) { c = 0; ++k; }
+        idle = 0;
+      } else if (published < issued) {
+        LS_T0();
+        switch (issued - published) {                            // all but the (in flight - 1) youngest tiles have landed
+          case 1: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+          case 2: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+          case 3: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+          case 4: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+          case 5: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+          case 6: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
+          default: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
+        }
+        LS_ACC(l_block);
+        ++published;
+        if (lane == 0) __atomic_store_n((unsigned*)ctrl, published, __ATOMIC_RELAXED);
+      } else {
+        if (++idle >= SPIN_LIMIT) break;                         // (bounded: a tile that is never freed ends the stream)
+        LS_T0();
+        __builtin_amdgcn_s_sleep(2);
+        LS_ACC(l_idle);
+      }
+    }
+#ifdef LS_COUNT
+    if (lane == 0) { unsigned long long* so = (unsigned long long*)out + 8192 + (size_t)wg * 4; so[0] = l_issue; so[1] = l_block; so[2] = l_idle; }
+#endif
+  } else {
+    // ------------------------------------ compute waves ------------------------------------
+    auto grab = [&]() -> int {
+      unsigned v = 0;
+      if (lane == 0) v = __atomic_fetch_add((unsigned*)(ctrl + 4), 1u, __ATOMIC_RELAXED);
+      return (int)__builtin_amdgcn_readfirstlane(v);
+    };
+    auto where = [&](int g, int& k, int& qb, int& crop, int& head) {
+      k = g / n_qb; qb = g - k * n_qb;
+      const int t = t0 + k;
+      crop = t / heads; head = t - crop * heads;
+    };
+    int g = grab();
+    bf16x8_t qn[4];
+    {
+      int k, qb, crop, head;
+      where(min(g, total_blocks - 1), k, qb, crop, head);
+      q_load(crop, head, qb, qn);
+    }
+    while (g < total_blocks) {
+      const int g_next = grab();
+      int k, qb, crop, head;
+      where(g, k, qb, crop, head);
+      bf16x8_t qf[4];
+#pragma unroll
+      for (int st = 0; st < 4; ++st) qf[st] = qn[st];
+      {                                                          // the next block's queries: in flight for the whole of this sweep
+        int k2, qb2, crop2, head2;
+        where(min(g_next, total_blocks - 1), k2, qb2, crop2, head2);
+        q_load(crop2, head2, qb2, qn);
+      }
+      const float ok = sweep(std::true_type{}, qf, (unsigned)(k * nkt), crop, head, qb);
+      if (ok < 0.f && lane == 0) __atomic_fetch_or((unsigned*)(ctrl + 256 + 4 * k), 1u << qb, __ATOMIC_RELAXED);
+      g = g_next;
+    }
+  }
+#ifdef LS_COUNT
+  if (lane == 0) { unsigned long long* so = (unsigned long long*)out + ((size_t)wg * NW + wave) * 2; so[0] = cnt_wait; so[1] = __builtin_amdgcn_s_memtime() - cnt_t0; unsigned long long* s2 = (unsigned long long*)out + 16384 + ((size_t)wg * NW + wave) * 2; s2[0] = cnt_w0; s2[1] = cnt_w2; }
+#endif
+  __syncthreads();                                               // the stream has drained: every tile is dead, every flag is set
+
+  // ---- the exact path for flagged blocks (rare): the task's K | V whole, the flagged blocks dealt to the waves, per-tile guard ----
+  for (int k = 0; k < ntask; ++k) {
+    const unsigned bits = __builtin_amdgcn_readfirstlane(lds_load_u32(ctrl + 256 + 4 * k));
+    if (bits == 0u) continue;                                    // (workgroup-uniform)
+    const int t = t0 + k;
+    const int crop = t / heads, head = t - crop * heads;
+    const char* tb = (const char*)(qkv + (size_t)crop * n_tok * ld + head * 64);
+    for (int j = wave; j < rows / 8; j += NW) issue_pieces(tb, j, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int nth = 0;
+    for (int qb = 0; qb < n_qb; ++qb) {
+      if (!((bits >> qb) & 1u)) continue;
+      if (nth++ % NW != wave) continue;
+      bf16x8_t qf[4];
+      q_load(crop, head, qb, qf);
+      sweep(std::false_type{}, qf, 0u, crop, head, qb);
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_attn_long_stream(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
+                                   const float* out_inv, hipStream_t stream) {
+  constexpr int NCW = 11;                                        // + the loader: three waves per SIMD
+  const int nkt = (n_tok + 31) / 32;
+  const int lds = nkt * 32 * 128 * 2 + 4096;
+  if (lds > 160 * 1024 || n_tok <= 288) return hipErrorInvalidValue;
+  static DeviceKernelSetup setup;
+  int n_cu = 256;
+  if (hipError_t e = setup.ensure((const void*)attn_long_stream_kernel<NCW>, 160 * 1024, &n_cu); e != hipSuccess) return e;
+  const int n_tasks = n_crops * heads;
+  int grid = n_tasks < n_cu ? n_tasks : n_cu;
+  while ((n_tasks + grid - 1) / grid > 496) grid *= 2;           // the redo bitmap holds 496 tasks per workgroup
+  const float scale_log2e = 0.125f * 1.44269504088896340736f;
+  hipLaunchKernelGGL((attn_long_stream_kernel<NCW>), dim3(grid), dim3((NCW + 1) * 64), lds, stream, qkv, out, n_tok, width, heads,
+                     scale_log2e, nkt, n_tasks, out_inv);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
 // Streaming variant for 225..288 tokens (ViT-L/14: 257): the throughput kernel.
 // One persistent workgroup per CU = 7 compute waves + 1 loader wave over a contiguous range of
 // (crop, head) tasks.  K and V of two tasks live in LDS (2 x 72 KiB).  The loader wave fills the buffer of
@@ -394,16 +787,11 @@ hipError_t launch_attn_long(const bf16_t* qkv, bf16_t* out, int n_crops, int n_t
 // Compute waves issue no LDS-DMA, so hipcc keeps counted waits for their Q loads and O stores.
 // O goes through a wave-private 2 KiB LDS image and leaves as whole 128-B rows.
 // ---------------------------------------------------------------------------------------------
-constexpr unsigned SPIN_LIMIT = 1u << 24;
 #ifdef ATTN_STAMPS               // timing experiment (results invalid): per-wave s_memtime ticks per section, written over `out`
 #define STAMP(i_) do { __builtin_amdgcn_sched_barrier(0); stamp[i_] = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define STAMP(i_) do { } while (0)
 #endif
-
-__device__ __forceinline__ unsigned lds_load_u32(const char* p) {
-  return __atomic_load_n((const unsigned*)p, __ATOMIC_RELAXED);
-}
 
 // The last block of a task of 32 b + 1 tokens holds ONE query; as a block it costs 1 / (b + 1) of the kernel, because the exponentials
 // of a block are lane-parallel over QUERIES.  Here the scores are taken the other way round, S = Q . K^T -- the Q fragment the caller
@@ -958,9 +1346,11 @@ hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int 
   static const bool tail_on_loader = [] { const char* e = getenv("CLIPENC_ATTN_TAIL"); return e ? atoi(e) != 0 : true; }();
   static const int qb_cap = [] { const char* e = getenv("CLIPENC_ATTN_QB"); return e ? atoi(e) : 0; }();   // timing experiment (results invalid)
   if (qb_cap > 0 && q_blocks > qb_cap) q_blocks = qb_cap;
+  static const int long_impl = [] { const char* e = getenv("CLIPENC_ATTN_LONG_IMPL"); return e ? atoi(e) : 2; }();   // 1 = attn_long_kernel for every long launch
 #else
   constexpr int impl = 2;
   constexpr bool tail_on_loader = true;
+  constexpr int long_impl = 2;
 #endif
   if (impl == 2 && nkt == 8 && n_crops * heads >= 64) return launch_attn_stream<8, 7, false>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
   if (impl == 2 && nkt == 9 && n_crops * heads >= 64) {
@@ -978,6 +1368,10 @@ hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int 
     case 7: return launch_attn<7>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
     case 8: return launch_attn<8>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
     case 9: return launch_attn<9>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
-    default: return launch_attn_long(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);   // up to 640 tokens (K, V of one head in LDS)
+    default:
+      // every block of >= 64 tasks, up to 608 tokens: the streaming form (K | V + 4 KiB of control words in 160 KiB)
+      if (long_impl == 2 && nkt <= 19 && q_blocks >= nkt && n_crops * heads >= 64)
+        return launch_attn_long_stream(q, o, n_crops, n_tok, width, heads, out_inv, stream);
+      return launch_attn_long(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);   // up to 640 tokens (K, V of one head in LDS)
   }
 }

@@ -929,7 +929,8 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
     }
     if (kind == PK_ATTENTION) {                      // the instantiation ce_attention picks for this token count
       const int nkt = (e->tokens + 31) / 32;
-      if (nkt > 9) *name = "attn_long_kernel<12>";
+      if (nkt > 19) *name = "attn_long_kernel<12>";
+      else if (nkt > 9) *name = "attn_long_stream_kernel<11>";     // (launches of fewer than 64 tasks take attn_long_kernel<12>)
       else if (nkt == 9) *name = (e->tokens & 31) == 1 ? "attn_stream_kernel<9, 7, true>" : "attn_stream_kernel<9, 7, false>";
       else if (nkt == 8) *name = "attn_stream_kernel<8, 7, false>";
       else if (nkt < 8) { static thread_local char buf[32]; snprintf(buf, sizeof buf, "attn_kernel<%d>", nkt); *name = buf; }

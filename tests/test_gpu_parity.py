@@ -176,15 +176,17 @@ def test_attention_streaming_kernel_takes_the_maximum_only_where_it_must(gpu, ca
 
 @pytest.mark.parametrize("case", ["small", "large", "very_negative", "rising", "dominant_key_tile0", "dominant_key_late", "dominant_key_last",
                                   "dominant_then_larger"])
-@pytest.mark.parametrize("n_tok", [577, 640])
-def test_long_attention_single_pass_softmax_rescales_where_it_must(gpu, case, n_tok):
+@pytest.mark.parametrize("n_tok,n_crops", [(577, 3), (640, 3), (577, 20), (353, 17)])
+def test_long_attention_single_pass_softmax_rescales_where_it_must(gpu, case, n_tok, n_crops):
     """The long kernel (289..640 tokens) walks the keys once: a row's reference is the maximum of its FIRST 32 keys and the row's state
     is rescaled only when a later score exceeds it by more than 64 / c (attention.hip).  Cases that never take the branch (small), that
     take it in most rows (large: logits ~ N(0, 25^2) nats), whose scores all lie far below zero, whose maximum rises tile after tile by
     ~60 nats (a rescale at nearly every tile), and one key that dominates every row by thousands of nats -- among the first 32 keys (every
-    other weight underflows to 0), in the middle, as the very last key of the partial tile, and twice (a second, larger one later)."""
+    other weight underflows to 0), in the middle, as the very last key of the partial tile, and twice (a second, larger one later).
+    3 crops x 4 heads (12 tasks) run attn_long_kernel, whose guard sits in every tile; 17 / 20 crops (>= 64 tasks, <= 608 tokens) run the
+    streaming form, attn_long_stream_kernel, which looks at a block's row sums once, flags the block and sweeps it again on the exact path."""
     lib = _lib.load()
-    n_crops, heads = 3, 4
+    heads = 4
     width = heads * 64
     g = torch.Generator().manual_seed(13)
     qkv = torch.randn(n_crops * n_tok, 3 * width, generator=g)
@@ -201,7 +203,7 @@ def test_long_attention_single_pass_softmax_rescales_where_it_must(gpu, case, n_
         k.mul_(0.05).add_((tile.float() * 7.5).view(-1, 1))     # + 7.5 per tile and channel: + 60 nats per tile
     else:
         q.fill_(30.0); k.zero_()
-        pos = {"dominant_key_tile0": [7], "dominant_key_late": [300], "dominant_key_last": [n_tok - 1], "dominant_then_larger": [40, 500]}[case]
+        pos = {"dominant_key_tile0": [7], "dominant_key_late": [300], "dominant_key_last": [n_tok - 1], "dominant_then_larger": [40, min(500, n_tok - 3)]}[case]
         for i, p_ in enumerate(pos):
             k[p_::n_tok] = 30.0 * (i + 1)                       # logit 7200 (and 14400 for the second one)
     qkv = qkv.to(torch.bfloat16)
@@ -218,6 +220,38 @@ def test_long_attention_single_pass_softmax_rescales_where_it_must(gpu, case, n_
     again = torch.empty_like(out)
     _lib.check(lib.clipenc_op_attention(qkv.to(gpu).data_ptr(), again.data_ptr(), n_crops, n_tok, width, heads, _stream(gpu)), "attention")
     assert torch.equal(out, again)
+
+
+@pytest.mark.parametrize("n_tok,scale", [(577, 1.0), (577, 3.0), (353, 1.0), (608, 1.5), (290, 1.0)])
+def test_long_attention_streaming_form_has_the_bits_of_the_resident_form(gpu, n_tok, scale):
+    """attn_long_stream_kernel (>= 64 tasks: key tiles of the next task replace the current task's in place, one guard per block) runs the
+    arithmetic of attn_long_kernel (< 64 tasks: the head's K | V resident, guard per tile) in the same order: the same crops give the same
+    BITS through either, wherever they sit in the batch, as long as no weight passes 2^64 (there the resident form moves a row's reference
+    in the tile it happens, the streaming form only when the block's row sum leaves [2^-100, 2^100], and then on its exact path: both are
+    the same softmax, rounded differently).  Crops 0-3: ordinary logits, compared bit for bit.  Crop 4 carries a key that towers over
+    most rows' first tile by up to ~100 nats: compared within the bf16 rounding of the weights."""
+    lib = _lib.load()
+    heads, base_crops, reps = 4, 5, 8
+    width = heads * 64
+    g = torch.Generator().manual_seed(n_tok)
+    qkv = (torch.randn(base_crops * n_tok, 3 * width, generator=g) * scale).to(torch.bfloat16)
+    qkv[4 * n_tok + 200, width:2 * width] = 40.0                 # crop 4, key 200
+    small = torch.empty((base_crops * n_tok, width), dtype=torch.bfloat16, device=gpu)
+    _lib.check(lib.clipenc_op_attention(qkv.to(gpu).data_ptr(), small.data_ptr(), base_crops, n_tok, width, heads, _stream(gpu)), "attention")
+    big_in = qkv.repeat(reps, 1).to(gpu)                          # 40 crops x 4 heads = 160 tasks
+    big = torch.full((reps * base_crops * n_tok, width), float("nan"), dtype=torch.bfloat16, device=gpu)
+    _lib.check(lib.clipenc_op_attention(big_in.data_ptr(), big.data_ptr(), reps * base_crops, n_tok, width, heads, _stream(gpu)), "attention")
+    torch.cuda.synchronize()
+    assert torch.isfinite(big.float()).all()
+    plain = 4 * n_tok                                             # rows of crops 0-3
+    # a weight beyond 2^64 needs a logit 64 / (0.125 log2 e) = 355 above the row's first-tile maximum in q.k units: |q.k| <= 64 * (4.5 scale)^2
+    bitwise = scale < 2.0
+    for i in range(reps):
+        rep = big[i * base_crops * n_tok:(i + 1) * base_crops * n_tok]
+        if bitwise:
+            assert torch.equal(rep[:plain], small[:plain]), f"replica {i}"
+        assert (rep.float() - small.float()).abs().max().item() < 0.03, f"replica {i}"
+        assert torch.equal(rep, big[:base_crops * n_tok]), f"replica {i} differs from replica 0"   # position in the batch changes no bit
 
 
 def test_attention_large_logits_do_not_overflow(gpu):
