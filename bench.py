@@ -366,13 +366,14 @@ def kernel_source_sha(kernel_name):
     return h.hexdigest()[:16]
 
 
-LEGACY_PROBLEM = "rows=526336,width=1024,mlp=4096"   # what every profile directory without `_meta.problem` was taken on (ViT-L/14, 2 048 crops)
+LEGACY_PROBLEM = "rows=526336,width=1024,mlp=4096,dtype=bf16"   # what a profile directory without `_meta.problem` is taken to be (ViT-L/14, 2 048 crops, bf16)
 
 
-def problem_key(cfg, crops):
-    """The problem a kernel's traffic constant belongs to: token rows of the batch and the tower's GEMM widths (M, N, K of every block
-    GEMM follow from them).  A constant taken on another problem is not quoted."""
-    return f"rows={crops * cfg.tokens},width={cfg.width},mlp={cfg.mlp_dim}"
+def problem_key(cfg, crops, dtype="bf16"):
+    """The problem a kernel's traffic constant belongs to: token rows of the batch, the tower's GEMM widths (M, N, K of every block
+    GEMM follow from them) and the arithmetic of the block GEMMs (in the e4m3 tower the attention kernel of the same name writes e4m3
+    rows).  A constant taken on another problem is not quoted."""
+    return f"rows={crops * cfg.tokens},width={cfg.width},mlp={cfg.mlp_dim},dtype={dtype}"
 
 
 def pmc_traffic(kernel_name, problem=LEGACY_PROBLEM):
@@ -431,7 +432,7 @@ def per_kernel_table(prof, prof_steps, cfg, crops, fp8=False):
     """roofline.per_kernel: for QKV / attention / out-proj / FC1 / FC2 the launches of the profiled pass priced against the dense MFMA
     peak of their arithmetic type, and the committed L2-miss traffic of that kernel over its algorithmic bytes."""
     names = list(prof)
-    problem = problem_key(cfg, crops)
+    problem = problem_key(cfg, crops, "fp8" if fp8 else "bf16")
 
     def find(*subs, shape=None):
         for k in names:
@@ -887,7 +888,7 @@ def main():
                     "BASELINE.json configs[1]+[2]: ViT-L/14 @224 bf16 encode")
         if not headline:
             workload = f"NOT the headline: {args.model} ({cfg.tokens} tokens, the reference's default model) {args.dtype} encode"
-        problem = problem_key(cfg, n_img * CROPS_PER_IMAGE)
+        problem = problem_key(cfg, n_img * CROPS_PER_IMAGE, args.dtype)
         line = {
             "metric": "images/sec (4 crops each) ViT-L/14 encode+score @ bs512" if headline else f"images/sec (4 crops each) {args.model} encode+score @ bs{n_img}",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
