@@ -745,7 +745,7 @@ def main():
                     help="BASELINE.json configs[3]: run a whole N-image job (sharded over the ranks, crops generated on the device "
                          "per batch, one gather at the end) instead of the resident-batch step loop; use with --dtype fp8")
     ap.add_argument("--job-seed", type=int, default=20240, help="base seed of the job's per-rank counter-based generators")
-    ap.add_argument("--model", default=MODEL, choices=["ViT-L-14", "ViT-L-14-336"],
+    ap.add_argument("--model", default=MODEL, choices=["ViT-L-14", "ViT-L-14-336", "ViT-H-14"],
                     help="the tower of the timed step: ViT-L-14 = the headline (BASELINE.json metric); ViT-L-14-336 = the reference's default "
                          "model as the PRIMARY workload (tools/profile_round.sh takes its rocprofv3 passes this way; secondary block skipped)")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
@@ -781,8 +781,9 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    cfg = vit_config.ARCHS[args.model]
+    cfg = vit_config.config_for(args.model + "/laion2b_s32b_b79k") if args.model == "ViT-H-14" else vit_config.ARCHS[args.model]   # (ViT-H-14 exists with laion tags only: erf-GELU)
     headline = args.model == MODEL
+    REG_SIZES[0] = CROPS_PER_IMAGE * cfg.embed_dim            # the regressor's input is the tower's four embeddings (3 072 for ViT-L, 4 096 for ViT-H)
     sd = vit_config.seeded_state_dict(cfg, 0)               # random-init weights of the named architecture
     Ws, bs = fc_weights(1)
     vit = HipViT(cfg, sd, dev, chunk_crops=args.chunk or None, precision=args.dtype)
@@ -899,7 +900,7 @@ def main():
             "images_per_s_per_rank": {"min": min(r["images_per_s"] for r in ranks), "max": max(r["images_per_s"] for r in ranks)},
             "t_gather_ms": t_gather_ms,
             "config": {"workload": f"{workload} of {n_img} images x 4 crops per GPU "
-                                   "+ fused fp32 regressor 3072-264-128-64-1, seeded random-init weights, crops resident in HBM",
+                                   f"+ fused fp32 regressor {REG_SIZES[0]}-264-128-64-1, seeded random-init weights, crops resident in HBM",
                        "images_per_gpu": n_img, "crops_per_image": CROPS_PER_IMAGE, "parallelism": f"image-sharded x{world}",
                        "chunk_crops": args.chunk or n_img * CROPS_PER_IMAGE, "problem": problem},
             "end_to_end": {"tflops": round(value * flop_per_image / 1e12, 1),

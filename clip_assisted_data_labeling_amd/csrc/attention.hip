@@ -13,6 +13,7 @@
 // as the next MFMA's operand"); V^T comes from the hardware-transposing LDS read.
 // The whole key range fits the register file (<= 9 tiles x 16 fp32), so the softmax is exact
 // two-pass (true row max), not an online rescale.
+#include <math.h>
 #include <stdlib.h>
 
 #include <type_traits>
@@ -186,6 +187,153 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Head dim 80 (ViT-H-14: width 1280, 16 heads), up to 288 tokens: the attn_kernel scheme -- one workgroup of four waves per (crop, head),
+// K and V of the head staged once, exact two-pass softmax with every score tile in registers -- on LDS rows of 256 B (160 B used:
+// ten 16-B chunks; chunk ch of row r sits at ch ^ (((r & 3) << 2) | ((r >> 2) & 3)), the image that serves the row-wise K reads and the
+// transposing V reads without bank conflicts: guide T10 (b)).  Five k steps of 16 for the scores; O^T in three 32-row tiles of d, the upper
+// half of the third (d = 80 .. 95) reads zero columns and is not stored.  (The score tiles of 288 keys + three output
+// tiles are ~230 registers), two waves per SIMD: a correct path for the wider tower, not a tuned one.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz256(int row, int chunk) { return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
+
+#ifndef HD_WAVES
+#define HD_WAVES 8                 // two waves per SIMD (the kernel needs ~230 registers)
+#endif
+template <int NKT, int HD>
+__global__ __launch_bounds__(HD_WAVES * 64, HD_WAVES / 4) void attn_hd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                         int n_tok, int width, int heads, float scale_log2e,
+                                                         const float* __restrict__ out_inv, int q_blocks) {
+  static_assert(HD % 16 == 0 && HD > 64 && HD <= 96, "five or six k steps, three output tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ROWS = NKT * 32, KS = HD / 16, CH = HD / 8;     // k steps; 16-B chunks per row
+  char* Ks = smem;
+  char* Vs = smem + ROWS * 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int crop = blockIdx.x / heads, head = blockIdx.x % heads;
+  const size_t ld = (size_t)3 * width;
+  const bf16_t* base = qkv + (size_t)crop * n_tok * ld + head * HD;
+
+  for (int idx = tid; idx < ROWS * 12; idx += HD_WAVES * 64) {             // chunks 0 .. CH-1: data; CH .. 11: the zero columns the third d tile reads
+    const int row = idx / 12, c = idx - row * 12;
+    uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
+    if (row < n_tok && c < CH) {
+      const bf16_t* g = base + (size_t)row * ld + c * 8;
+      kv = *(const uint4*)(g + width);
+      vv = *(const uint4*)(g + 2 * width);
+    }
+    *(uint4*)(Ks + swz256(row, c)) = kv;
+    *(uint4*)(Vs + swz256(row, c)) = vv;
+  }
+  __syncthreads();
+
+  const int r = lane & 31, h = lane >> 5;
+  const int n_qb = min((n_tok + 31) >> 5, q_blocks);
+  for (int qb = wave; qb < n_qb; qb += HD_WAVES) {
+    const int q = qb * 32 + r;
+    const bf16_t* qrow = base + (size_t)min(q, n_tok - 1) * ld;
+    bf16x8_t qf[KS];
+#pragma unroll
+    for (int st = 0; st < KS; ++st) qf[st] = *(const bf16x8_t*)(qrow + st * 16 + h * 8);
+    f32x16_t s[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s[kt][e] = 0.f;
+#pragma unroll
+      for (int st = 0; st < KS; ++st) {
+        const bf16x8_t kf = *(const bf16x8_t*)(Ks + swz256(kt * 32 + r, st * 2 + h));
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[st], s[kt], 0, 0, 0);
+      }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (kt == NKT - 1) {
+          const int key = kt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (key >= n_tok) s[kt][e] = -INFINITY;
+        }
+        mx = fmaxf(mx, s[kt][e]);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float moff = mx * scale_log2e;
+    f32x16_t o[3], lacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; o[2][e] = 0.f; lacc[e] = 0.f; }
+    const u32x4_t ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_w);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        if (kt < NKT - 1 || s2 == 0 || kt * 32 + 16 < n_tok) {   // wave-uniform; skips an all-padding k step
+          float pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) pv[j] = __builtin_amdgcn_exp2f(fmaf(s[kt][s2 * 8 + j], scale_log2e, -moff));
+          const u32x4_t pw = {cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]), cvt_pk_bf16(pv[6], pv[7])};
+          const bf16x8_t pf = __builtin_bit_cast(bf16x8_t, pw);
+          lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
+          const int key0 = kt * 32 + s2 * 16 + 4 * h;
+#pragma unroll
+          for (int dt = 0; dt < 3; ++dt) {
+            const int i = lane & 15, qq = i >> 2, pp = i & 3, g1 = (lane >> 4) & 1;
+            const int chunk = dt * 4 + g1 * 2 + (pp >> 1);        // 16-B chunk of d = 32 dt + 16 g1 + 4 pp .. + 3
+            const int ra = key0 + qq, rb = key0 + 8 + qq;
+            s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(Vs + swz256(ra, chunk) + (pp & 1) * 8));
+            s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(Vs + swz256(rb, chunk) + (pp & 1) * 8));
+            typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+            s16x8_t vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vv), pf, o[dt], 0, 0, 0);
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const float inv = 1.0f / lacc[0];
+    if (q < n_tok && out_inv) {
+      uint8_t* orow = (uint8_t*)out + ((size_t)crop * n_tok + q) * width + head * HD;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int col = dt * 32 + g4 * 8 + h * 4;
+          if (col < HD) {
+            const f32x4_t is = *(const f32x4_t*)(out_inv + head * HD + col);
+            *(int*)(orow + col) = pack_fp8x4(o[dt][g4 * 4 + 0] * inv * is[0], o[dt][g4 * 4 + 1] * inv * is[1],
+                                             o[dt][g4 * 4 + 2] * inv * is[2], o[dt][g4 * 4 + 3] * inv * is[3]);
+          }
+        }
+    } else if (q < n_tok) {
+      bf16_t* orow = out + ((size_t)crop * n_tok + q) * width + head * HD;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int col = dt * 32 + g4 * 8 + h * 4;
+          if (col < HD)
+            *(uint2*)(orow + col) = uint2{pack_bf16x2(o[dt][g4 * 4 + 0] * inv, o[dt][g4 * 4 + 1] * inv),
+                                          pack_bf16x2(o[dt][g4 * 4 + 2] * inv, o[dt][g4 * 4 + 3] * inv)};
+        }
+    }
+  }
+}
+
+template <int NKT, int HD>
+hipError_t launch_attn_hd(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
+                          const float* out_inv, int q_blocks, hipStream_t stream) {
+  const int lds = NKT * 32 * 256 * 2;
+  static DeviceKernelSetup setup;
+  if (hipError_t e = setup.ensure((const void*)attn_hd_kernel<NKT, HD>, lds, nullptr); e != hipSuccess) return e;
+  const float scale_log2e = 1.44269504088896340736f / sqrtf((float)HD);
+  hipLaunchKernelGGL((attn_hd_kernel<NKT, HD>), dim3(n_crops * heads), dim3(HD_WAVES * 64), lds, stream, qkv, out, n_tok, width, heads, scale_log2e, out_inv,
+                     q_blocks);
+  return hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------------------------
 // Long-sequence kernel (289..640 tokens, e.g. ViT-L-14-336: 577 -- the reference's default model,
@@ -1337,10 +1485,25 @@ hipError_t launch_attn(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, i
 hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int width, int heads,
                         const float* out_inv, int q_blocks, hipStream_t stream) {
   if (q_blocks < 1) q_blocks = 1 << 20;                         // all query blocks
-  if (width != heads * 64 || n_tok < 1 || n_crops < 1) return hipErrorInvalidValue;
+  if (heads < 1 || width % heads != 0 || n_tok < 1 || n_crops < 1) return hipErrorInvalidValue;
   const int nkt = (n_tok + 31) / 32;
   const bf16_t* q = (const bf16_t*)qkv;
   bf16_t* o = (bf16_t*)out;
+  if (width == heads * 80) {                                      // ViT-H-14: its own kernel family, up to 288 tokens
+    switch (nkt) {
+      case 1: return launch_attn_hd<1, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+      case 2: return launch_attn_hd<2, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+      case 3: return launch_attn_hd<3, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+      case 4: return launch_attn_hd<4, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+      case 5: return launch_attn_hd<5, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+      case 6: return launch_attn_hd<6, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+      case 7: return launch_attn_hd<7, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+      case 8: return launch_attn_hd<8, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+      case 9: return launch_attn_hd<9, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
+      default: return hipErrorInvalidValue;
+    }
+  }
+  if (width != heads * 64) return hipErrorInvalidValue;
 #ifdef CLIPENC_DIAG                         // developer A/B: 0 = one workgroup per (crop, head) for every shape; CLIPENC_ATTN_TAIL=0: the odd query as a block
   static const int impl = [] { const char* e = getenv("CLIPENC_ATTN_IMPL"); return e ? atoi(e) : 2; }();
   static const bool tail_on_loader = [] { const char* e = getenv("CLIPENC_ATTN_TAIL"); return e ? atoi(e) != 0 : true; }();

@@ -267,6 +267,9 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
   const clipenc_config& g = e->cfg;
   const int T = c * e->tokens, P = c * (e->tokens - 1);
   const int parts = g.width / 256;
+  // what a LayerNorm-folded consumer is handed: the producer's parts as they are (its LDS layout holds four), or -- wider towers -- ONE part,
+  // the producer's added up by a small pass behind it (fold_stats)
+  const int cparts = parts > 4 ? 1 : parts;
   const int Tp = (int)align_up((size_t)T, 256);
   Profiler& pf = e->prof;
   const double dT = (double)T, dD = (double)g.width;
@@ -308,6 +311,9 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     pf.end(st);
     *done = err == hipSuccess;
     return err;
+  };
+  auto fold_stats = [&](float* stats, int ld, int n) -> hipError_t {
+    return parts > 4 ? ce_combine_row_stats(stats, ld, parts, n, st) : hipSuccess;
   };
   pf.begin(PK_PATCHIFY, 0.0, st);
   HIP_TRY(ce_patchify(crops, in_dtype, e->a_patch, c, g.image_size, g.patch, e->kpad, e->pix_mean, e->pix_std, st));
@@ -539,12 +545,13 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       o.ticket = ticket();
       pf.begin(PK_GEMM_RESID, 2.0 * c * dD * dD, st, PK_SUB_OUT);
       HIP_TRY(ce_gemm_nt(o, CE_DT_BF16, EPI_RESID, st));
+      HIP_TRY(fold_stats(e->stats_a, Tpc, c));
       pf.end(st);
       // h[cls] = act(LN2(x[cls]) . Wfc^T + b)   (compact [c][mlp])
       GemmParams f{};
       f.A = e->x; f.lda = stride * Dw; f.W = L.w_fc; f.ldw = Dw; f.M = c; f.N = g.mlp_dim; f.K = Dw;
       f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
-      f.stats_in = e->stats_a; f.stats_in_parts = parts; f.stats_ld = Tpc; f.inv_width = 1.0f / Dw; f.eps = g.ln_eps; f.act = g.act;
+      f.stats_in = e->stats_a; f.stats_in_parts = cparts; f.stats_ld = Tpc; f.inv_width = 1.0f / Dw; f.eps = g.ln_eps; f.act = g.act;
       f.ticket = ticket();
       pf.begin(PK_GEMM_FC1, 2.0 * c * dD * g.mlp_dim, st);
       HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
@@ -579,12 +586,13 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       o.ticket = ticket();
     pf.begin(PK_GEMM_RESID, 2.0 * dT * dD * dD, st, PK_SUB_OUT);
     HIP_TRY(ce_gemm_nt(o, CE_DT_BF16, EPI_RESID, st));
+    HIP_TRY(fold_stats(e->stats_a, Tp, T));
     pf.end(st);
     // K6: h = act(LN2(x) . Wfc^T + b)
     GemmParams f{};
     f.A = e->x; f.lda = g.width; f.W = L.w_fc; f.ldw = g.width; f.M = T; f.N = g.mlp_dim; f.K = g.width;
     f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
-    f.stats_in = e->stats_a; f.stats_in_parts = parts; f.stats_ld = Tp; f.inv_width = 1.0f / g.width; f.eps = g.ln_eps; f.act = g.act;
+    f.stats_in = e->stats_a; f.stats_in_parts = cparts; f.stats_ld = Tp; f.inv_width = 1.0f / g.width; f.eps = g.ln_eps; f.act = g.act;
       f.ticket = ticket();
     pf.begin(PK_GEMM_FC1, 2.0 * dT * dD * g.mlp_dim, st);
     HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
@@ -596,8 +604,9 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       r.ticket = ticket();
     pf.begin(PK_GEMM_RESID, 2.0 * dT * dD * g.mlp_dim, st, PK_SUB_FC2);
     HIP_TRY(ce_gemm_nt(r, CE_DT_BF16, EPI_RESID, st));
+    HIP_TRY(fold_stats(e->stats_b, Tp, T));
     pf.end(st);
-    stats_in = e->stats_b; stats_parts = parts;
+    stats_in = e->stats_b; stats_parts = cparts;
   }
   return 0;
 }
@@ -623,16 +632,16 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
   const clipenc_config g = *cfg;
   if (g.width <= 0 || g.width % 256 != 0) return fail("width %d must be a positive multiple of 256", g.width);
   if (g.mlp_dim <= 0 || g.mlp_dim % 256 != 0) return fail("mlp_dim %d must be a positive multiple of 256", g.mlp_dim);
-  if (g.heads * 64 != g.width) return fail("only head dim 64 is built (width %d, heads %d)", g.width, g.heads);
+  if (g.heads < 1 || (g.heads * 64 != g.width && g.heads * 80 != g.width))
+    return fail("head dims 64 and 80 are built (width %d, heads %d)", g.width, g.heads);
   if (g.patch <= 0 || g.image_size % g.patch != 0) return fail("image_size %d not divisible by patch %d", g.image_size, g.patch);
   if (g.embed_dim <= 0 || g.embed_dim > 1024) return fail("embed_dim %d out of range (1..1024)", g.embed_dim);
-  if (g.width > 1024)
-    return fail("width %d > 1024 not built: the LayerNorm-folded GEMM keeps one row-statistics part per 256 columns of the "
-                "residual stream and its LDS layout holds 4 parts (ViT-B = 768, ViT-L = 1024)", g.width);
+  if (g.width > 2048) return fail("width %d > 2048 not built (LayerNorm / head kernels)", g.width);
   if (g.layers < 1) return fail("layers %d < 1", g.layers);
   if (g.act != CLIPENC_ACT_QUICK_GELU && g.act != CLIPENC_ACT_GELU_ERF) return fail("unknown activation %d", g.act);
   const int grid = g.image_size / g.patch, tokens = grid * grid + 1;
   if (tokens > 640) return fail("%d tokens > 640: K and V of one head no longer fit the 160 KiB LDS", tokens);
+  if (g.heads * 80 == g.width && tokens > 288) return fail("%d tokens > 288 at head dim 80: only the one-pass attention kernel is built for it", tokens);
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail("device %d out of range (%d visible)", device, ndev);
@@ -929,7 +938,8 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
     }
     if (kind == PK_ATTENTION) {                      // the instantiation ce_attention picks for this token count
       const int nkt = (e->tokens + 31) / 32;
-      if (nkt > 19) *name = "attn_long_kernel<12>";
+      if (e->cfg.heads * 80 == e->cfg.width) { static thread_local char hb[32]; snprintf(hb, sizeof hb, "attn_hd_kernel<%d, 80>", nkt); *name = hb; }
+      else if (nkt > 19) *name = "attn_long_kernel<12>";
       else if (nkt > 9) *name = "attn_long_stream_kernel<11>";     // (launches of fewer than 64 tasks take attn_long_kernel<12>)
       else if (nkt == 9) *name = (e->tokens & 31) == 1 ? "attn_stream_kernel<9, 7, true>" : "attn_stream_kernel<9, 7, false>";
       else if (nkt == 8) *name = "attn_stream_kernel<8, 7, false>";

@@ -468,6 +468,23 @@ __global__ void gather_row_stats_kernel(const float2* __restrict__ in, int in_ld
   if (i < n) out[(size_t)part * out_ld + i] = in[(size_t)part * in_ld + (size_t)i * row_stride];
 }
 
+// Towers wider than 1024 (ViT-H-14: five 256-column parts): the LayerNorm-folded GEMM's LDS layout holds four parts per row, so the
+// producer's parts are added up here, in a fixed order, into part 0 and the consumer is handed one part.
+__global__ void combine_row_stats_kernel(float2* __restrict__ stats, int ld, int parts, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float2 a = stats[i];
+  for (int p = 1; p < parts; ++p) { const float2 b = stats[(size_t)p * ld + i]; a.x += b.x; a.y += b.y; }
+  stats[i] = a;
+}
+
+hipError_t ce_combine_row_stats(float* stats, int ld, int parts, int n, hipStream_t stream) {
+  if (n < 1 || parts < 1) return hipErrorInvalidValue;
+  if (parts == 1) return hipSuccess;
+  hipLaunchKernelGGL(combine_row_stats_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (float2*)stats, ld, parts, n);
+  return hipGetLastError();
+}
+
 hipError_t ce_gather_row_stats(const float* in, int in_ld, float* out, int out_ld, int parts, int n, int row_stride, hipStream_t stream) {
   if (n < 1 || parts < 1) return hipErrorInvalidValue;
   hipLaunchKernelGGL(gather_row_stats_kernel, dim3((n + 255) / 256, parts), dim3(256), 0, stream, (const float2*)in, in_ld, (float2*)out,

@@ -70,7 +70,7 @@ typedef __attribute__((ext_vector_type(2))) short s16x2_t;
 template <int ACT>
 __device__ __forceinline__ float act_apply_t(float u) {
   if constexpr (ACT == CE_ACT_QUICK_GELU) return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * u));
-  else if constexpr (ACT == CE_ACT_GELU_ERF) return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
+  else if constexpr (ACT == CE_ACT_GELU_ERF) return ce_gelu_erf(u);
   else return u;
 }
 
@@ -650,6 +650,13 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
             asm volatile("" : "+v"(den[0]), "+v"(den[1]), "+v"(den[2]), "+v"(den[3]));
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = F8_SAT(a[e] * den[e]);
+          } else if constexpr (ACT == CE_ACT_GELU_ERF) {
+            f32x4_t u4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) u4[e] = acc[mt][nt][g * 4 + e] * sa[mt];
+            u4 = ce_gelu_erf4(u4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = F8_SAT(u4[e] * is[e]);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = F8_SAT(act_apply_t<ACT>(acc[mt][nt][g * 4 + e] * sa[mt]) * is[e]);

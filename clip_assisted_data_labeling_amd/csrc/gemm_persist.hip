@@ -55,7 +55,7 @@ template <int ACT>
 __device__ __forceinline__ float act_apply_t(float u) {
   // compile-time activation: a run-time `act` makes hipcc evaluate BOTH activations per element and select
   if constexpr (ACT == CE_ACT_QUICK_GELU) return u * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930156f * u));
-  else if constexpr (ACT == CE_ACT_GELU_ERF) return 0.5f * u * (1.0f + erff(u * 0.70710678118654752f));
+  else if constexpr (ACT == CE_ACT_GELU_ERF) return ce_gelu_erf(u);
   else return u;
 }
 
@@ -585,6 +585,8 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
 #pragma unroll
             for (int e = 0; e < 4; ++e) t[e] = __builtin_amdgcn_rcpf(t[e]);
             v = v * t;
+          } else if constexpr (ACT == CE_ACT_GELU_ERF) {
+            v = ce_gelu_erf4(v);
           } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = act_apply_t<ACT>(v[e]);

@@ -26,6 +26,8 @@ hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float*
                            hipStream_t stream);
 // out[part][i] = in[part][i * row_stride] for i < n (float2 statistics of every row_stride-th row), parts x n
 hipError_t ce_gather_row_stats(const float* in, int in_ld, float* out, int out_ld, int parts, int n, int row_stride, hipStream_t stream);
+// stats[0][i] += stats[1][i] + ... + stats[parts - 1][i] (in that order), i < n: towers wider than 1024 hand the LayerNorm-folded GEMM ONE part
+hipError_t ce_combine_row_stats(float* stats, int ld, int parts, int n, hipStream_t stream);
 hipError_t ce_clock_probe(unsigned long long* out2, int spin_ticks, hipStream_t stream);   // {shader cycles, 100 MHz ticks}
 // n_cu workgroups x 8 waves x iters x (16 bf16 16x16x32 | 8 fp8 32x32x64) MFMAs on operands read once from a 32-KiB buffer
 hipError_t ce_mfma_stream(const void* operands_32k, int fp8, float* sink, long long iters, int n_cu, hipStream_t stream);

@@ -67,10 +67,15 @@ ARCHS: Dict[str, ViTConfig] = {
     "ViT-B-16": ViTConfig(224, 16, 768, 12, 12, 3072, 512),
     "ViT-L-14": ViTConfig(224, 14, 1024, 24, 16, 4096, 768),
     "ViT-L-14-336": ViTConfig(336, 14, 1024, 24, 16, 4096, 768),
+    # open_clip's ViT-H-14 (laion2b tags: erf-GELU through config_for): width 1280 = 16 heads of 80, five 256-column statistics parts;
+    # bf16 only (its 5 120-wide MLP is past what the e4m3 tower is built for)
+    "ViT-H-14": ViTConfig(224, 14, 1280, 32, 16, 5120, 1024),
     # small shapes used by the parity tests (not open_clip names)
     "ViT-tiny-test": ViTConfig(28, 14, 256, 2, 4, 512, 32),
     "ViT-small-test": ViTConfig(98, 14, 256, 3, 4, 1024, 64),
     "ViT-long-test": ViTConfig(336, 14, 256, 2, 4, 512, 32),      # 577 tokens like ViT-L-14-336
+    "ViT-H-tiny-test": ViTConfig(28, 14, 1280, 2, 16, 5120, 64),  # head dim 80, five statistics parts, 5 tokens
+    "ViT-H-mid-test": ViTConfig(98, 14, 1280, 3, 16, 5120, 64),   # ... 50 tokens: two key tiles, a partial one
 }
 
 

@@ -335,6 +335,9 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["erf"]:          # only the fixture added in round 4 (needs transformers, not the reference)
         make_encoder("ViT-small-test", 5, seed=1, in_seed=2, pretrained="laion2b_s32b_b82k")
         sys.exit(0)
+    if sys.argv[1:] == ["vit_h"]:        # round 6: ViT-H-14 at full size (1280 wide x 32 blocks, head dim 80, erf-GELU; ~2 min of CPU, 8 GB)
+        make_encoder("ViT-H-14", 2, seed=15, in_seed=16, pretrained="laion2b_s32b_b79k")
+        sys.exit(0)
     if sys.argv[1:] == ["full"]:         # round 5: the full-size towers (needs transformers, not the reference; ~1 min of CPU, 5 GB)
         make_encoder("ViT-L-14", 4, seed=11, in_seed=12)
         make_encoder("ViT-L-14-336", 2, seed=13, in_seed=14)

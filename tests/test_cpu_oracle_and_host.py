@@ -75,6 +75,12 @@ def test_vit_oracle_at_full_size_matches_the_transformers_vectors(golden_dir):
     assert np.abs(g["emb"] - g["emb_transformers"]).max() < 1e-5 and float(g["oracle_vs_transformers_max_abs"]) < 1e-5
     g336 = np.load(os.path.join(golden_dir, "encoder_ViT-L-14-336.npz"))
     assert golden_cfg(g336).tokens == 577 and np.abs(g336["emb"] - g336["emb_transformers"]).max() < 1e-5
+    # ViT-H-14 (`make_golden.py vit_h`: 1280 wide x 32 blocks, 16 heads of 80, erf-GELU): the committed vectors only -- a crop of it
+    # through the oracle is the GPU suite's business (tests/test_gpu_vit_h.py)
+    gh = np.load(os.path.join(golden_dir, "encoder_ViT-H-14-erf.npz"))
+    ch = golden_cfg(gh)
+    assert (ch.width, ch.layers, ch.heads, ch.mlp_dim, ch.embed_dim, ch.act) == (1280, 32, 16, 5120, 1024, vit_config.ACT_GELU_ERF)
+    assert np.abs(gh["emb"] - gh["emb_transformers"]).max() < 1e-5 and float(gh["oracle_vs_transformers_max_abs"]) < 1e-5
 
 
 def test_dedup_oracle_matches_reference_golden(golden_dir):
