@@ -888,7 +888,8 @@ def main():
                     "(per-token x per-channel scales), bf16 attention/residual" if fp8 else
                     "BASELINE.json configs[1]+[2]: ViT-L/14 @224 bf16 encode")
         if not headline:
-            workload = f"NOT the headline: {args.model} ({cfg.tokens} tokens, the reference's default model) {args.dtype} encode"
+            what = "the reference's default model" if args.model == "ViT-L-14-336" else "open_clip's ViT-H-14: width 1280, 16 heads of 80, erf-GELU"
+            workload = f"NOT the headline: {args.model} ({cfg.tokens} tokens, {what}) {args.dtype} encode"
         problem = problem_key(cfg, n_img * CROPS_PER_IMAGE, args.dtype)
         line = {
             "metric": "images/sec (4 crops each) ViT-L/14 encode+score @ bs512" if headline else f"images/sec (4 crops each) {args.model} encode+score @ bs{n_img}",

@@ -64,6 +64,33 @@ def test_single_gpu_line_has_the_contract_keys(gpu):
     assert g8.get("images") == 4096 and g8["pt_files_written"] == 4096 and g8["value"] > g["value"] and "fp8" in g8["workload"], g8
 
 
+def test_single_gpu_line_secondary_head_and_problem_key(gpu):
+    """Round 6: the secondary rates once more right behind `value` (a truncated tail still carries them) and the problem a traffic
+    constant is quoted for; a committed constant is never quoted for another problem (32 images are not the profiled 512)."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--images", "32", "--no-cpu-baseline",
+                        "--secondary", "fp8,dedup"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_json(p.stdout)
+    keys = list(d)
+    assert keys[:4] == ["metric", "value", "unit", "secondary_head"] and d["secondary_head"]["fp8_step"] == d["secondary"]["fp8_step"]["value"]
+    assert d["config"]["problem"] == f"rows={32 * 4 * 257},width=1024,mlp=4096,dtype=bf16"
+    assert d["roofline"]["traffic"] is None and all(r["traffic_ratio"] is None for r in d["roofline"]["per_kernel"].values())
+
+
+@pytest.mark.parametrize("model,tokens,attn", [("ViT-L-14-336", 577, "attn_long"), ("ViT-H-14", 257, "attn_hd_kernel<9, 80>")])
+def test_other_towers_as_the_primary_workload(gpu, model, tokens, attn):
+    """`bench.py --model M`: another tower as the timed step (what `tools/profile_round.sh <tag> bf16 M` profiles): its own metric label, no
+    headline-only blocks, the attention row from the kernel that tower launches."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--model", model, "--steps", "1", "--warmup", "1", "--images", "24"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = _last_json(p.stdout)
+    assert model in d["metric"] and "NOT the headline" in d["config"]["workload"] and "secondary" not in d and "cpu_baseline" not in d
+    assert d["config"]["problem"].startswith(f"rows={24 * 4 * tokens},") and d["value"] > 0
+    assert d["roofline"]["per_kernel"]["attention"]["kernel"].startswith(attn)
+    assert all(r["traffic_ratio"] is None or r["traffic_ratio"] >= 0.99 for r in d["roofline"]["per_kernel"].values())
+
+
 def test_two_ranks_report_the_whole_job(gpu):
     env = dict(os.environ, BENCH_DEVICE="0", BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
