@@ -411,12 +411,22 @@ def traffic_source(kernel_name, problem=LEGACY_PROBLEM):
     return PMC_SOURCE.get((kernel_name, problem))
 
 
-def algorithmic_bytes_per_step(cfg, crops):
-    """ALGORITHMIC bytes one step moves per kernel kind (every operand read once, every result written once; bf16 activations and
-    weights, fp32 row statistics left out): what `roofline.per_kernel[*].traffic_ratio` divides the measured L2-miss bytes by.
+def algorithmic_bytes_per_step(cfg, crops, fp8=False):
+    """ALGORITHMIC bytes one step moves per kernel kind (every operand read once, every result written once; fp32 row statistics left
+    out): what `roofline.per_kernel[*].traffic_ratio` divides the measured L2-miss bytes by.  bf16 tower: bf16 activations and weights.
+    e4m3 tower (fused form): the GEMM operands are one byte per element -- QKV / FC1 read the residual stream's e4m3 copy, attention writes
+    e4m3 rows, FC1 writes e4m3 hidden rows, the residual GEMMs read them, read and write the bf16 residual rows and write their e4m3 copy.
     The tower's last block runs on the class-token rows only, its attention without K and V."""
     T, D, M, L = crops * cfg.tokens, cfg.width, cfg.mlp_dim, cfg.layers
     full = L - 1
+    if fp8:
+        return {
+            "qkv": full * (T * D + 3 * D * D + T * 3 * D * 2) + (2 * crops * D + D * D),
+            "attention": full * (T * 3 * D * 2 + T * D),
+            "out_proj": full * (T * D + D * D + 2 * T * D * 2 + T * D) + (crops * D + D * D + 2 * crops * D * 2 + crops * D),
+            "fc1": full * (T * D + M * D + T * M) + (crops * D + M * D + crops * M),
+            "fc2": full * (T * M + D * M + 2 * T * D * 2 + T * D) + (crops * M + D * M + 2 * crops * D * 2 + crops * D),
+        }
     return {
         "qkv": full * (T * D * 2 + 3 * D * D * 2 + T * 3 * D * 2) + (2 * crops * D * 2 + D * D * 2),
         # (the L - 1 streaming launches alone; the last block's class-token attention -- five small launches, cls_attention.hip --
@@ -447,7 +457,7 @@ def per_kernel_table(prof, prof_steps, cfg, crops, fp8=False):
             "attention": next((k for k in names if k.startswith("attn_") and prof[k][1] > 0), None),
             "out_proj": find(shape="out_proj"), "fc2": find(shape="fc2"),
             "fc1": (find("gemm_fp8_kernel<2") if fp8 else (find("gemm_persist_kernel<2, 0>") or find("gemm_persist_kernel<2, 1>")))}
-    alg = algorithmic_bytes_per_step(cfg, crops)
+    alg = algorithmic_bytes_per_step(cfg, crops, fp8)
     out = {}
     for key, k in rows.items():
         if k is None or prof[k][1] == 0 or prof[k][0] <= 0:
