@@ -32,6 +32,11 @@
 #include "common.h"
 #include "gemm.h"
 
+#ifndef F8_NT_STORES             // 1: the QKV / FC1 outputs (written once, read by another kernel) leave with the streaming cache policy, so that the
+                                 // 2-4 MB an XCD round writes stop evicting the e4m3 A panels (2 MB) its next round re-reads: QKV 1.703 -> 1.665 ms, FC1
+                                 // 2.242 -> 2.207, e4m3 step +0.9 % (three interleaved pairs; 0: plain stores)
+#define F8_NT_STORES 1
+#endif
 #ifndef F8_MMA_ORDER
 #define F8_MMA_ORDER 1
 #endif
@@ -672,7 +677,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
           const int row = k * 16 + (lane_e >> 2);
           const uint4 v = *(const uint4*)(tr + row * 80 + (lane_e & 3) * 16);
           const int m = mw0 + mt * 32 + row;
+#if F8_NT_STORES
+          if (m < p.M) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)((char*)p.out + (size_t)m * p.ldo + nb + (lane_e & 3) * 16));
+#else
           if (m < p.M) *(uint4*)((char*)p.out + (size_t)m * p.ldo + nb + (lane_e & 3) * 16) = v;
+#endif
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -733,7 +742,11 @@ __global__ __launch_bounds__(512, 2) void gemm_fp8_kernel(const GemmParams p) {
       for (int k = 0; k < 4; ++k) {
         const uint4 v = *(const uint4*)(tr + k * 1024 + tr_base);
         const int m = mw0 + mt * 32 + k * 8 + row_l;
+#if F8_NT_STORES
+        if (m < p.M) { if constexpr (EPI == 0) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, v), (u32x4_t*)((bf16_t*)p.out + (size_t)m * p.ldo + gcol)); else *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + gcol) = v; }
+#else
         if (m < p.M) *(uint4*)((bf16_t*)p.out + (size_t)m * p.ldo + gcol) = v;
+#endif
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // image reads done before the next block's writes
     }

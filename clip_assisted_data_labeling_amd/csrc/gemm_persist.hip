@@ -632,8 +632,12 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       const uint4 v0 = *(const uint4*)(tr + tr_base);
       const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
       const unsigned oa = (unsigned)(wr * 128 + mt * 16 + row_l) * row_bytes + lcol_b;
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v0), orsrc, oa, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v1), orsrc, oa + 8 * row_bytes, 0, 0);
+#ifndef GEMM_NT_STORES
+#define GEMM_NT_STORES 0
+#endif
+      constexpr int ST_AUX = (GEMM_NT_STORES && EPI == EPI_LNFOLD) ? 2 : 0;     // 2 = nt (streaming)
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v0), orsrc, oa, 0, ST_AUX);
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v1), orsrc, oa + 8 * row_bytes, 0, ST_AUX);
 #ifdef CLIPENC_DIAG
       if (mt == 0 && p.dbg && tid == 0) p.dbg[(size_t)idx * 8 + 7] = __builtin_amdgcn_s_memrealtime();   // first 16-row block out: column sums / bias / residual have arrived
 #endif
