@@ -150,3 +150,25 @@ def test_full_size_tower_matches_the_independent_implementation(gpu, golden_dir,
         assert omc8.max().item() < 1e-3, omc8
     finally:
         vit.close()
+
+
+@pytest.mark.parametrize("name", ["ViT-B-16/openai", "ViT-B-16/laion2b_s34b_b88k", "ViT-L-14/laion2b_s32b_b82k"])
+def test_other_named_towers_match_fp32_oracle(gpu, name):
+    """The other towers `utils/embedder.py:63-73` can name: ViT-B-16 (768 wide = three statistics parts, 197 tokens: the small-launch
+    attention kernel with seven key tiles) with QuickGELU and with the erf-GELU of the laion tags, and ViT-L-14 with erf-GELU (the
+    Abramowitz-Stegun epilogue at the headline shape) -- bf16 and e4m3 block GEMMs against the fp32 CPU oracle, north_star tolerance."""
+    cfg = vit_config.config_for(name)
+    sd = vit_config.seeded_state_dict(cfg, 5)
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    crops = synthetic_crops(3 if cfg.width > 768 else 5, cfg.image_size, 91)
+    ref = vit_oracle.encode_image(sd, cfg, crops)
+    vit = HipViT(cfg, sd, gpu)
+    try:
+        for prec in ("bf16", "fp8"):
+            vit.set_precision(prec)
+            got = vit.encode(crops.to(gpu)).cpu()
+            omc = one_minus_cos(got, ref)
+            print(f"{name} {prec} 1-cos vs fp32 oracle:", omc.max().item())
+            assert torch.isfinite(got).all() and omc.max().item() < 1e-3, (prec, omc)
+    finally:
+        vit.close()
