@@ -66,6 +66,36 @@ def test_streaming_attention_is_stable_over_repeats(gpu):
             assert torch.equal(out, first), f"run {it} differs from run 0"
 
 
+@pytest.mark.parametrize("n_crops,n_tok,heads,planted", [(150, 577, 16, False), (90, 400, 8, True), (300, 321, 4, False)])
+def test_long_streaming_attention_is_stable_over_repeats(gpu, n_crops, n_tok, heads, planted):
+    """attn_long_stream_kernel's tile hand-over (the next task's key tiles replace the current task's in place: `landed` / `done[]` words in
+    LDS, a loader wave, no barrier): 2 400 / 720 / 1 200 tasks = 3-10 per workgroup, run eight times -- every run must give the first
+    run's bits, and sampled crops the fp32 softmax.  `planted`: every seventh crop carries a key hundreds of nats above its first tile, so
+    that flagged blocks take the exact second sweep in most workgroups."""
+    lib = _lib.load()
+    st = _lib.current_stream_ptr(gpu)
+    width = heads * 64
+    g = torch.Generator(device=gpu).manual_seed(n_tok)
+    qkv = (torch.randn(n_crops * n_tok, 3 * width, device=gpu, generator=g) * 1.5).to(torch.bfloat16)
+    if planted:
+        for crop in range(0, n_crops, 7):
+            qkv[crop * n_tok + 211, width:2 * width] = 24.0
+    first = None
+    for it in range(8):
+        out = torch.full((n_crops * n_tok, width), float("nan"), dtype=torch.bfloat16, device=gpu)
+        _lib.check(lib.clipenc_op_attention(qkv.data_ptr(), out.data_ptr(), n_crops, n_tok, width, heads, st), "attention")
+        if first is None:
+            first = out
+            assert torch.isfinite(out).all()
+            for crop in (0, 7, n_crops // 2, n_crops - 1):
+                blk = qkv[crop * n_tok:(crop + 1) * n_tok].double().view(n_tok, 3, heads, 64).permute(1, 2, 0, 3)
+                ref = (torch.softmax(blk[0] @ blk[1].transpose(-1, -2) * 0.125, -1) @ blk[2]).permute(1, 0, 2).reshape(n_tok, width).float()
+                got = out[crop * n_tok:(crop + 1) * n_tok].float()
+                assert (got - ref).abs().max().item() < 0.04, crop
+        else:
+            assert torch.equal(out, first), f"run {it} differs from run 0"
+
+
 def test_encoder_repeatability_under_load(gpu):
     cfg = vit_config.ARCHS["ViT-small-test"]
     vit = HipViT(cfg, vit_config.seeded_state_dict(cfg, 2), gpu)
