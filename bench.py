@@ -557,6 +557,30 @@ def vit_l14_336_step(dev, Ws, bs):
     return out
 
 
+def vit_l14_336_fp8_step(dev, Ws, bs, n_img=512):
+    """The reference's default model with the e4m3 block GEMMs (BASELINE.json configs[3] arithmetic on ViT-L-14-336): 512 images x 4 crops
+    of 336 x 336, two timed steps."""
+    from clip_assisted_data_labeling_amd import vit_config
+    from clip_assisted_data_labeling_amd.embedder import HipViT
+    from clip_assisted_data_labeling_amd.nn_model import HipRegressor
+    cfg = vit_config.ARCHS["ViT-L-14-336"]
+    sel = list(range(CROPS_PER_IMAGE))
+    vit = HipViT(cfg, vit_config.seeded_state_dict(cfg, 0), dev, chunk_crops=n_img * CROPS_PER_IMAGE, precision="fp8")
+    reg = HipRegressor([torch.from_numpy(w) for w in Ws], [torch.from_numpy(b) for b in bs], 0.01, dev)
+    try:
+        crops = synthetic_crops(n_img * CROPS_PER_IMAGE, cfg.image_size, 336, dev)
+        dt = timed_steps(lambda: vit.encode_score(crops, reg, CROPS_PER_IMAGE, sel), 2)
+    finally:
+        vit.close()
+        reg.close()
+        torch.cuda.empty_cache()
+    flop = 2.0 * cfg.macs_per_crop() * CROPS_PER_IMAGE
+    value = n_img / dt
+    return {"workload": f"ViT-L-14-336 with e4m3 MFMA block GEMMs, encode + score of {n_img} images x 4 crops of 336 x 336, 2 steps",
+            "value": round(value, 2), "unit": "images/s", "ms_per_step": round(dt * 1e3, 3), "dtype": "fp8",
+            "end_to_end_tflops": round(value * flop / 1e12, 1), "frac_of_fp8_peak": round(value * flop / 1e12 / PEAK_FP8_TFLOPS, 4)}
+
+
 def embed_e2e(dev, n=4096, size=512, workers=16, batch=512):
     """The real-data rate of the embed driver (/root/reference/_1_embed_with_CLIP.py:95-184 -> embed_driver.Feature_Dataset):
     `n` generated JPEG files -> decode -> GPU crop/resize front end -> ViT-L/14 encoder -> one .pt per image, start-up included.
@@ -970,6 +994,7 @@ def main():
             if "l14_336" in want:
                 sec["vit_l14_336"] = vit_l14_336_step(dev, Ws, bs)
                 torch.cuda.empty_cache()
+                sec["vit_l14_336_fp8"] = vit_l14_336_fp8_step(dev, Ws, bs)
             if "e2e" in want:
                 try:
                     sec["embed_e2e"], sec["embed_e2e_gpu_decode"], sec["embed_e2e_gpu_decode_fp8"] = embed_e2e(dev)

@@ -57,6 +57,8 @@ def test_single_gpu_line_has_the_contract_keys(gpu):
     assert sec["dedup_100k"]["candidates"] == 1000 and sec["dedup_100k"]["exact_search"]["pairs_found"] == 1000
     l336 = sec["vit_l14_336"]
     assert l336["value"] > 0 and 0 < l336["attention_share_of_step"] < 1 and any(k.startswith("attn_long") for k in l336["kernels_ms_per_step"])
+    l336f = sec["vit_l14_336_fp8"]                                            # the reference's default model with the e4m3 block GEMMs
+    assert l336f["dtype"] == "fp8" and l336f["value"] > l336["value"] and 0 < l336f["frac_of_fp8_peak"] < 1
     assert sec["embed_e2e"].get("images") == 4096 and sec["embed_e2e"]["pt_files_written"] == 4096 and sec["embed_e2e"]["value"] > 0, sec["embed_e2e"]
     g = sec["embed_e2e_gpu_decode"]                                           # the same files, JPEG decode on the device
     assert g.get("images") == 4096 and g["pt_files_written"] == 4096 and g["value"] > 0 and g["workers"] == 0, g
