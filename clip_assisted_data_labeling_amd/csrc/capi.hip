@@ -771,7 +771,7 @@ int clipenc_set_precision(clipenc_t e, int precision) {
   if (precision != CLIPENC_PREC_BF16 && precision != CLIPENC_PREC_FP8) return fail("unknown precision %d", precision);
   if (precision == CLIPENC_PREC_FP8 && e->layers8.empty()) {
     const clipenc_config& g = e->cfg;
-    if (g.mlp_dim > 4096 || g.width > 4096) return fail("fp8: rows longer than 4096 not built (width %d, mlp_dim %d)", g.width, g.mlp_dim);
+    if (g.mlp_dim > 8192 || g.width > 4096) return fail("fp8: width %d over 4096 (the row quantiser) or mlp_dim %d over 8192 not built", g.width, g.mlp_dim);
     HIP_TRY(hipSetDevice(e->device));
     const size_t D = g.width, M = g.mlp_dim;
     size_t off = 0;

@@ -11,7 +11,7 @@
 
 namespace {
 
-constexpr int QMAXC = 8;                     // row length <= 4096 elements
+constexpr int QMAXC = 16;                    // row length <= 8192 elements (ViT-H-14's 5 120-wide hidden rows: weight rows of FC2)
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -394,7 +394,7 @@ hipError_t ce_colsum_fp8(const void* W8, const float* scale, int N, int K, float
   return hipGetLastError();
 }
 
-// in: bf16 (in_f32 == 0) or fp32 rows of K elements (K % 8 == 0, K <= 4096); ln != 0 normalises each row first.
+// in: bf16 (in_f32 == 0) or fp32 rows of K elements (K % 8 == 0, K <= 8192); ln != 0 normalises each row first.
 hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out8, size_t ld_out, float* scale, int n_rows,
                              int K, int ln, float eps, hipStream_t stream, int pow2) {
   if (n_rows < 1 || K < 8 || K % 8 != 0 || K > QMAXC * 512 || ld_in < (size_t)K || ld_out < (size_t)K) return hipErrorInvalidValue;
@@ -423,7 +423,8 @@ hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out
     if (chunks <= 1) QLAUNCH(T, LNV, 1, 4);                                                 \
     else if (chunks <= 2) QLAUNCH(T, LNV, 2, 4);                                            \
     else if (chunks <= 4) QLAUNCH(T, LNV, 4, 2);                                            \
-    else QLAUNCH(T, LNV, 8, 1);                                                             \
+    else if (chunks <= 8) QLAUNCH(T, LNV, 8, 1);                                            \
+    else QLAUNCH(T, LNV, 16, 1);                                                            \
   } while (0)
   if (in_f32) { if (ln) QDISPATCH(float, true); else QDISPATCH(float, false); }
   else { if (ln) QDISPATCH(bf16_t, true); else QDISPATCH(bf16_t, false); }

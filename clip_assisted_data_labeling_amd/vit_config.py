@@ -68,7 +68,7 @@ ARCHS: Dict[str, ViTConfig] = {
     "ViT-L-14": ViTConfig(224, 14, 1024, 24, 16, 4096, 768),
     "ViT-L-14-336": ViTConfig(336, 14, 1024, 24, 16, 4096, 768),
     # open_clip's ViT-H-14 (laion2b tags: erf-GELU through config_for): width 1280 = 16 heads of 80, five 256-column statistics parts;
-    # bf16 only (its 5 120-wide MLP is past what the e4m3 tower is built for)
+    # the e4m3 tower runs its unfused form (row-quantised operands) for it
     "ViT-H-14": ViTConfig(224, 14, 1280, 32, 16, 5120, 1024),
     # small shapes used by the parity tests (not open_clip names)
     "ViT-tiny-test": ViTConfig(28, 14, 256, 2, 4, 512, 32),
