@@ -7,13 +7,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from clip_assisted_data_labeling_amd import vit_config
 from clip_assisted_data_labeling_amd.embedder import HipViT
 dev = torch.device("cuda", 0)
-cfg = vit_config.ARCHS["ViT-L-14"]
-sd = vit_config.seeded_state_dict(cfg, 0)
 n_rep = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-for prec, crops_n in (("bf16", 2048), ("fp8", 2048), ("bf16", 333), ("fp8", 61)):     # full tiles and ragged last tiles
+ARCH = sys.argv[2] if len(sys.argv) > 2 else "ViT-L-14"        # ViT-L-14-336: the long streaming attention kernel; ViT-H-14: head dim 80
+cfg = vit_config.config_for(ARCH + "/laion2b") if ARCH == "ViT-H-14" else vit_config.ARCHS[ARCH]
+sd = vit_config.seeded_state_dict(cfg, 0)
+big = 2048 if cfg.tokens < 300 else 640
+for prec, crops_n in (("bf16", big), ("fp8", big), ("bf16", 333), ("fp8", 61)):     # full tiles and ragged last tiles
     vit = HipViT(cfg, sd, dev, precision=prec)
     g = torch.Generator(device=dev).manual_seed(crops_n)
-    crops = torch.randn(crops_n, 3, 224, 224, device=dev, generator=g)
+    crops = torch.randn(crops_n, 3, cfg.image_size, cfg.image_size, device=dev, generator=g)
     first = vit.encode(crops).clone()
     assert torch.isfinite(first).all()
     bad = 0
