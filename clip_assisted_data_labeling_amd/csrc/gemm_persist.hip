@@ -632,8 +632,12 @@ __global__ __launch_bounds__(512, 2) void gemm_persist_kernel(const GemmParams p
       const uint4 v0 = *(const uint4*)(tr + tr_base);
       const uint4 v1 = *(const uint4*)(tr + 1024 + tr_base);
       const unsigned oa = (unsigned)(wr * 128 + mt * 16 + row_l) * row_bytes + lcol_b;
+      // The QKV / FC1 outputs (EPI_LNFOLD) are written once and read by another kernel: they leave with the streaming policy, so that an XCD
+      // round's 4 MB of output rows do not push operand panels and the attention kernel's rows out of the L2 / Infinity Cache on their way.
+      // Six interleaved pairs, same box: 1 915-1 926 -> 1 929-1 935 images/s (+0.6 %, every pair), QKV 60.2 -> 59.5 ms, FC1 86.2 -> 85.5, attention
+      // 22.9 -> 22.7 (round 2 had measured three pairs "equal"; GEMM_NT_STORES=0: plain stores).
 #ifndef GEMM_NT_STORES
-#define GEMM_NT_STORES 0
+#define GEMM_NT_STORES 1
 #endif
       constexpr int ST_AUX = (GEMM_NT_STORES && EPI == EPI_LNFOLD) ? 2 : 0;     // 2 = nt (streaming)
       __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v0), orsrc, oa, 0, ST_AUX);
