@@ -396,7 +396,7 @@ def pmc_traffic(kernel_name, problem=LEGACY_PROBLEM):
             if k != "_meta" and (k == kernel_name if kernel_name.startswith("shape:") else (kernel_name in k and not k.startswith("shape:"))):
                 recorded = doc.get("_meta", {}).get("source_sha", {}).get(base)
                 if recorded != kernel_source_sha(base):
-                    return None                       # taken with other sources (or before shas were recorded)
+                    break                             # this directory was taken with other sources (or before shas were recorded): try the next
                 PMC_SOURCE[(kernel_name, problem)] = os.path.relpath(os.path.dirname(path), ROOT)
                 return round(float(v.get("bytes_per_launch", v.get("hbm_bytes", 0.0))), 1)
     return None
