@@ -1489,20 +1489,22 @@ hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int 
   const int nkt = (n_tok + 31) / 32;
   const bf16_t* q = (const bf16_t*)qkv;
   bf16_t* o = (bf16_t*)out;
-  if (width == heads * 80) {                                      // ViT-H-14: its own kernel family, up to 288 tokens
-    switch (nkt) {
-      case 1: return launch_attn_hd<1, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
-      case 2: return launch_attn_hd<2, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
-      case 3: return launch_attn_hd<3, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
-      case 4: return launch_attn_hd<4, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
-      case 5: return launch_attn_hd<5, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
-      case 6: return launch_attn_hd<6, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
-      case 7: return launch_attn_hd<7, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
-      case 8: return launch_attn_hd<8, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
-      case 9: return launch_attn_hd<9, 80>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);
-      default: return hipErrorInvalidValue;
-    }
+#define ATTN_HD_CASES(HD)                                                                                                  \
+  switch (nkt) {                                                                                                           \
+    case 1: return launch_attn_hd<1, HD>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);                   \
+    case 2: return launch_attn_hd<2, HD>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);                   \
+    case 3: return launch_attn_hd<3, HD>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);                   \
+    case 4: return launch_attn_hd<4, HD>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);                   \
+    case 5: return launch_attn_hd<5, HD>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);                   \
+    case 6: return launch_attn_hd<6, HD>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);                   \
+    case 7: return launch_attn_hd<7, HD>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);                   \
+    case 8: return launch_attn_hd<8, HD>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);                   \
+    case 9: return launch_attn_hd<9, HD>(q, o, n_crops, n_tok, width, heads, out_inv, q_blocks, stream);                   \
+    default: return hipErrorInvalidValue;                                                                                  \
   }
+  if (width == heads * 80) { ATTN_HD_CASES(80) }                  // ViT-H-14: its own kernel family, up to 288 tokens
+  if (width == heads * 96) { ATTN_HD_CASES(96) }                  // ViT-g-14's 88-wide heads, zero-padded by clipenc_create
+#undef ATTN_HD_CASES
   if (width != heads * 64) return hipErrorInvalidValue;
 #ifdef CLIPENC_DIAG                         // developer A/B: 0 = one workgroup per (crop, head) for every shape; CLIPENC_ATTN_TAIL=0: the odd query as a block
   static const int impl = [] { const char* e = getenv("CLIPENC_ATTN_IMPL"); return e ? atoi(e) : 2; }();

@@ -150,7 +150,10 @@ struct Profiler {
 constexpr int CE_TICKET_WORDS = 2048;                   // 256 launches x 8 words per pass (a 24-block tower issues 146)
 struct clipenc_s {
   Profiler prof;
-  clipenc_config cfg;
+  clipenc_config cfg;                                    // the tower as it runs on the device: width, heads, mlp_dim after zero padding (clipenc_create)
+  clipenc_config user;                                   // the tower as the caller described it
+  int ln_width = 0;                                      // = user.width: the columns a LayerNorm is over
+  bool padded = false;
   int device = 0;
   int tokens = 0, kpad = 0;
   float pix_mean[3] = {0.48145466f, 0.4578275f, 0.40821073f};      // OpenAI CLIP constants (utils/embedder.py:121-124)
@@ -326,7 +329,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
   pf.end(st);
   pf.begin(PK_EMBED_LN_PRE, 0.0, st);
   HIP_TRY(ce_embed_ln_pre(e->pe, e->cls, e->pos, e->ln_pre_w, e->ln_pre_b, e->x, e->stats0, c, e->tokens, g.width,
-                          g.ln_eps, st));
+                          e->ln_width, g.ln_eps, st));
   pf.end(st);
   const float* stats_in = e->stats0;
   int stats_parts = 1;
@@ -515,7 +518,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       GemmParams qc{};
       qc.A = e->x; qc.lda = stride * Dw; qc.W = L.w_qkv; qc.ldw = Dw; qc.M = c; qc.N = Dw; qc.K = Dw;
       qc.out = e->qkv; qc.ldo = stride * 3 * Dw; qc.bias = L.b_qkv; qc.colsum = L.cs_qkv;
-      qc.stats_in = stats_c; qc.stats_in_parts = stats_parts; qc.stats_ld = Tpc; qc.inv_width = 1.0f / Dw; qc.eps = g.ln_eps; qc.act = -1;
+      qc.stats_in = stats_c; qc.stats_in_parts = stats_parts; qc.stats_ld = Tpc; qc.inv_width = 1.0f / e->ln_width; qc.eps = g.ln_eps; qc.act = -1;
       qc.ticket = ticket();
       pf.begin(PK_GEMM_QKV, 2.0 * c * dD * dD, st);
       HIP_TRY(ce_gemm_nt(qc, CE_DT_BF16, EPI_LNFOLD, st));
@@ -528,7 +531,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
         GemmParams kv{};
         kv.A = e->x; kv.lda = Dw; kv.W = L.w_qkv + (size_t)Dw * Dw; kv.ldw = Dw; kv.M = T; kv.N = 2 * Dw; kv.K = Dw;
         kv.out = e->qkv + Dw; kv.ldo = 3 * Dw; kv.bias = L.b_qkv + Dw; kv.colsum = L.cs_qkv + Dw;
-        kv.stats_in = stats_in; kv.stats_in_parts = stats_parts; kv.stats_ld = Tp; kv.inv_width = 1.0f / Dw; kv.eps = g.ln_eps; kv.act = -1;
+        kv.stats_in = stats_in; kv.stats_in_parts = stats_parts; kv.stats_ld = Tp; kv.inv_width = 1.0f / e->ln_width; kv.eps = g.ln_eps; kv.act = -1;
         kv.ticket = ticket();
         pf.begin(PK_GEMM_QKV, 2.0 * dT * 2.0 * dD * dD, st);
         HIP_TRY(ce_gemm_nt(kv, CE_DT_BF16, EPI_LNFOLD, st));
@@ -551,7 +554,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       GemmParams f{};
       f.A = e->x; f.lda = stride * Dw; f.W = L.w_fc; f.ldw = Dw; f.M = c; f.N = g.mlp_dim; f.K = Dw;
       f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
-      f.stats_in = e->stats_a; f.stats_in_parts = cparts; f.stats_ld = Tpc; f.inv_width = 1.0f / Dw; f.eps = g.ln_eps; f.act = g.act;
+      f.stats_in = e->stats_a; f.stats_in_parts = cparts; f.stats_ld = Tpc; f.inv_width = 1.0f / e->ln_width; f.eps = g.ln_eps; f.act = g.act;
       f.ticket = ticket();
       pf.begin(PK_GEMM_FC1, 2.0 * c * dD * g.mlp_dim, st);
       HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
@@ -570,7 +573,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     GemmParams q{};
     q.A = e->x; q.lda = g.width; q.W = L.w_qkv; q.ldw = g.width; q.M = T; q.N = 3 * g.width; q.K = g.width;
     q.out = e->qkv; q.ldo = 3 * g.width; q.bias = L.b_qkv; q.colsum = L.cs_qkv;
-    q.stats_in = stats_in; q.stats_in_parts = stats_parts; q.stats_ld = Tp; q.inv_width = 1.0f / g.width; q.eps = g.ln_eps; q.act = -1;
+    q.stats_in = stats_in; q.stats_in_parts = stats_parts; q.stats_ld = Tp; q.inv_width = 1.0f / e->ln_width; q.eps = g.ln_eps; q.act = -1;
       q.ticket = ticket();
     pf.begin(PK_GEMM_QKV, 2.0 * dT * 3.0 * dD * dD, st);
     HIP_TRY(ce_gemm_nt(q, CE_DT_BF16, EPI_LNFOLD, st));
@@ -592,7 +595,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     GemmParams f{};
     f.A = e->x; f.lda = g.width; f.W = L.w_fc; f.ldw = g.width; f.M = T; f.N = g.mlp_dim; f.K = g.width;
     f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
-    f.stats_in = e->stats_a; f.stats_in_parts = cparts; f.stats_ld = Tp; f.inv_width = 1.0f / g.width; f.eps = g.ln_eps; f.act = g.act;
+    f.stats_in = e->stats_a; f.stats_in_parts = cparts; f.stats_ld = Tp; f.inv_width = 1.0f / e->ln_width; f.eps = g.ln_eps; f.act = g.act;
       f.ticket = ticket();
     pf.begin(PK_GEMM_FC1, 2.0 * dT * dD * g.mlp_dim, st);
     HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
@@ -629,32 +632,48 @@ int clipenc_device_count(int* count) {
 
 int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int device, clipenc_t* out) {
   if (!cfg || !w || !out) return fail("clipenc_create: NULL argument");
-  const clipenc_config g = *cfg;
-  if (g.width <= 0 || g.width % 256 != 0) return fail("width %d must be a positive multiple of 256", g.width);
-  if (g.mlp_dim <= 0 || g.mlp_dim % 256 != 0) return fail("mlp_dim %d must be a positive multiple of 256", g.mlp_dim);
-  if (g.heads < 1 || (g.heads * 64 != g.width && g.heads * 80 != g.width))
-    return fail("head dims 64 and 80 are built (width %d, heads %d)", g.width, g.heads);
+  const clipenc_config u = *cfg;                            // the caller's tower; `g` below is the one the kernels run
+  if (u.width <= 0 || u.width % 8 != 0) return fail("width %d must be a positive multiple of 8", u.width);
+  if (u.mlp_dim <= 0) return fail("mlp_dim %d must be positive", u.mlp_dim);
+  if (u.heads < 1 || u.width % u.heads != 0) return fail("width %d is not a multiple of heads %d", u.width, u.heads);
+  // Shapes the kernels are built for: heads of 64, 80 or 96 columns, width = heads x that, width and mlp_dim multiples of 256.  Any other
+  // tower is run as the next such shape with ZERO weights in the added places -- exact arithmetic, not an approximation:
+  //   * a head of hd_r < hd columns gets hd - hd_r zero rows in W_q, W_k, W_v (and zero bias): the scores and the output do not see them;
+  //     the attention kernels scale by hd^-1/2, so the q rows (weights and bias) carry (hd / hd_r)^1/2;
+  //   * whole zero heads until heads x hd is a multiple of 256 (uniform softmax over zero values: zero output, zero out-projection columns);
+  //   * residual-stream columns beyond the true width stay zero through every block (zero conv / embedding / out-proj / FC2 rows and bias);
+  //     the LayerNorms divide by the TRUE width (ln_width) and their gamma / beta are zero there;
+  //   * zero FC1 rows / FC2 columns up to a multiple of 256 (both activations map 0 to 0).
+  const int hd_r = u.width / u.heads;
+  const int hd = hd_r <= 64 ? 64 : (hd_r <= 80 ? 80 : 96);
+  if (hd_r > 96) return fail("head dim %d > 96 not built (width %d, heads %d)", hd_r, u.width, u.heads);
+  int heads_d = u.heads;
+  while ((heads_d * hd) % 256 != 0) ++heads_d;
+  clipenc_config g = u;
+  g.heads = heads_d; g.width = heads_d * hd; g.mlp_dim = (int)align_up((size_t)u.mlp_dim, 256);
+  const bool padded = g.width != u.width || g.heads != u.heads || g.mlp_dim != u.mlp_dim;
   if (g.patch <= 0 || g.image_size % g.patch != 0) return fail("image_size %d not divisible by patch %d", g.image_size, g.patch);
   if (g.embed_dim <= 0 || g.embed_dim > 1024) return fail("embed_dim %d out of range (1..1024)", g.embed_dim);
-  if (g.width > 2048) return fail("width %d > 2048 not built (LayerNorm / head kernels)", g.width);
+  if (g.width > 2048) return fail("width %d%s > 2048 not built (LayerNorm / head kernels)", g.width, padded ? " (after padding)" : "");
   if (g.layers < 1) return fail("layers %d < 1", g.layers);
   if (g.act != CLIPENC_ACT_QUICK_GELU && g.act != CLIPENC_ACT_GELU_ERF) return fail("unknown activation %d", g.act);
   const int grid = g.image_size / g.patch, tokens = grid * grid + 1;
   if (tokens > 640) return fail("%d tokens > 640: K and V of one head no longer fit the 160 KiB LDS", tokens);
-  if (g.heads * 80 == g.width && tokens > 288) return fail("%d tokens > 288 at head dim 80: only the one-pass attention kernel is built for it", tokens);
+  if (hd != 64 && tokens > 288) return fail("%d tokens > 288 at head dim %d: only the one-pass attention kernel is built for it", tokens, hd_r);
   int ndev = 0;
   HIP_TRY(hipGetDeviceCount(&ndev));
   if (device < 0 || device >= ndev) return fail("device %d out of range (%d visible)", device, ndev);
   HIP_TRY(hipSetDevice(device));
 
   clipenc_s* e = new clipenc_s();
-  e->cfg = g; e->device = device; e->tokens = tokens;
+  e->cfg = g; e->user = u; e->ln_width = u.width; e->padded = padded; e->device = device; e->tokens = tokens;
 #ifdef CLIPENC_DIAG                         // diagnostic library only: run the last block on every token (tests/test_gpu_cls_only.py)
   e->cls_only_last = getenv("CLIPENC_FULL_LAST_BLOCK") == nullptr;
   e->fp8_unfused = getenv("CLIPENC_FP8_UNFUSED") != nullptr;
   e->dynamic_tail = getenv("CLIPENC_STATIC_TILES") == nullptr;
   e->cls_shortcut = getenv("CLIPENC_CLS_KV") == nullptr;
 #endif
+  if (padded) e->cls_shortcut = false;                     // (its kernels take 64^-1/2 and 1 / width as constants)
   const int kreal = 3 * g.patch * g.patch;
   e->kpad = (int)align_up(kreal, 128);
   const int D = g.width, M = g.mlp_dim, L = g.layers, E = g.embed_dim;
@@ -677,16 +696,53 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
   const size_t o_wkt = take((size_t)D * D * 2);
   std::vector<char> host(off);
   char* hb = host.data();
+  // device index -> index in the caller's tensor, or -1 (zero): residual columns, head-major columns (q / k / v rows, out-proj columns), MLP
+  const int Du = u.width, Mu = u.mlp_dim;
+  std::vector<int> res_map(D), head_map(D), mlp_map(M), qkv_map(3 * (size_t)D);
+  for (int j = 0; j < D; ++j) {
+    res_map[j] = j < Du ? j : -1;
+    head_map[j] = (j / hd < u.heads && j % hd < hd_r) ? (j / hd) * hd_r + j % hd : -1;
+  }
+  for (int j = 0; j < M; ++j) mlp_map[j] = j < Mu ? j : -1;
+  for (int j = 0; j < 3 * D; ++j) qkv_map[j] = head_map[j % D] < 0 ? -1 : (j / D) * Du + head_map[j % D];
+  // zero-padded fp32 copy [Nd][Kd] of the caller's [..][Ku] matrix (rows / columns through the maps); vectors likewise
+  auto pad_mat = [&](const float* W, int Ku, const std::vector<int>& nmap, int Nd, const std::vector<int>& kmap, int Kd) {
+    std::vector<float> o((size_t)Nd * Kd, 0.f);
+    float* op = o.data();
+    const int *nm = nmap.data(), *km = kmap.data();
+    parallel_for(Nd, [=](int n) {
+      if (nm[n] < 0) return;
+      for (int k = 0; k < Kd; ++k)
+        if (km[k] >= 0) op[(size_t)n * Kd + k] = W[(size_t)nm[n] * Ku + km[k]];
+    });
+    return o;
+  };
+  auto pad_vec = [&](const float* v, const std::vector<int>& map, int n) {
+    std::vector<float> o(n, 0.f);
+    for (int i = 0; i < n; ++i) if (map[i] >= 0) o[i] = v[map[i]];
+    return o;
+  };
   {
     bf16_t* wc = (bf16_t*)(hb + o_conv);
     for (int n = 0; n < D; ++n)
       for (int k = 0; k < e->kpad; ++k)
-        wc[(size_t)n * e->kpad + k] = k < kreal ? host_f32_to_bf16(w->conv1_weight[(size_t)n * kreal + k]) : 0;
-    memcpy(hb + o_cls, w->class_embedding, D * 4);
-    memcpy(hb + o_pos, w->positional_embedding, (size_t)tokens * D * 4);
-    memcpy(hb + o_lpw, w->ln_pre_w, D * 4); memcpy(hb + o_lpb, w->ln_pre_b, D * 4);
-    memcpy(hb + o_low, w->ln_post_w, D * 4); memcpy(hb + o_lob, w->ln_post_b, D * 4);
-    memcpy(hb + o_proj, w->proj, (size_t)D * E * 4);
+        wc[(size_t)n * e->kpad + k] = (k < kreal && res_map[n] >= 0) ? host_f32_to_bf16(w->conv1_weight[(size_t)res_map[n] * kreal + k]) : 0;
+    if (!padded) {
+      memcpy(hb + o_cls, w->class_embedding, D * 4);
+      memcpy(hb + o_pos, w->positional_embedding, (size_t)tokens * D * 4);
+      memcpy(hb + o_lpw, w->ln_pre_w, D * 4); memcpy(hb + o_lpb, w->ln_pre_b, D * 4);
+      memcpy(hb + o_low, w->ln_post_w, D * 4); memcpy(hb + o_lob, w->ln_post_b, D * 4);
+      memcpy(hb + o_proj, w->proj, (size_t)D * E * 4);
+    } else {
+      std::vector<int> all_tok(tokens), all_e(E);
+      for (int i = 0; i < tokens; ++i) all_tok[i] = i;
+      for (int i = 0; i < E; ++i) all_e[i] = i;
+      memcpy(hb + o_cls, pad_vec(w->class_embedding, res_map, D).data(), D * 4);
+      memcpy(hb + o_pos, pad_mat(w->positional_embedding, Du, all_tok, tokens, res_map, D).data(), (size_t)tokens * D * 4);
+      memcpy(hb + o_lpw, pad_vec(w->ln_pre_w, res_map, D).data(), D * 4); memcpy(hb + o_lpb, pad_vec(w->ln_pre_b, res_map, D).data(), D * 4);
+      memcpy(hb + o_low, pad_vec(w->ln_post_w, res_map, D).data(), D * 4); memcpy(hb + o_lob, pad_vec(w->ln_post_b, res_map, D).data(), D * 4);
+      memcpy(hb + o_proj, pad_mat(w->proj, E, res_map, D, all_e, E).data(), (size_t)D * E * 4);
+    }
   }
   // LayerNorm folding:  LN(x).W^T + b = rstd*(x.(g*W)^T - mean*colsum) + (b + W.beta)
   auto fold = [&](const float* W, const float* b, const float* gamma, const float* beta, int N, int K, bf16_t* Wq,
@@ -710,14 +766,31 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
     });
   };
   for (int l = 0; l < L; ++l) {
-    fold(w->in_proj_w[l], w->in_proj_b[l], w->ln_1_w[l], w->ln_1_b[l], 3 * D, D, (bf16_t*)(hb + lo[l].w_qkv),
-         (float*)(hb + lo[l].cs_qkv), (float*)(hb + lo[l].b_qkv));
-    plain(w->out_proj_w[l], D, D, (bf16_t*)(hb + lo[l].w_out));
-    memcpy(hb + lo[l].b_out, w->out_proj_b[l], D * 4);
-    fold(w->c_fc_w[l], w->c_fc_b[l], w->ln_2_w[l], w->ln_2_b[l], M, D, (bf16_t*)(hb + lo[l].w_fc),
-         (float*)(hb + lo[l].cs_fc), (float*)(hb + lo[l].b_fc));
-    plain(w->c_proj_w[l], D, M, (bf16_t*)(hb + lo[l].w_proj));
-    memcpy(hb + lo[l].b_proj, w->c_proj_b[l], D * 4);
+    const float *ipw = w->in_proj_w[l], *ipb = w->in_proj_b[l], *opw = w->out_proj_w[l], *opb = w->out_proj_b[l];
+    const float *g1 = w->ln_1_w[l], *b1 = w->ln_1_b[l], *g2 = w->ln_2_w[l], *b2 = w->ln_2_b[l];
+    const float *fcw = w->c_fc_w[l], *fcb = w->c_fc_b[l], *pjw = w->c_proj_w[l], *pjb = w->c_proj_b[l];
+    std::vector<float> t[12];                              // the padded copies of this block (released with the iteration)
+    if (padded) {
+      t[0] = pad_mat(ipw, Du, qkv_map, 3 * D, res_map, D); t[1] = pad_vec(ipb, qkv_map, 3 * D);
+      const float qs = sqrtf((float)hd / (float)hd_r);     // the kernels' hd^-1/2 -> the tower's hd_r^-1/2
+      if (hd != hd_r) {
+        for (size_t i = 0; i < (size_t)D * D; ++i) t[0][i] *= qs;
+        for (int i = 0; i < D; ++i) t[1][i] *= qs;
+      }
+      t[2] = pad_mat(opw, Du, res_map, D, head_map, D); t[3] = pad_vec(opb, res_map, D);
+      t[4] = pad_vec(g1, res_map, D); t[5] = pad_vec(b1, res_map, D); t[6] = pad_vec(g2, res_map, D); t[7] = pad_vec(b2, res_map, D);
+      t[8] = pad_mat(fcw, Du, mlp_map, M, res_map, D); t[9] = pad_vec(fcb, mlp_map, M);
+      t[10] = pad_mat(pjw, Mu, res_map, D, mlp_map, M); t[11] = pad_vec(pjb, res_map, D);
+      ipw = t[0].data(); ipb = t[1].data(); opw = t[2].data(); opb = t[3].data();
+      g1 = t[4].data(); b1 = t[5].data(); g2 = t[6].data(); b2 = t[7].data();
+      fcw = t[8].data(); fcb = t[9].data(); pjw = t[10].data(); pjb = t[11].data();
+    }
+    fold(ipw, ipb, g1, b1, 3 * D, D, (bf16_t*)(hb + lo[l].w_qkv), (float*)(hb + lo[l].cs_qkv), (float*)(hb + lo[l].b_qkv));
+    plain(opw, D, D, (bf16_t*)(hb + lo[l].w_out));
+    memcpy(hb + lo[l].b_out, opb, D * 4);
+    fold(fcw, fcb, g2, b2, M, D, (bf16_t*)(hb + lo[l].w_fc), (float*)(hb + lo[l].cs_fc), (float*)(hb + lo[l].b_fc));
+    plain(pjw, D, M, (bf16_t*)(hb + lo[l].w_proj));
+    memcpy(hb + lo[l].b_proj, pjb, D * 4);
   }
   {
     // (gamma-folded W_k of the LAST layer)^T: Wt[k][n] = W'_k[n][k]  (cls_attention.hip: r_h = sum_{n in head} q_n W'_k[n, :])
@@ -771,6 +844,7 @@ int clipenc_set_precision(clipenc_t e, int precision) {
   if (precision != CLIPENC_PREC_BF16 && precision != CLIPENC_PREC_FP8) return fail("unknown precision %d", precision);
   if (precision == CLIPENC_PREC_FP8 && e->layers8.empty()) {
     const clipenc_config& g = e->cfg;
+    if (e->padded) return fail("fp8: not built for a zero-padded tower (width %d, %d heads run as %d, %d)", e->user.width, e->user.heads, g.width, g.heads);
     if (g.mlp_dim > 8192 || g.width > 4096) return fail("fp8: width %d over 4096 (the row quantiser) or mlp_dim %d over 8192 not built", g.width, g.mlp_dim);
     HIP_TRY(hipSetDevice(e->device));
     const size_t D = g.width, M = g.mlp_dim;
@@ -876,7 +950,7 @@ int clipenc_encode(clipenc_t e, const void* crops_dev, int n_crops, int in_dtype
     if (int rc = run_tower(e, (const char*)crops_dev + (size_t)c0 * cb, c, in_dtype, g.layers, st, e->cls_only_last)) return rc;
     e->prof.begin(PK_HEAD, 2.0 * c * (double)g.width * g.embed_dim, st);
     HIP_TRY(ce_head(e->x, e->ln_post_w, e->ln_post_b, e->proj, emb_dev + (size_t)c0 * g.embed_dim, c, e->tokens,
-                    g.width, g.embed_dim, g.ln_eps, normalize, st));
+                    g.width, e->ln_width, g.embed_dim, g.ln_eps, normalize, st));
     e->prof.end(st);
   }
   return 0;
@@ -938,7 +1012,7 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
     }
     if (kind == PK_ATTENTION) {                      // the instantiation ce_attention picks for this token count
       const int nkt = (e->tokens + 31) / 32;
-      if (e->cfg.heads * 80 == e->cfg.width) { static thread_local char hb[32]; snprintf(hb, sizeof hb, "attn_hd_kernel<%d, 80>", nkt); *name = hb; }
+      if (e->cfg.heads * 64 != e->cfg.width) { static thread_local char hb[32]; snprintf(hb, sizeof hb, "attn_hd_kernel<%d, %d>", nkt, e->cfg.width / e->cfg.heads); *name = hb; }
       else if (nkt > 19) *name = "attn_long_kernel<12>";
       else if (nkt > 9) *name = "attn_long_stream_kernel<11>";     // (launches of fewer than 64 tasks take attn_long_kernel<12>)
       else if (nkt == 9) *name = (e->tokens & 31) == 1 ? "attn_stream_kernel<9, 7, true>" : "attn_stream_kernel<9, 7, false>";
@@ -962,7 +1036,13 @@ int clipenc_forward_tokens(clipenc_t e, const void* crops_dev, int n_crops, int 
   if (e->ws_chunk != e->chunk || e->ws_precision != e->precision) return fail("workspace not allocated (internal error)");
   hipStream_t st = (hipStream_t)stream;
   if (int rc = run_tower(e, crops_dev, n_crops, in_dtype, n_layers, st)) return rc;
-  HIP_TRY(hipMemcpyAsync(x_out, e->x, (size_t)n_crops * e->tokens * e->cfg.width * 2, hipMemcpyDeviceToDevice, st));
+  if (!e->padded) {
+    HIP_TRY(hipMemcpyAsync(x_out, e->x, (size_t)n_crops * e->tokens * e->cfg.width * 2, hipMemcpyDeviceToDevice, st));
+    return 0;
+  }
+  // [rows][user width] to the caller: a padded tower's rows are wider on the device, their extra columns are zeros
+  HIP_TRY(hipMemcpy2DAsync(x_out, (size_t)e->user.width * 2, e->x, (size_t)e->cfg.width * 2, (size_t)e->user.width * 2,
+                           (size_t)n_crops * e->tokens, hipMemcpyDeviceToDevice, st));
   return 0;
 }
 

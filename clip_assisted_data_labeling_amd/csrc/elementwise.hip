@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(const bf16_t* __restr
                                                            const float* __restrict__ pos, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, bf16_t* __restrict__ x,
                                                            float* __restrict__ stats, int n_crops, int n_tok, int width,
-                                                           float eps, int cpw, int waves_per_tok) {
+                                                           int ln_width, float eps, int cpw, int waves_per_tok) {
   const int lane = threadIdx.x & 63;
   const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int tok = gw / waves_per_tok, slot = gw - tok * waves_per_tok;
@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(const bf16_t* __restr
         for (int j = 0; j < 8; ++j) s += v[ci][j];
       }
     }
-    const float mean = wave_sum(s) / (float)width;
+    // a zero-padded tower (capi.hip, clipenc_create): columns ln_width .. width - 1 hold zeros and zero gamma / beta; they add nothing to the
+    // sum, mean^2 each to the squared deviations (taken off again: exactly nothing when ln_width == width), and come out as zeros
+    const float mean = wave_sum(s) / (float)ln_width;
     float ss = 0.f;
 #pragma unroll
     for (int ci = 0; ci < NCH; ++ci) {
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(const bf16_t* __restr
         for (int j = 0; j < 8; ++j) { const float d = v[ci][j] - mean; ss += d * d; }
       }
     }
-    const float rstd = rsqrtf(wave_sum(ss) / (float)width + eps);
+    const float rstd = rsqrtf((wave_sum(ss) - (float)(width - ln_width) * mean * mean) / (float)ln_width + eps);
     float rs = 0.f, rss = 0.f;
     const size_t row = (size_t)crop * n_tok + tok;
 #pragma unroll
@@ -235,8 +237,8 @@ constexpr int HEAD_CROPS = 8;      // class-token rows per workgroup: every row 
 
 __global__ __launch_bounds__(256) void head_kernel(const bf16_t* __restrict__ x, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, const float* __restrict__ proj,
-                                                   float* __restrict__ emb, int n_crops, int n_tok, int width, int embed,
-                                                   float eps, int normalize) {
+                                                   float* __restrict__ emb, int n_crops, int n_tok, int width, int ln_width,
+                                                   int embed, float eps, int normalize) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* c = (float*)smem;                         // [HEAD_CROPS][width]
   float* red = c + HEAD_CROPS * width;             // [HEAD_CROPS][4]
@@ -249,10 +251,10 @@ __global__ __launch_bounds__(256) void head_kernel(const bf16_t* __restrict__ x,
       const bf16_t* row = x + (size_t)crop * n_tok * width;
       float s = 0.f;
       for (int k = lane; k < width; k += 64) s += bf16_to_f32(row[k]);
-      const float mean = wave_sum(s) / (float)width;
+      const float mean = wave_sum(s) / (float)ln_width;       // (zero-padded towers: as in embed_ln_pre_kernel)
       float ss = 0.f;
       for (int k = lane; k < width; k += 64) { const float d = bf16_to_f32(row[k]) - mean; ss += d * d; }
-      const float rstd = rsqrtf(wave_sum(ss) / (float)width + eps);
+      const float rstd = rsqrtf((wave_sum(ss) - (float)(width - ln_width) * mean * mean) / (float)ln_width + eps);
       for (int k = lane; k < width; k += 64)
         c[cw * width + k] = (bf16_to_f32(row[k]) - mean) * rstd * gamma[k] + beta[k];
     } else {
@@ -347,9 +349,9 @@ hipError_t ce_patchify(const void* crops, int in_dtype, void* a_patch, int n_cro
 }
 
 hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float* pos, const float* gamma,
-                           const float* beta, void* x, float* stats, int n_crops, int n_tok, int width, float eps,
-                           hipStream_t stream) {
-  if (width % 8 != 0 || width > LN_MAX_CHUNKS * 512) return hipErrorInvalidValue;
+                           const float* beta, void* x, float* stats, int n_crops, int n_tok, int width, int ln_width,
+                           float eps, hipStream_t stream) {
+  if (width % 8 != 0 || width > LN_MAX_CHUNKS * 512 || ln_width < 1 || ln_width > width) return hipErrorInvalidValue;
   // crops per wave: enough rows to pay for the per-wave constants, enough waves to fill the chip
   const int cpw = n_crops >= 2048 ? 16 : (n_crops >= 256 ? 8 : (n_crops >= 32 ? 2 : 1));
   const int waves_per_tok = (n_crops + cpw - 1) / cpw;
@@ -358,7 +360,7 @@ hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float*
   const int nch = (width + 511) / 512;
 #define LAUNCH_LN_PRE(N)                                                                                                  \
   hipLaunchKernelGGL(embed_ln_pre_kernel<N>, grid, block, 0, stream, (const bf16_t*)patch_emb, cls, pos, gamma, beta, (bf16_t*)x, \
-                     stats, n_crops, n_tok, width, eps, cpw, waves_per_tok)
+                     stats, n_crops, n_tok, width, ln_width, eps, cpw, waves_per_tok)
   switch (nch) {
     case 1: LAUNCH_LN_PRE(1); break;
     case 2: LAUNCH_LN_PRE(2); break;
@@ -370,11 +372,11 @@ hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float*
 }
 
 hipError_t ce_head(const void* x, const float* gamma, const float* beta, const float* proj, float* emb, int n_crops,
-                   int n_tok, int width, int embed, float eps, int normalize, hipStream_t stream) {
-  if (embed > 1024 || width > 2048 || width % 4 != 0) return hipErrorInvalidValue;
+                   int n_tok, int width, int ln_width, int embed, float eps, int normalize, hipStream_t stream) {
+  if (embed > 1024 || width > 2048 || width % 4 != 0 || ln_width < 1 || ln_width > width) return hipErrorInvalidValue;
   const size_t lds = (size_t)HEAD_CROPS * width * 4 + HEAD_CROPS * 4 * 4;
   hipLaunchKernelGGL(head_kernel, dim3((n_crops + HEAD_CROPS - 1) / HEAD_CROPS), dim3(256), lds, stream,
-                     (const bf16_t*)x, gamma, beta, proj, emb, n_crops, n_tok, width, embed, eps, normalize);
+                     (const bf16_t*)x, gamma, beta, proj, emb, n_crops, n_tok, width, ln_width, embed, eps, normalize);
   return hipGetLastError();
 }
 

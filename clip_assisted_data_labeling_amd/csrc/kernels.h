@@ -22,8 +22,8 @@ hipError_t ce_cls_finish(const void* Of, const float* mz, const float* colsum_v,
 hipError_t ce_patchify(const void* crops, int in_dtype, void* a_patch, int n_crops, int image, int patch, int kpad,
                        const float* mean3, const float* std3, hipStream_t stream);
 hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float* pos, const float* gamma,
-                           const float* beta, void* x, float* stats, int n_crops, int n_tok, int width, float eps,
-                           hipStream_t stream);
+                           const float* beta, void* x, float* stats, int n_crops, int n_tok, int width, int ln_width,
+                           float eps, hipStream_t stream);   // ln_width <= width: the columns the LayerNorm is over (the rest are zero padding)
 // out[part][i] = in[part][i * row_stride] for i < n (float2 statistics of every row_stride-th row), parts x n
 hipError_t ce_gather_row_stats(const float* in, int in_ld, float* out, int out_ld, int parts, int n, int row_stride, hipStream_t stream);
 // stats[0][i] += stats[1][i] + ... + stats[parts - 1][i] (in that order), i < n: towers wider than 1024 hand the LayerNorm-folded GEMM ONE part
@@ -32,7 +32,7 @@ hipError_t ce_clock_probe(unsigned long long* out2, int spin_ticks, hipStream_t 
 // n_cu workgroups x 8 waves x iters x (16 bf16 16x16x32 | 8 fp8 32x32x64) MFMAs on operands read once from a 32-KiB buffer
 hipError_t ce_mfma_stream(const void* operands_32k, int fp8, float* sink, long long iters, int n_cu, hipStream_t stream);
 hipError_t ce_head(const void* x, const float* gamma, const float* beta, const float* proj, float* emb, int n_crops,
-                   int n_tok, int width, int embed, float eps, int normalize, hipStream_t stream);
+                   int n_tok, int width, int ln_width, int embed, float eps, int normalize, hipStream_t stream);
 
 // quant_fp8.hip
 hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out8, size_t ld_out, float* scale, int n_rows,

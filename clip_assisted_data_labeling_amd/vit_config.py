@@ -70,12 +70,21 @@ ARCHS: Dict[str, ViTConfig] = {
     # open_clip's ViT-H-14 (laion2b tags: erf-GELU through config_for): width 1280 = 16 heads of 80, five 256-column statistics parts;
     # the e4m3 tower runs its unfused form (row-quantised operands) for it
     "ViT-H-14": ViTConfig(224, 14, 1280, 32, 16, 5120, 1024),
+    "ViT-L-16": ViTConfig(224, 16, 1024, 24, 16, 4096, 768),
+    "ViT-H-16": ViTConfig(224, 16, 1280, 32, 16, 5120, 1024),
+    # towers whose shapes the kernels are not built for run zero-padded (capi.hip, clipenc_create: exact arithmetic, bf16 only):
+    # ViT-g-14's 16 heads of 88 run as heads of 96 (width 1408 -> 1536); ViT-B-16-plus-240's 14 heads of 64 as 16 (896 -> 1024)
+    "ViT-g-14": ViTConfig(224, 14, 1408, 40, 16, 6144, 1024),
+    "ViT-B-16-plus-240": ViTConfig(240, 16, 896, 12, 14, 3584, 640),
     # small shapes used by the parity tests (not open_clip names)
     "ViT-tiny-test": ViTConfig(28, 14, 256, 2, 4, 512, 32),
     "ViT-small-test": ViTConfig(98, 14, 256, 3, 4, 1024, 64),
     "ViT-long-test": ViTConfig(336, 14, 256, 2, 4, 512, 32),      # 577 tokens like ViT-L-14-336
     "ViT-H-tiny-test": ViTConfig(28, 14, 1280, 2, 16, 5120, 64),  # head dim 80, five statistics parts, 5 tokens
     "ViT-H-mid-test": ViTConfig(98, 14, 1280, 3, 16, 5120, 64),   # ... 50 tokens: two key tiles, a partial one
+    "ViT-g-tiny-test": ViTConfig(28, 14, 704, 2, 8, 1024, 32),    # 8 heads of 88 -> heads of 96 (width 768 on the device), 5 tokens
+    "ViT-g-mid-test": ViTConfig(98, 14, 704, 3, 8, 1024, 64),     # ... 50 tokens
+    "ViT-pad-test": ViTConfig(98, 14, 288, 3, 6, 640, 32),        # every kind of padding: heads of 48 -> 64, 6 heads -> 8, mlp 640 -> 768
 }
 
 

@@ -338,6 +338,10 @@ if __name__ == "__main__":
     if sys.argv[1:] == ["vit_h"]:        # round 6: ViT-H-14 at full size (1280 wide x 32 blocks, head dim 80, erf-GELU; ~2 min of CPU, 8 GB)
         make_encoder("ViT-H-14", 2, seed=15, in_seed=16, pretrained="laion2b_s32b_b79k")
         sys.exit(0)
+    if sys.argv[1:] == ["vit_g"]:        # round 6: ViT-g-14 at full size (1408 wide = 16 heads of 88, 40 blocks, 1.0 G parameters; ~4 min of CPU, 13 GB)
+        make_encoder("ViT-g-14", 2, seed=17, in_seed=18, pretrained="laion2b_s34b_b88k")
+        make_encoder("ViT-pad-test", 5, seed=19, in_seed=20)
+        sys.exit(0)
     if sys.argv[1:] == ["full"]:         # round 5: the full-size towers (needs transformers, not the reference; ~1 min of CPU, 5 GB)
         make_encoder("ViT-L-14", 4, seed=11, in_seed=12)
         make_encoder("ViT-L-14-336", 2, seed=13, in_seed=14)
