@@ -275,7 +275,11 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
   const int cparts = parts > 4 ? 1 : parts;
   const int Tp = (int)align_up((size_t)T, 256);
   Profiler& pf = e->prof;
-  const double dT = (double)T, dD = (double)g.width;
+  // profiler flops are the TOWER's (the caller's widths): a zero-padded tower's extra columns are work, not result
+  const double dT = (double)T, dD = (double)e->user.width, dM = (double)e->user.mlp_dim;
+  auto own = [&](int n) -> double {          // a GEMM dimension on the device -> the tower's own
+    return n == g.mlp_dim ? (double)n * e->user.mlp_dim / g.mlp_dim : (double)n * e->user.width / g.width;
+  };
   // ticket counters of this pass's persistent GEMM launches (at most 6 per block + the patch GEMM): zeroed by one fill
   int tk = 0;
   if (e->dynamic_tail) HIP_TRY(hipMemsetAsync(e->tickets, 0, CE_TICKET_WORDS * sizeof(unsigned), st));
@@ -344,7 +348,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     uint8_t* h8 = (uint8_t*)e->hid;
     auto run8 = [&](GemmParams& q, int epi, int kind, int sub) -> hipError_t {
       q.ticket = ticket();
-      pf.begin(kind, 2.0 * (double)q.M * (double)q.N * (double)q.K, st, sub);
+      pf.begin(kind, 2.0 * (double)q.M * own(q.N) * own(q.K), st, sub);
       hipError_t err = ce_gemm_fp8(q, epi, st);
       pf.end(st);
       return err;
@@ -370,7 +374,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     };
     auto consts = [&](const float* stats, int parts, int ld, int n) -> hipError_t {
       pf.begin(PK_ROW_CONSTS, 0.0, st);
-      hipError_t err = ce_row_norm_consts(stats, parts, (size_t)ld, n, Dw, g.ln_eps, e->rr8, e->rd8, 1, st);
+      hipError_t err = ce_row_norm_consts(stats, parts, (size_t)ld, n, e->ln_width, g.ln_eps, e->rr8, e->rd8, 1, st);
       pf.end(st);
       return err;
     };
@@ -438,7 +442,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       GemmParams q{};
       q.A = A8; q.lda = lda; q.W = W8; q.ldw = K; q.M = M; q.N = N; q.K = K; q.out = out; q.ldo = ldo; q.bias = bias;
       q.scale_a = sa; q.scale_w = sw; q.act = act; q.resid = epi == EPI_RESID ? out : nullptr; q.out_inv_scale = out_inv;
-      pf.begin(kind, 2.0 * (double)M * (double)N * (double)K, st, sub);
+      pf.begin(kind, 2.0 * (double)M * own(N) * own(K), st, sub);
       hipError_t err = ce_gemm_fp8(q, epi, st);
       pf.end(st);
       return err;
@@ -449,7 +453,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     };
     auto quant = [&](const bf16_t* in, size_t K, int ln) -> hipError_t {
       pf.begin(ln ? PK_QUANT_LN : PK_QUANT, 0.0, st);
-      hipError_t err = ce_quant_rows_fp8(in, 0, K, e->a8, K, e->sa8, T, (int)K, ln, g.ln_eps, st);
+      hipError_t err = ce_quant_rows_fp8(in, 0, K, e->a8, K, e->sa8, T, (int)K, ln, g.ln_eps, st, 0, ln ? e->ln_width : 0);
       pf.end(st);
       return err;
     };
@@ -467,7 +471,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
                        e->qkv + Dw, 3 * g.width, EPI_STORE_BF16, nullptr, PK_GEMM8_QKV, -1));
         auto quant_cls = [&]() -> hipError_t {                 // LN + quantise the CLS rows of x -> a8[0..c), sa8[0..c)
           pf.begin(PK_QUANT_LN, 0.0, st);
-          hipError_t err = ce_quant_rows_fp8(e->x, 0, (size_t)stride * Dw, e->a8, Dw, e->sa8, c, (int)Dw, 1, g.ln_eps, st);
+          hipError_t err = ce_quant_rows_fp8(e->x, 0, (size_t)stride * Dw, e->a8, Dw, e->sa8, c, (int)Dw, 1, g.ln_eps, st, 0, e->ln_width);
           pf.end(st);
           return err;
         };
@@ -556,7 +560,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
       f.stats_in = e->stats_a; f.stats_in_parts = cparts; f.stats_ld = Tpc; f.inv_width = 1.0f / e->ln_width; f.eps = g.ln_eps; f.act = g.act;
       f.ticket = ticket();
-      pf.begin(PK_GEMM_FC1, 2.0 * c * dD * g.mlp_dim, st);
+      pf.begin(PK_GEMM_FC1, 2.0 * c * dD * dM, st);
       HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
       pf.end(st);
       // x[cls] += h . Wproj^T + b
@@ -564,7 +568,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
       r.A = e->hid; r.lda = g.mlp_dim; r.W = L.w_proj; r.ldw = g.mlp_dim; r.M = c; r.N = Dw; r.K = g.mlp_dim;
       r.out = e->x; r.ldo = stride * Dw; r.bias = L.b_proj; r.resid = e->x; r.stats_out = e->stats_b; r.stats_ld = Tpc;
       r.ticket = ticket();
-      pf.begin(PK_GEMM_RESID, 2.0 * c * dD * g.mlp_dim, st, PK_SUB_FC2);
+      pf.begin(PK_GEMM_RESID, 2.0 * c * dD * dM, st, PK_SUB_FC2);
       HIP_TRY(ce_gemm_nt(r, CE_DT_BF16, EPI_RESID, st));
       pf.end(st);
       break;
@@ -597,7 +601,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     f.out = e->hid; f.ldo = g.mlp_dim; f.bias = L.b_fc; f.colsum = L.cs_fc;
     f.stats_in = e->stats_a; f.stats_in_parts = cparts; f.stats_ld = Tp; f.inv_width = 1.0f / e->ln_width; f.eps = g.ln_eps; f.act = g.act;
       f.ticket = ticket();
-    pf.begin(PK_GEMM_FC1, 2.0 * dT * dD * g.mlp_dim, st);
+    pf.begin(PK_GEMM_FC1, 2.0 * dT * dD * dM, st);
     HIP_TRY(ce_gemm_nt(f, CE_DT_BF16, EPI_LNFOLD, st));
     pf.end(st);
     // K7: x += h . Wproj^T + b
@@ -605,7 +609,7 @@ int run_tower(clipenc_s* e, const void* crops, int c, int in_dtype, int n_layers
     r.A = e->hid; r.lda = g.mlp_dim; r.W = L.w_proj; r.ldw = g.mlp_dim; r.M = T; r.N = g.width; r.K = g.mlp_dim;
     r.out = e->x; r.ldo = g.width; r.bias = L.b_proj; r.resid = e->x; r.stats_out = e->stats_b; r.stats_ld = Tp;
       r.ticket = ticket();
-    pf.begin(PK_GEMM_RESID, 2.0 * dT * dD * g.mlp_dim, st, PK_SUB_FC2);
+    pf.begin(PK_GEMM_RESID, 2.0 * dT * dD * dM, st, PK_SUB_FC2);
     HIP_TRY(ce_gemm_nt(r, CE_DT_BF16, EPI_RESID, st));
     HIP_TRY(fold_stats(e->stats_b, Tp, T));
     pf.end(st);
@@ -844,7 +848,6 @@ int clipenc_set_precision(clipenc_t e, int precision) {
   if (precision != CLIPENC_PREC_BF16 && precision != CLIPENC_PREC_FP8) return fail("unknown precision %d", precision);
   if (precision == CLIPENC_PREC_FP8 && e->layers8.empty()) {
     const clipenc_config& g = e->cfg;
-    if (e->padded) return fail("fp8: not built for a zero-padded tower (width %d, %d heads run as %d, %d)", e->user.width, e->user.heads, g.width, g.heads);
     if (g.mlp_dim > 8192 || g.width > 4096) return fail("fp8: width %d over 4096 (the row quantiser) or mlp_dim %d over 8192 not built", g.width, g.mlp_dim);
     HIP_TRY(hipSetDevice(e->device));
     const size_t D = g.width, M = g.mlp_dim;
@@ -948,7 +951,7 @@ int clipenc_encode(clipenc_t e, const void* crops_dev, int n_crops, int in_dtype
   for (int c0 = 0; c0 < n_crops; c0 += e->chunk) {
     const int c = std::min(e->chunk, n_crops - c0);
     if (int rc = run_tower(e, (const char*)crops_dev + (size_t)c0 * cb, c, in_dtype, g.layers, st, e->cls_only_last)) return rc;
-    e->prof.begin(PK_HEAD, 2.0 * c * (double)g.width * g.embed_dim, st);
+    e->prof.begin(PK_HEAD, 2.0 * c * (double)e->user.width * g.embed_dim, st);
     HIP_TRY(ce_head(e->x, e->ln_post_w, e->ln_post_b, e->proj, emb_dev + (size_t)c0 * g.embed_dim, c, e->tokens,
                     g.width, e->ln_width, g.embed_dim, g.ln_eps, normalize, st));
     e->prof.end(st);

@@ -36,7 +36,7 @@ hipError_t ce_head(const void* x, const float* gamma, const float* beta, const f
 
 // quant_fp8.hip
 hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out8, size_t ld_out, float* scale, int n_rows,
-                             int K, int ln, float eps, hipStream_t stream, int pow2 = 0);
+                             int K, int ln, float eps, hipStream_t stream, int pow2 = 0, int ln_k = 0);   // ln_k: LayerNorm over the first ln_k columns (0: all K)
 // block-exponent rows (gemm.h): the standalone quantiser (the tower's first block; later blocks are quantised by the GEMM that
 // produces them), the per-row constants of the folded LayerNorm, the column sums of dequantised fp8 weight rows
 hipError_t ce_quant_block_fp8(const void* in, size_t ld_in, void* out8, size_t ld_out, void* exps, size_t ld_exp, float* stats,

@@ -41,7 +41,9 @@ template <> __device__ __forceinline__ void load8<float>(const float* p, float (
 // in flight to approach the HBM rate), rows strided over the grid.
 template <typename TIN, bool LN, int CH, int NR>
 __global__ __launch_bounds__(256) void quant_rows_kernel(const TIN* __restrict__ in, size_t ld_in, uint8_t* __restrict__ out,
-                                                         size_t ld_out, float* __restrict__ scale, int n_rows, int K, float eps, int pow2) {
+                                                         size_t ld_out, float* __restrict__ scale, int n_rows, int K, float eps, int pow2,
+                                                         int ln_k) {
+  // ln_k <= K (LN only): the columns the LayerNorm is over; the rest are a padded tower's zeros and stay zeros
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), n_waves = gridDim.x * 4;
   for (int row0 = wave * NR; row0 < n_rows; row0 += n_waves * NR) {
@@ -70,15 +72,15 @@ __global__ __launch_bounds__(256) void quant_rows_kernel(const TIN* __restrict__
         for (int ci = 0; ci < CH; ++ci)
 #pragma unroll
           for (int j = 0; j < 8; ++j) s += v[r][ci][j];
-        const float mean = wave_sum(s) / (float)K;
+        const float mean = wave_sum(s) / (float)ln_k;
         float ss = 0.f;
 #pragma unroll
         for (int ci = 0; ci < CH; ++ci)
-          if (ci * 512 + lane * 8 < K) {
+          if (ci * 512 + lane * 8 < ln_k) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { v[r][ci][j] -= mean; ss += v[r][ci][j] * v[r][ci][j]; }
           }
-        const float rstd = rsqrtf(wave_sum(ss) / (float)K + eps);
+        const float rstd = rsqrtf(wave_sum(ss) / (float)ln_k + eps);
 #pragma unroll
         for (int ci = 0; ci < CH; ++ci)
 #pragma unroll
@@ -396,9 +398,11 @@ hipError_t ce_colsum_fp8(const void* W8, const float* scale, int N, int K, float
 
 // in: bf16 (in_f32 == 0) or fp32 rows of K elements (K % 8 == 0, K <= 8192); ln != 0 normalises each row first.
 hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out8, size_t ld_out, float* scale, int n_rows,
-                             int K, int ln, float eps, hipStream_t stream, int pow2) {
+                             int K, int ln, float eps, hipStream_t stream, int pow2, int ln_k) {
   if (n_rows < 1 || K < 8 || K % 8 != 0 || K > QMAXC * 512 || ld_in < (size_t)K || ld_out < (size_t)K) return hipErrorInvalidValue;
-  if (!pow2 && !in_f32 && ln && K % 128 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in | (uintptr_t)out8) % 16 == 0) {
+  if (ln_k <= 0) ln_k = K;
+  if (ln_k > K || ln_k % 8 != 0) return hipErrorInvalidValue;
+  if (!pow2 && !in_f32 && ln && ln_k == K && K % 128 == 0 && ld_in % 8 == 0 && ld_out % 8 == 0 && ((uintptr_t)in | (uintptr_t)out8) % 16 == 0) {
     // the tower's LayerNorm-quantise pass: 16 lanes per row (quant_ln16_kernel)
     const int waves = (n_rows + 3) / 4;
     dim3 grid((unsigned)std::min((waves + 3) / 4, 16384)), block(256);
@@ -416,7 +420,7 @@ hipError_t ce_quant_rows_fp8(const void* in, int in_f32, size_t ld_in, void* out
     const int waves = (n_rows + (NR) - 1) / (NR);                                           \
     dim3 grid((unsigned)std::min((waves + 3) / 4, 8192)), block(256);                       \
     hipLaunchKernelGGL((quant_rows_kernel<T, LNV, CH, NR>), grid, block, 0, stream, (const T*)in, ld_in, (uint8_t*)out8, ld_out, scale, \
-                       n_rows, K, eps, pow2);                                                     \
+                       n_rows, K, eps, pow2, ln_k);                                               \
   } while (0)
 #define QDISPATCH(T, LNV)                                                                   \
   do {                                                                                      \

@@ -72,7 +72,7 @@ ARCHS: Dict[str, ViTConfig] = {
     "ViT-H-14": ViTConfig(224, 14, 1280, 32, 16, 5120, 1024),
     "ViT-L-16": ViTConfig(224, 16, 1024, 24, 16, 4096, 768),
     "ViT-H-16": ViTConfig(224, 16, 1280, 32, 16, 5120, 1024),
-    # towers whose shapes the kernels are not built for run zero-padded (capi.hip, clipenc_create: exact arithmetic, bf16 only):
+    # towers whose shapes the kernels are not built for run zero-padded (capi.hip, clipenc_create: exact arithmetic):
     # ViT-g-14's 16 heads of 88 run as heads of 96 (width 1408 -> 1536); ViT-B-16-plus-240's 14 heads of 64 as 16 (896 -> 1024)
     "ViT-g-14": ViTConfig(224, 14, 1408, 40, 16, 6144, 1024),
     "ViT-B-16-plus-240": ViTConfig(240, 16, 896, 12, 14, 3584, 640),
@@ -84,6 +84,7 @@ ARCHS: Dict[str, ViTConfig] = {
     "ViT-H-mid-test": ViTConfig(98, 14, 1280, 3, 16, 5120, 64),   # ... 50 tokens: two key tiles, a partial one
     "ViT-g-tiny-test": ViTConfig(28, 14, 704, 2, 8, 1024, 32),    # 8 heads of 88 -> heads of 96 (width 768 on the device), 5 tokens
     "ViT-g-mid-test": ViTConfig(98, 14, 704, 3, 8, 1024, 64),     # ... 50 tokens
+    "ViT-g-wide-test": ViTConfig(98, 14, 1232, 2, 14, 1024, 64),  # 14 heads of 88 -> 16 of 96: 1536 columns on the device (six statistics parts)
     "ViT-pad-test": ViTConfig(98, 14, 288, 3, 6, 640, 32),        # every kind of padding: heads of 48 -> 64, 6 heads -> 8, mlp 640 -> 768
 }
 

@@ -81,6 +81,18 @@ def test_vit_oracle_at_full_size_matches_the_transformers_vectors(golden_dir):
     ch = golden_cfg(gh)
     assert (ch.width, ch.layers, ch.heads, ch.mlp_dim, ch.embed_dim, ch.act) == (1280, 32, 16, 5120, 1024, vit_config.ACT_GELU_ERF)
     assert np.abs(gh["emb"] - gh["emb_transformers"]).max() < 1e-5 and float(gh["oracle_vs_transformers_max_abs"]) < 1e-5
+    # ViT-g-14 (`make_golden.py vit_g`: 1408 wide = 16 heads of 88, 40 blocks; runs zero-padded on the device, tests/test_gpu_padded_towers.py)
+    gg = np.load(os.path.join(golden_dir, "encoder_ViT-g-14-erf.npz"))
+    cg = golden_cfg(gg)
+    assert (cg.width, cg.layers, cg.heads, cg.mlp_dim, cg.embed_dim, cg.act) == (1408, 40, 16, 6144, 1024, vit_config.ACT_GELU_ERF)
+    assert np.abs(gg["emb"] - gg["emb_transformers"]).max() < 1e-5 and float(gg["oracle_vs_transformers_max_abs"]) < 1e-5
+    # ... and the small tower with every kind of padding, this one THROUGH the oracle here
+    gp = np.load(os.path.join(golden_dir, "encoder_ViT-pad-test.npz"))
+    cp = golden_cfg(gp)
+    assert cp.width // cp.heads == 48 and cp.width % 256 and cp.mlp_dim % 256
+    sdp = vit_config.seeded_state_dict(cp, int(gp["weight_seed"]))
+    embp = vit_oracle.encode_image(sdp, cp, synthetic_crops(int(gp["n_crops"]), cp.image_size, int(gp["input_seed"])))
+    assert np.abs(embp.numpy() - gp["emb_transformers"]).max() < 1e-5
 
 
 def test_dedup_oracle_matches_reference_golden(golden_dir):
