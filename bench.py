@@ -779,7 +779,7 @@ def main():
                     help="BASELINE.json configs[3]: run a whole N-image job (sharded over the ranks, crops generated on the device "
                          "per batch, one gather at the end) instead of the resident-batch step loop; use with --dtype fp8")
     ap.add_argument("--job-seed", type=int, default=20240, help="base seed of the job's per-rank counter-based generators")
-    ap.add_argument("--model", default=MODEL, choices=["ViT-L-14", "ViT-L-14-336", "ViT-H-14", "ViT-g-14"],
+    ap.add_argument("--model", default=MODEL, choices=["ViT-L-14", "ViT-L-14-336", "ViT-H-14", "ViT-g-14", "ViT-bigG-14"],
                     help="the tower of the timed step: ViT-L-14 = the headline (BASELINE.json metric); ViT-L-14-336 = the reference's default "
                          "model as the PRIMARY workload (tools/profile_round.sh takes its rocprofv3 passes this way; secondary block skipped)")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",
@@ -816,7 +816,7 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     # (ViT-H-14 and ViT-g-14 exist with laion tags only: erf-GELU; ViT-g-14 runs zero-padded, 1408 -> 1536 columns: its flops are the tower's own)
-    cfg = vit_config.config_for(args.model + "/laion2b_s32b_b79k") if args.model in ("ViT-H-14", "ViT-g-14") else vit_config.ARCHS[args.model]
+    cfg = vit_config.config_for(args.model + "/laion2b_s32b_b79k") if args.model in ("ViT-H-14", "ViT-g-14", "ViT-bigG-14") else vit_config.ARCHS[args.model]
     headline = args.model == MODEL
     REG_SIZES[0] = CROPS_PER_IMAGE * cfg.embed_dim            # the regressor's input is the tower's four embeddings (3 072 for ViT-L, 4 096 for ViT-H)
     sd = vit_config.seeded_state_dict(cfg, 0)               # random-init weights of the named architecture

@@ -198,14 +198,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const bf16_t* __restrict__
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz256(int row, int chunk) { return row * 256 + ((chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))) << 4); }
 
-#ifndef HD_WAVES
-#define HD_WAVES 8                 // two waves per SIMD (the kernel needs ~230 registers)
-#endif
-template <int NKT, int HD>
-__global__ __launch_bounds__(HD_WAVES * 64, HD_WAVES / 4) void attn_hd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+// Heads of 97 .. 128 columns (ViT-bigG-14's 104, run as 112): a fourth output tile.  Eight waves of 256 registers spill there (~20 registers at nine key
+// tiles) and are still 20 % faster than four waves of 512 that do not (2 048 crops x 257 tokens x 16 heads of 112: 3.12 against 3.90 ms, same bits).
+template <int NKT, int HD, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void attn_hd_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                          int n_tok, int width, int heads, float scale_log2e,
                                                          const float* __restrict__ out_inv, int q_blocks) {
-  static_assert(HD % 16 == 0 && HD > 64 && HD <= 96, "five or six k steps, three output tiles");
+  static_assert(HD % 16 == 0 && HD > 64 && HD <= 128, "five to eight k steps, three or four output tiles");
+  constexpr int NDT = (HD + 31) / 32, NCHUNK = NDT * 4;         // output tiles of 32 columns; 16-B chunks per LDS row that are read
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ROWS = NKT * 32, KS = HD / 16, CH = HD / 8;     // k steps; 16-B chunks per row
   char* Ks = smem;
@@ -216,8 +216,8 @@ __global__ __launch_bounds__(HD_WAVES * 64, HD_WAVES / 4) void attn_hd_kernel(co
   const size_t ld = (size_t)3 * width;
   const bf16_t* base = qkv + (size_t)crop * n_tok * ld + head * HD;
 
-  for (int idx = tid; idx < ROWS * 12; idx += HD_WAVES * 64) {             // chunks 0 .. CH-1: data; CH .. 11: the zero columns the third d tile reads
-    const int row = idx / 12, c = idx - row * 12;
+  for (int idx = tid; idx < ROWS * NCHUNK; idx += WAVES * 64) {            // chunks 0 .. CH-1: data; CH .. NCHUNK-1: the zero columns the last d tile reads
+    const int row = idx / NCHUNK, c = idx - row * NCHUNK;
     uint4 kv = {0, 0, 0, 0}, vv = {0, 0, 0, 0};
     if (row < n_tok && c < CH) {
       const bf16_t* g = base + (size_t)row * ld + c * 8;
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(HD_WAVES * 64, HD_WAVES / 4) void attn_hd_kernel(co
 
   const int r = lane & 31, h = lane >> 5;
   const int n_qb = min((n_tok + 31) >> 5, q_blocks);
-  for (int qb = wave; qb < n_qb; qb += HD_WAVES) {
+  for (int qb = wave; qb < n_qb; qb += WAVES) {
     const int q = qb * 32 + r;
     const bf16_t* qrow = base + (size_t)min(q, n_tok - 1) * ld;
     bf16x8_t qf[KS];
@@ -262,9 +262,13 @@ __global__ __launch_bounds__(HD_WAVES * 64, HD_WAVES / 4) void attn_hd_kernel(co
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float moff = mx * scale_log2e;
-    f32x16_t o[3], lacc;
+    f32x16_t o[NDT], lacc;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { o[0][e] = 0.f; o[1][e] = 0.f; o[2][e] = 0.f; lacc[e] = 0.f; }
+    for (int e = 0; e < 16; ++e) {
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) o[dt][e] = 0.f;
+      lacc[e] = 0.f;
+    }
     const u32x4_t ones_w = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_w);
 #pragma unroll
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(HD_WAVES * 64, HD_WAVES / 4) void attn_hd_kernel(co
           lacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, pf, lacc, 0, 0, 0);
           const int key0 = kt * 32 + s2 * 16 + 4 * h;
 #pragma unroll
-          for (int dt = 0; dt < 3; ++dt) {
+          for (int dt = 0; dt < NDT; ++dt) {
             const int i = lane & 15, qq = i >> 2, pp = i & 3, g1 = (lane >> 4) & 1;
             const int chunk = dt * 4 + g1 * 2 + (pp >> 1);        // 16-B chunk of d = 32 dt + 16 g1 + 4 pp .. + 3
             const int ra = key0 + qq, rb = key0 + 8 + qq;
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(HD_WAVES * 64, HD_WAVES / 4) void attn_hd_kernel(co
     if (q < n_tok && out_inv) {
       uint8_t* orow = (uint8_t*)out + ((size_t)crop * n_tok + q) * width + head * HD;
 #pragma unroll
-      for (int dt = 0; dt < 3; ++dt)
+      for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int col = dt * 32 + g4 * 8 + h * 4;
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(HD_WAVES * 64, HD_WAVES / 4) void attn_hd_kernel(co
     } else if (q < n_tok) {
       bf16_t* orow = out + ((size_t)crop * n_tok + q) * width + head * HD;
 #pragma unroll
-      for (int dt = 0; dt < 3; ++dt)
+      for (int dt = 0; dt < NDT; ++dt)
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           const int col = dt * 32 + g4 * 8 + h * 4;
@@ -323,14 +327,18 @@ __global__ __launch_bounds__(HD_WAVES * 64, HD_WAVES / 4) void attn_hd_kernel(co
   }
 }
 
+#ifndef HD_WAVES_WIDE
+#define HD_WAVES_WIDE 8            // heads of 97 .. 128 columns (4: one wave per SIMD, no spills, slower)
+#endif
 template <int NKT, int HD>
 hipError_t launch_attn_hd(const bf16_t* qkv, bf16_t* out, int n_crops, int n_tok, int width, int heads,
                           const float* out_inv, int q_blocks, hipStream_t stream) {
+  constexpr int WAVES = HD <= 96 ? 8 : HD_WAVES_WIDE;           // two waves per SIMD (the kernel needs ~230 registers at three output tiles)
   const int lds = NKT * 32 * 256 * 2;
   static DeviceKernelSetup setup;
-  if (hipError_t e = setup.ensure((const void*)attn_hd_kernel<NKT, HD>, lds, nullptr); e != hipSuccess) return e;
+  if (hipError_t e = setup.ensure((const void*)attn_hd_kernel<NKT, HD, WAVES>, lds, nullptr); e != hipSuccess) return e;
   const float scale_log2e = 1.44269504088896340736f / sqrtf((float)HD);
-  hipLaunchKernelGGL((attn_hd_kernel<NKT, HD>), dim3(n_crops * heads), dim3(HD_WAVES * 64), lds, stream, qkv, out, n_tok, width, heads, scale_log2e, out_inv,
+  hipLaunchKernelGGL((attn_hd_kernel<NKT, HD, WAVES>), dim3(n_crops * heads), dim3(WAVES * 64), lds, stream, qkv, out, n_tok, width, heads, scale_log2e, out_inv,
                      q_blocks);
   return hipGetLastError();
 }
@@ -1504,6 +1512,8 @@ hipError_t ce_attention(const void* qkv, void* out, int n_crops, int n_tok, int 
   }
   if (width == heads * 80) { ATTN_HD_CASES(80) }                  // ViT-H-14: its own kernel family, up to 288 tokens
   if (width == heads * 96) { ATTN_HD_CASES(96) }                  // ViT-g-14's 88-wide heads, zero-padded by clipenc_create
+  if (width == heads * 112) { ATTN_HD_CASES(112) }                // ViT-bigG-14's 104-wide heads
+  if (width == heads * 128) { ATTN_HD_CASES(128) }
 #undef ATTN_HD_CASES
   if (width != heads * 64) return hipErrorInvalidValue;
 #ifdef CLIPENC_DIAG                         // developer A/B: 0 = one workgroup per (crop, head) for every shape; CLIPENC_ATTN_TAIL=0: the odd query as a block

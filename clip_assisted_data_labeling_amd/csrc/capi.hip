@@ -640,7 +640,7 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
   if (u.width <= 0 || u.width % 8 != 0) return fail("width %d must be a positive multiple of 8", u.width);
   if (u.mlp_dim <= 0) return fail("mlp_dim %d must be positive", u.mlp_dim);
   if (u.heads < 1 || u.width % u.heads != 0) return fail("width %d is not a multiple of heads %d", u.width, u.heads);
-  // Shapes the kernels are built for: heads of 64, 80 or 96 columns, width = heads x that, width and mlp_dim multiples of 256.  Any other
+  // Shapes the kernels are built for: heads of 64, 80, 96, 112 or 128 columns, width = heads x that, width and mlp_dim multiples of 256.  Any other
   // tower is run as the next such shape with ZERO weights in the added places -- exact arithmetic, not an approximation:
   //   * a head of hd_r < hd columns gets hd - hd_r zero rows in W_q, W_k, W_v (and zero bias): the scores and the output do not see them;
   //     the attention kernels scale by hd^-1/2, so the q rows (weights and bias) carry (hd / hd_r)^1/2;
@@ -649,15 +649,15 @@ int clipenc_create(const clipenc_config* cfg, const clipenc_weights* w, int devi
   //     the LayerNorms divide by the TRUE width (ln_width) and their gamma / beta are zero there;
   //   * zero FC1 rows / FC2 columns up to a multiple of 256 (both activations map 0 to 0).
   const int hd_r = u.width / u.heads;
-  const int hd = hd_r <= 64 ? 64 : (hd_r <= 80 ? 80 : 96);
-  if (hd_r > 96) return fail("head dim %d > 96 not built (width %d, heads %d)", hd_r, u.width, u.heads);
+  const int hd = hd_r <= 64 ? 64 : (hd_r <= 80 ? 80 : (hd_r + 15) / 16 * 16);
+  if (hd_r > 128) return fail("head dim %d > 128 not built (width %d, heads %d)", hd_r, u.width, u.heads);
   int heads_d = u.heads;
   while ((heads_d * hd) % 256 != 0) ++heads_d;
   clipenc_config g = u;
   g.heads = heads_d; g.width = heads_d * hd; g.mlp_dim = (int)align_up((size_t)u.mlp_dim, 256);
   const bool padded = g.width != u.width || g.heads != u.heads || g.mlp_dim != u.mlp_dim;
   if (g.patch <= 0 || g.image_size % g.patch != 0) return fail("image_size %d not divisible by patch %d", g.image_size, g.patch);
-  if (g.embed_dim <= 0 || g.embed_dim > 1024) return fail("embed_dim %d out of range (1..1024)", g.embed_dim);
+  if (g.embed_dim <= 0 || g.embed_dim > 1280) return fail("embed_dim %d out of range (1..1280)", g.embed_dim);
   if (g.width > 2048) return fail("width %d%s > 2048 not built (LayerNorm / head kernels)", g.width, padded ? " (after padding)" : "");
   if (g.layers < 1) return fail("layers %d < 1", g.layers);
   if (g.act != CLIPENC_ACT_QUICK_GELU && g.act != CLIPENC_ACT_GELU_ERF) return fail("unknown activation %d", g.act);
@@ -1015,7 +1015,7 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
     }
     if (kind == PK_ATTENTION) {                      // the instantiation ce_attention picks for this token count
       const int nkt = (e->tokens + 31) / 32;
-      if (e->cfg.heads * 64 != e->cfg.width) { static thread_local char hb[32]; snprintf(hb, sizeof hb, "attn_hd_kernel<%d, %d>", nkt, e->cfg.width / e->cfg.heads); *name = hb; }
+      if (e->cfg.heads * 64 != e->cfg.width) { static thread_local char hb[32]; const int hdv = e->cfg.width / e->cfg.heads; snprintf(hb, sizeof hb, "attn_hd_kernel<%d, %d, 8>", nkt, hdv); *name = hb; }
       else if (nkt > 19) *name = "attn_long_kernel<12>";
       else if (nkt > 9) *name = "attn_long_stream_kernel<11>";     // (launches of fewer than 64 tasks take attn_long_kernel<12>)
       else if (nkt == 9) *name = (e->tokens & 31) == 1 ? "attn_stream_kernel<9, 7, true>" : "attn_stream_kernel<9, 7, false>";

@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void head_kernel(const bf16_t* __restrict__ x,
   float sq[HEAD_CROPS];
 #pragma unroll
   for (int r = 0; r < HEAD_CROPS; ++r) sq[r] = 0.f;
-  constexpr int MAX_E_PER_THREAD = 4;              // embed <= 1024
+  constexpr int MAX_E_PER_THREAD = 5;              // embed <= 1280
   float acc[MAX_E_PER_THREAD][HEAD_CROPS];
 #pragma unroll
   for (int i = 0; i < MAX_E_PER_THREAD; ++i)
@@ -373,7 +373,7 @@ hipError_t ce_embed_ln_pre(const void* patch_emb, const float* cls, const float*
 
 hipError_t ce_head(const void* x, const float* gamma, const float* beta, const float* proj, float* emb, int n_crops,
                    int n_tok, int width, int ln_width, int embed, float eps, int normalize, hipStream_t stream) {
-  if (embed > 1024 || width > 2048 || width % 4 != 0 || ln_width < 1 || ln_width > width) return hipErrorInvalidValue;
+  if (embed > 1280 || width > 2048 || width % 4 != 0 || ln_width < 1 || ln_width > width) return hipErrorInvalidValue;
   const size_t lds = (size_t)HEAD_CROPS * width * 4 + HEAD_CROPS * 4 * 4;
   hipLaunchKernelGGL(head_kernel, dim3((n_crops + HEAD_CROPS - 1) / HEAD_CROPS), dim3(256), lds, stream,
                      (const bf16_t*)x, gamma, beta, proj, emb, n_crops, n_tok, width, ln_width, embed, eps, normalize);

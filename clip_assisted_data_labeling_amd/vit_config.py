@@ -76,6 +76,7 @@ ARCHS: Dict[str, ViTConfig] = {
     # ViT-g-14's 16 heads of 88 run as heads of 96 (width 1408 -> 1536); ViT-B-16-plus-240's 14 heads of 64 as 16 (896 -> 1024)
     "ViT-g-14": ViTConfig(224, 14, 1408, 40, 16, 6144, 1024),
     "ViT-B-16-plus-240": ViTConfig(240, 16, 896, 12, 14, 3584, 640),
+    "ViT-bigG-14": ViTConfig(224, 14, 1664, 48, 16, 8192, 1280),  # 16 heads of 104 run as heads of 112: 1792 columns on the device
     # small shapes used by the parity tests (not open_clip names)
     "ViT-tiny-test": ViTConfig(28, 14, 256, 2, 4, 512, 32),
     "ViT-small-test": ViTConfig(98, 14, 256, 3, 4, 1024, 64),
@@ -85,6 +86,9 @@ ARCHS: Dict[str, ViTConfig] = {
     "ViT-g-tiny-test": ViTConfig(28, 14, 704, 2, 8, 1024, 32),    # 8 heads of 88 -> heads of 96 (width 768 on the device), 5 tokens
     "ViT-g-mid-test": ViTConfig(98, 14, 704, 3, 8, 1024, 64),     # ... 50 tokens
     "ViT-g-wide-test": ViTConfig(98, 14, 1232, 2, 14, 1024, 64),  # 14 heads of 88 -> 16 of 96: 1536 columns on the device (six statistics parts)
+    "ViT-bigG-tiny-test": ViTConfig(28, 14, 1664, 2, 16, 2048, 1280),   # heads of 104 -> 112 (1792 columns), the 1280-wide embedding, 5 tokens
+    "ViT-bigG-mid-test": ViTConfig(98, 14, 1664, 2, 16, 2048, 96),     # ... 50 tokens
+    "ViT-hd120-test": ViTConfig(98, 14, 240, 2, 2, 512, 32),            # two heads of 120 -> 128 (256 columns)
     "ViT-pad-test": ViTConfig(98, 14, 288, 3, 6, 640, 32),        # every kind of padding: heads of 48 -> 64, 6 heads -> 8, mlp 640 -> 768
 }
 

@@ -60,9 +60,9 @@ int clipenc_device_count(int* count);
 
 /* Replaces the model construction of CLIP_Encoder.__init__
  * (/root/reference/utils/embedder.py:66-74: open_clip.create_model_and_transforms + .to(device).eval()).
- * Shapes: width % heads == 0 with heads of at most 96 columns, at most 640 tokens (288 when the heads are not 64 wide),
- * embed_dim <= 1024.  The kernels are built for heads of 64 / 80 / 96 columns and widths / MLP widths that are multiples of
- * 256; any other tower (ViT-g-14: 16 heads of 88) is run as the next such shape with zero weights in the added places and
+ * Shapes: width % heads == 0 with heads of at most 128 columns, at most 640 tokens (288 when the heads are not 64 wide),
+ * embed_dim <= 1280.  The kernels are built for heads of 64 / 80 / 96 / 112 / 128 columns and widths / MLP widths that are
+ * multiples of 256; any other tower (ViT-g-14: 16 heads of 88; ViT-bigG-14: 16 heads of 104) is run as the next such shape with zero weights in the added places and
  * LayerNorms over its true width -- the same arithmetic; at most 2048 columns after padding.  Weights are always handed over
  * and token rows (clipenc_forward_tokens) returned at the tower's OWN widths. */
 int clipenc_create(const clipenc_config* cfg, const clipenc_weights* weights, int device, clipenc_t* out);

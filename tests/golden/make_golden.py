@@ -342,6 +342,9 @@ if __name__ == "__main__":
         make_encoder("ViT-g-14", 2, seed=17, in_seed=18, pretrained="laion2b_s34b_b88k")
         make_encoder("ViT-pad-test", 5, seed=19, in_seed=20)
         sys.exit(0)
+    if sys.argv[1:] == ["vit_bigg"]:     # round 6: ViT-bigG-14 at full size (1664 wide = 16 heads of 104, 48 blocks, 1.8 G parameters; ~5 min of CPU, 25 GB)
+        make_encoder("ViT-bigG-14", 2, seed=21, in_seed=22, pretrained="laion2b_s39b_b160k")
+        sys.exit(0)
     if sys.argv[1:] == ["full"]:         # round 5: the full-size towers (needs transformers, not the reference; ~1 min of CPU, 5 GB)
         make_encoder("ViT-L-14", 4, seed=11, in_seed=12)
         make_encoder("ViT-L-14-336", 2, seed=13, in_seed=14)

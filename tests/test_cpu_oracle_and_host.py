@@ -86,6 +86,10 @@ def test_vit_oracle_at_full_size_matches_the_transformers_vectors(golden_dir):
     cg = golden_cfg(gg)
     assert (cg.width, cg.layers, cg.heads, cg.mlp_dim, cg.embed_dim, cg.act) == (1408, 40, 16, 6144, 1024, vit_config.ACT_GELU_ERF)
     assert np.abs(gg["emb"] - gg["emb_transformers"]).max() < 1e-5 and float(gg["oracle_vs_transformers_max_abs"]) < 1e-5
+    gb = np.load(os.path.join(golden_dir, "encoder_ViT-bigG-14-erf.npz"))       # `make_golden.py vit_bigg`: 16 heads of 104, a 1280-wide embedding
+    cb = golden_cfg(gb)
+    assert (cb.width, cb.layers, cb.heads, cb.mlp_dim, cb.embed_dim) == (1664, 48, 16, 8192, 1280) and gb["emb_transformers"].shape == (2, 1280)
+    assert np.abs(gb["emb"] - gb["emb_transformers"]).max() < 1e-5 and float(gb["oracle_vs_transformers_max_abs"]) < 1e-5
     # ... and the small tower with every kind of padding, this one THROUGH the oracle here
     gp = np.load(os.path.join(golden_dir, "encoder_ViT-pad-test.npz"))
     cp = golden_cfg(gp)

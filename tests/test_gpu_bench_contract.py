@@ -79,8 +79,8 @@ def test_single_gpu_line_secondary_head_and_problem_key(gpu):
     assert d["roofline"]["traffic"] is None and all(r["traffic_ratio"] is None for r in d["roofline"]["per_kernel"].values())
 
 
-@pytest.mark.parametrize("model,tokens,attn", [("ViT-L-14-336", 577, "attn_long"), ("ViT-H-14", 257, "attn_hd_kernel<9, 80>"),
-                                               ("ViT-g-14", 257, "attn_hd_kernel<9, 96>")])
+@pytest.mark.parametrize("model,tokens,attn", [("ViT-L-14-336", 577, "attn_long"), ("ViT-H-14", 257, "attn_hd_kernel<9, 80,"),
+                                               ("ViT-g-14", 257, "attn_hd_kernel<9, 96,")])
 def test_other_towers_as_the_primary_workload(gpu, model, tokens, attn):
     """`bench.py --model M`: another tower as the timed step (what `tools/profile_round.sh <tag> bf16 M` profiles): its own metric label, no
     headline-only blocks, the attention row from the kernel that tower launches."""

@@ -18,10 +18,11 @@ pytestmark = pytest.mark.gpu
 COS_TOL = 1e-3
 
 
+@pytest.mark.parametrize("hd", [96, 112, 128])
 @pytest.mark.parametrize("n_crops,n_tok,heads", [(2, 5, 8), (3, 50, 8), (2, 257, 16), (1, 288, 16), (5, 33, 8), (3, 1, 8), (1, 273, 8)])
-def test_attention_head_dim_96_matches_fp32_reference(gpu, n_crops, n_tok, heads):
+def test_attention_wide_heads_match_fp32_reference(gpu, n_crops, n_tok, heads, hd):
     lib = _lib.load()
-    width = heads * 96
+    width = heads * hd
     g = torch.Generator().manual_seed(n_tok + heads)
     qkv = (torch.randn(n_crops * n_tok, 3 * width, generator=g) * 1.5).to(torch.bfloat16)
     out = torch.full((n_crops * n_tok, width), float("nan"), dtype=torch.bfloat16, device=gpu)
@@ -29,8 +30,8 @@ def test_attention_head_dim_96_matches_fp32_reference(gpu, n_crops, n_tok, heads
     st = _lib.current_stream_ptr(gpu)
     _lib.check(lib.clipenc_op_attention(qkv_dev.data_ptr(), out.data_ptr(), n_crops, n_tok, width, heads, st), "attention")
     torch.cuda.synchronize()
-    q, k, v = qkv.float().view(n_crops, n_tok, 3, heads, 96).permute(2, 0, 3, 1, 4)
-    ref = (torch.softmax(q @ k.transpose(-1, -2) * 96.0 ** -0.5, -1) @ v).permute(0, 2, 1, 3).reshape(n_crops * n_tok, width)
+    q, k, v = qkv.float().view(n_crops, n_tok, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * float(hd) ** -0.5, -1) @ v).permute(0, 2, 1, 3).reshape(n_crops * n_tok, width)
     got = out.float().cpu()
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max().item() < 0.03
@@ -42,7 +43,8 @@ def test_attention_head_dim_96_matches_fp32_reference(gpu, n_crops, n_tok, heads
 
 @pytest.mark.parametrize("arch,tag,n_crops", [("ViT-g-tiny-test", "seed0", 7), ("ViT-g-tiny-test", "laion2b", 300), ("ViT-g-mid-test", "laion2b", 70),
                                              ("ViT-g-wide-test", "laion2b", 40),
-                                             ("ViT-pad-test", "openai", 5), ("ViT-pad-test", "laion2b", 130)])
+                                             ("ViT-pad-test", "openai", 5), ("ViT-pad-test", "laion2b", 130),
+                                             ("ViT-bigG-tiny-test", "laion2b", 9), ("ViT-bigG-mid-test", "laion2b", 40), ("ViT-hd120-test", "openai", 33)])
 def test_padded_towers_match_fp32_oracle(gpu, arch, tag, n_crops):
     cfg = vit_config.config_for(f"{arch}/{tag}")
     assert cfg.width % 256 != 0 and cfg.width // cfg.heads not in (64, 80)
@@ -141,10 +143,39 @@ def test_vit_g_14_full_size_matches_the_independent_implementation(gpu, golden_d
         vit.close()
 
 
+def test_vit_bigg_14_full_size_matches_the_independent_implementation(gpu, golden_dir):
+    """tests/golden/encoder_ViT-bigG-14-erf.npz (`make_golden.py vit_bigg`): transformers on the seeded FULL-SIZE tower (1664 wide = 16 heads of
+    104, 48 blocks, an 8 192-wide MLP, a 1280-wide embedding, 1.8 G parameters).  On the device: 1792 columns, heads of 112."""
+    g = np.load(os.path.join(golden_dir, "encoder_ViT-bigG-14-erf.npz"))
+    cfg = vit_config.config_for(f"{str(g['arch'])}/{str(g['pretrained'])}")
+    assert (cfg.width, cfg.heads, cfg.layers, cfg.mlp_dim, cfg.embed_dim) == (1664, 16, 48, 8192, 1280)
+    sd = vit_config.seeded_state_dict(cfg, int(g["weight_seed"]))
+    wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(wsum - float(g["weight_abs_sum"])) <= 1e-9 * wsum, "the seeded weights are not the ones the fixture was made with"
+    crops = synthetic_crops(int(g["n_crops"]), cfg.image_size, int(g["input_seed"]))
+    hf = torch.from_numpy(g["emb_transformers"])
+    vit = HipViT(cfg, sd, gpu, chunk_crops=256)
+    del sd
+    try:
+        got = vit.encode(crops.to(gpu)).cpu()
+        omc = one_minus_cos(got, hf)
+        print("ViT-bigG-14 bf16 1-cos vs transformers:", omc.max().item())
+        assert omc.max().item() < COS_TOL, omc
+        x1 = vit.forward_tokens(crops.to(gpu), 1).float().cpu()
+        assert x1.shape == (2, 257, 1664)
+        assert one_minus_cos(x1[:, 0], torch.from_numpy(g["block0_cls"])).max().item() < 1e-4
+        vit.set_precision("fp8")
+        omc8 = one_minus_cos(vit.encode(crops.to(gpu)).cpu(), hf)
+        print("ViT-bigG-14 fp8 1-cos vs transformers:", omc8.max().item())
+        assert omc8.max().item() < COS_TOL, omc8
+    finally:
+        vit.close()
+
+
 def test_shapes_no_padding_reaches_are_refused_by_name(gpu):
-    cfg = vit_config.ViTConfig(28, 14, 1664, 2, 16, 8192, 64)           # ViT-bigG-14's heads of 104
+    cfg = vit_config.ViTConfig(28, 14, 288, 2, 2, 512, 64)              # heads of 144
     sd = vit_config.seeded_state_dict(cfg, 0)
-    with pytest.raises(_lib.ClipencError, match="head dim 104"):
+    with pytest.raises(_lib.ClipencError, match="head dim 144"):
         HipViT(cfg, sd, gpu)
     cfg = vit_config.ViTConfig(28, 14, 2112, 2, 24, 1024, 64)           # 24 heads of 88 -> 2304 columns
     with pytest.raises(_lib.ClipencError, match="2048"):

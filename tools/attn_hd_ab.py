@@ -5,7 +5,7 @@ def load(sfx):
     f = lib.clipenc_op_attention
     f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]; f.restype = ctypes.c_int
     return f
-dev = torch.device("cuda", 0); crops, n_tok, heads, hd = 2048, 257, 16, 80
+dev = torch.device("cuda", 0); crops, n_tok, heads, hd = 2048, 257, 16, int(os.environ.get('ATTN_HD', '80'))
 T = crops * n_tok; width = heads * hd
 qkv = (torch.randn(T, 3 * width, device=dev) * 1.5).to(torch.bfloat16)
 st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
