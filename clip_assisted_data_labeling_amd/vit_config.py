@@ -248,7 +248,10 @@ def _read_checkpoint(path: str) -> Dict[str, torch.Tensor]:
 _TAG_ALIASES = {"openai": ("openai",), "laion2b_s32b_b82k": ("laion2b-s32b-b82k", "laion2b"),
                 "laion2b_s34b_b79k": ("laion2b-s34b-b79k", "laion2b"), "laion400m_e31": ("laion400m-e31", "laion400m"),
                 "laion400m_e32": ("laion400m-e32", "laion400m"), "datacomp_xl_s13b_b90k": ("datacomp-xl-s13b-b90k", "datacomp"),
-                "dfn2b": ("dfn2b",)}
+                "dfn2b": ("dfn2b",),
+                # ViT-H-14, ViT-g-14, ViT-bigG-14 (the bigG repository spells its tag without the 's': CLIP-ViT-bigG-14-laion2B-39B-b160k)
+                "laion2b_s32b_b79k": ("laion2b-s32b-b79k", "laion2b"), "laion2b_s12b_b42k": ("laion2b-s12b-b42k", "laion2b"),
+                "laion2b_s34b_b88k": ("laion2b-s34b-b88k", "laion2b"), "laion2b_s39b_b160k": ("laion2b-39b-b160k", "laion2b-s39b-b160k", "laion2b")}
 
 
 # what open_clip appends to an architecture name to make ANOTHER architecture: 'ViT-B-16-plus-240', 'ViT-B-32-quickgelu',

@@ -278,6 +278,10 @@ def test_load_weights_from_what_open_clip_leaves_in_cache_dir(tmp_path):
     assert not vit_config._has_component("models--timm--vit-b-16-siglip-webli", "vit-b-16")
     assert not vit_config._has_component("models--x--vit-l-14-clipa-datacomp1b", "vit-l-14")
     assert vit_config._has_component("models--laion--clip-vit-b-16-laion400m-e32", "vit-b-16")
+    assert vit_config._has_component("models--laion--clip-vit-g-14-laion2b-s34b-b88k", "vit-g-14")
+    assert vit_config._has_component("models--laion--clip-vit-bigg-14-laion2b-39b-b160k", "vit-bigg-14")
+    assert not vit_config._has_component("models--laion--clip-vit-bigg-14-laion2b-39b-b160k", "vit-g-14")
+    assert "laion2b-39b-b160k" in vit_config._TAG_ALIASES["laion2b_s39b_b160k"]      # the repository's own spelling of that tag
     assert vit_config._has_component("models--laion--clip-vit-b-32-datacomp-xl-s13b-b90k", "vit-b-32")    # '-xl' belongs to the TAG here
     # the exact hand-placed file wins over a hub snapshot of the same name pair
     exact = {k: v + 1.0 for k, v in sd.items()}
