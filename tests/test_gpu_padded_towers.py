@@ -85,6 +85,19 @@ def test_padded_towers_match_fp32_oracle(gpu, arch, tag, n_crops):
         vit.close()
 
 
+def test_reference_surface_takes_a_padded_tower(gpu):
+    """CLIP_Encoder("<arch>/<tag>") as /root/reference/_1_embed_with_CLIP.py:73 builds it, on a tower that runs padded: nothing at that level knows."""
+    from clip_assisted_data_labeling_amd.embedder import CLIP_Encoder
+    enc = CLIP_Encoder("ViT-g-mid-test/seed6", None, device="cuda")
+    cfg = vit_config.config_for("ViT-g-mid-test/seed6")
+    assert enc.img_resolution == cfg.image_size
+    crops = synthetic_crops(3 * 4, cfg.image_size, 31)
+    f = enc.encode_image(crops.to("cuda"))
+    assert f.shape == (12, cfg.embed_dim)
+    ref = vit_oracle.encode_image(vit_config.seeded_state_dict(cfg, 6), cfg, crops)
+    assert one_minus_cos(f.cpu().float(), ref).max().item() < COS_TOL
+
+
 def test_padded_tower_matches_its_golden_fixture(gpu, golden_dir):
     """tests/golden/encoder_ViT-pad-test.npz (`make_golden.py vit_g`): oracle embeddings asserted within 1e-5 of transformers'."""
     g = np.load(os.path.join(golden_dir, "encoder_ViT-pad-test.npz"))
