@@ -9,7 +9,7 @@ from clip_assisted_data_labeling_amd.embedder import HipViT
 dev = torch.device("cuda", 0)
 n_rep = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 ARCH = sys.argv[2] if len(sys.argv) > 2 else "ViT-L-14"        # ViT-L-14-336: the long streaming attention kernel; ViT-H-14: head dim 80
-cfg = vit_config.config_for(ARCH + "/laion2b") if ARCH == "ViT-H-14" else vit_config.ARCHS[ARCH]
+cfg = vit_config.config_for(ARCH + "/laion2b") if ARCH in ("ViT-H-14", "ViT-g-14", "ViT-bigG-14") else vit_config.ARCHS[ARCH]   # (g / bigG: the zero-padded towers)
 sd = vit_config.seeded_state_dict(cfg, 0)
 big = 2048 if cfg.tokens < 300 else 640
 for prec, crops_n in (("bf16", big), ("fp8", big), ("bf16", 333), ("fp8", 61)):     # full tiles and ragged last tiles
