@@ -76,6 +76,11 @@ ARCHS: Dict[str, ViTConfig] = {
     # ViT-g-14's 16 heads of 88 run as heads of 96 (width 1408 -> 1536); ViT-B-16-plus-240's 14 heads of 64 as 16 (896 -> 1024)
     "ViT-g-14": ViTConfig(224, 14, 1408, 40, 16, 6144, 1024),
     "ViT-B-16-plus-240": ViTConfig(240, 16, 896, 12, 14, 3584, 640),
+    # open_clip's smaller and odd-resolution towers (padding where needed: ViT-S's 6 heads run as 8; 280 / 320 px are the long attention kernel's)
+    "ViT-S-32": ViTConfig(224, 32, 384, 12, 6, 1536, 384), "ViT-S-16": ViTConfig(224, 16, 384, 12, 6, 1536, 384),
+    "ViT-M-32": ViTConfig(224, 32, 512, 12, 8, 2048, 512), "ViT-M-16": ViTConfig(224, 16, 512, 12, 8, 2048, 512),
+    "ViT-B-32-256": ViTConfig(256, 32, 768, 12, 12, 3072, 512), "ViT-B-16-plus": ViTConfig(224, 16, 896, 12, 14, 3584, 640),
+    "ViT-L-14-280": ViTConfig(280, 14, 1024, 24, 16, 4096, 768), "ViT-L-16-320": ViTConfig(320, 16, 1024, 24, 16, 4096, 768),
     "ViT-bigG-14": ViTConfig(224, 14, 1664, 48, 16, 8192, 1280),  # 16 heads of 104 run as heads of 112: 1792 columns on the device
     # small shapes used by the parity tests (not open_clip names)
     "ViT-tiny-test": ViTConfig(28, 14, 256, 2, 4, 512, 32),

@@ -85,6 +85,29 @@ def test_padded_towers_match_fp32_oracle(gpu, arch, tag, n_crops):
         vit.close()
 
 
+@pytest.mark.parametrize("arch", ["ViT-S-32", "ViT-S-16", "ViT-M-16", "ViT-B-32-256", "ViT-B-16-plus", "ViT-B-16-plus-240", "ViT-L-14-280", "ViT-L-16-320"])
+def test_named_open_clip_towers_match_fp32_oracle(gpu, arch):
+    """Every architecture name of vit_config.ARCHS builds and matches the oracle at its real shape, the tower cut to three blocks
+    (the depth adds nothing a two-/three-block tower does not show; the full depth is pinned for ViT-B-32 / L / H / g / bigG)."""
+    import dataclasses
+    cfg = dataclasses.replace(vit_config.config_for(arch + "/laion2b"), layers=3)
+    sd = vit_config.seeded_state_dict(cfg, 7)
+    crops = synthetic_crops(6, cfg.image_size, 44)
+    ref = vit_oracle.encode_image(sd, cfg, crops[:3])
+    vit = HipViT(cfg, sd, gpu)
+    try:
+        emb = vit.encode(crops.to(gpu))
+        omc = one_minus_cos(emb[:3].cpu(), ref)
+        assert omc.max().item() < COS_TOL, omc
+        assert torch.equal(emb, vit.encode(crops.to(gpu)))
+        vit.set_precision("fp8")
+        omc8 = one_minus_cos(vit.encode(crops.to(gpu))[:3].cpu(), ref)
+        print(f"{arch} 1-cos bf16 {omc.max().item():.2e} fp8 {omc8.max().item():.2e}")
+        assert omc8.max().item() < COS_TOL, omc8
+    finally:
+        vit.close()
+
+
 def test_reference_surface_takes_a_padded_tower(gpu):
     """CLIP_Encoder("<arch>/<tag>") as /root/reference/_1_embed_with_CLIP.py:73 builds it, on a tower that runs padded: nothing at that level knows."""
     from clip_assisted_data_labeling_amd.embedder import CLIP_Encoder
