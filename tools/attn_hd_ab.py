@@ -18,4 +18,5 @@ for n in sys.argv[1:]:
     s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True); s.record()
     for _ in range(10): f(qkv.data_ptr(), o.data_ptr(), crops, n_tok, width, heads, st)
     e.record(); torch.cuda.synchronize(); ms = s.elapsed_time(e) / 10
-    print(n, f"{ms:.3f} ms  {4.0 * crops * heads * n_tok * n_tok * hd / ms / 1e9:.0f} TFLOP/s", "equal to first:", bool(torch.equal(outs[n], outs[sys.argv[1]])))
+    print(n, f"{ms:.3f} ms  {4.0 * crops * heads * n_tok * n_tok * hd / ms / 1e9:.0f} TFLOP/s", "equal to first:", bool(torch.equal(outs[n], outs[sys.argv[1]])),
+          f"max |d| {(outs[n].float() - outs[sys.argv[1]].float()).abs().max().item():.3e}", "finite:", bool(torch.isfinite(outs[n].float()).all()))
