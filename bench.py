@@ -779,7 +779,7 @@ def main():
                     help="BASELINE.json configs[3]: run a whole N-image job (sharded over the ranks, crops generated on the device "
                          "per batch, one gather at the end) instead of the resident-batch step loop; use with --dtype fp8")
     ap.add_argument("--job-seed", type=int, default=20240, help="base seed of the job's per-rank counter-based generators")
-    ap.add_argument("--model", default=MODEL, choices=["ViT-L-14", "ViT-L-14-336", "ViT-H-14", "ViT-g-14", "ViT-bigG-14"],
+    ap.add_argument("--model", default=MODEL, choices=["ViT-L-14", "ViT-L-14-336", "ViT-H-14", "ViT-g-14", "ViT-bigG-14", "ViT-B-16", "ViT-B-32"],
                     help="the tower of the timed step: ViT-L-14 = the headline (BASELINE.json metric); ViT-L-14-336 = the reference's default "
                          "model as the PRIMARY workload (tools/profile_round.sh takes its rocprofv3 passes this way; secondary block skipped)")
     ap.add_argument("--dtype", choices=["bf16", "fp8"], default="bf16",

@@ -137,6 +137,31 @@ def test_attention_matches_fp32_reference(gpu, n_crops, n_tok, heads):
     assert one_minus_cos(got, ref).max().item() < 2e-4
 
 
+@pytest.mark.parametrize("n_tok", [65, 80, 81, 96, 97, 112, 113, 128, 129, 145, 160, 161, 176, 177, 192, 193, 197, 208, 209, 224, 225, 257])
+def test_attention_streaming_form_has_the_bits_of_the_one_workgroup_form(gpu, n_tok):
+    """From 64 (crop, head) tasks up, 65 .. 288 tokens go to the persistent streaming kernel (three to nine key tiles; round 6 added three to seven:
+    ViT-B-16 / L-16 at 224 px are 197 tokens), smaller launches to one workgroup per task: the same arithmetic, so a crop's rows do not depend on the
+    batch it came in -- bit for bit, at every count of real keys in the last 16-key step and of real queries in the last block; plus the fp32 reference."""
+    lib = _lib.load()
+    heads, width = 4, 256
+    g = torch.Generator().manual_seed(1000 + n_tok)
+    big = (torch.randn(40 * n_tok, 3 * width, generator=g) * 1.5).to(torch.bfloat16).to(gpu)        # 160 tasks: streaming
+    out_big = torch.full((40 * n_tok, width), float("nan"), dtype=torch.bfloat16, device=gpu)
+    _lib.check(lib.clipenc_op_attention(big.data_ptr(), out_big.data_ptr(), 40, n_tok, width, heads, _stream(gpu)), "attention")
+    small = big[17 * n_tok:20 * n_tok].contiguous()                                                    # crops 17 .. 19 alone: 12 tasks
+    out_small = torch.full((3 * n_tok, width), float("nan"), dtype=torch.bfloat16, device=gpu)
+    _lib.check(lib.clipenc_op_attention(small.data_ptr(), out_small.data_ptr(), 3, n_tok, width, heads, _stream(gpu)), "attention")
+    torch.cuda.synchronize()
+    assert torch.isfinite(out_big.float()).all()
+    assert torch.equal(out_big[17 * n_tok:20 * n_tok], out_small)
+    q, k, v = small.float().cpu().view(3, n_tok, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).permute(0, 2, 1, 3).reshape(3 * n_tok, width)
+    assert (out_small.float().cpu() - ref).abs().max().item() < 0.03
+    again = torch.empty_like(out_big)
+    _lib.check(lib.clipenc_op_attention(big.data_ptr(), again.data_ptr(), 40, n_tok, width, heads, _stream(gpu)), "attention")
+    assert torch.equal(again, out_big)
+
+
 @pytest.mark.parametrize("case", ["small", "large", "very_negative", "mixed", "one_dominant_key"])
 def test_attention_streaming_kernel_takes_the_maximum_only_where_it_must(gpu, case):
     """>= 64 (crop, head) tasks at 257 tokens: the streaming kernel's exact row maximum under small logits, large ones, all scores far
