@@ -102,7 +102,7 @@ static const char* const kProfileNames[PK_COUNT] = {
     "cls_attn_kernel"};
 // (template arguments: <EPI, ACT> and, fp8, <EPI, ACT, LNF>; FC1 is <2, 0> with QuickGELU and <2, 1> with erf-GELU; the fp8
 //  names above are the unfused tower's (widths over 1024), clipenc_profile_read substitutes the fused tower's; the attention
-//  name is the ViT-L/14 instantiation, other token counts use attn_kernel<NKT> / attn_long_kernel<12>; quant_ln16_kernel<width / 128>)
+//  name is the ViT-L/14 instantiation, other token counts use attn_stream_kernel<NKT, 7, false> / attn_kernel<NKT> / attn_long_stream_kernel<11>; quant_ln16_kernel<width / 128>)
 
 struct ProfRec { int kind, sub; hipEvent_t a, b; double flops; };
 
@@ -1019,8 +1019,8 @@ int clipenc_profile_read(clipenc_t e, int kind, const char** name, double* total
       else if (nkt > 19) *name = "attn_long_kernel<12>";
       else if (nkt > 9) *name = "attn_long_stream_kernel<11>";     // (launches of fewer than 64 tasks take attn_long_kernel<12>)
       else if (nkt == 9) *name = (e->tokens & 31) == 1 ? "attn_stream_kernel<9, 7, true>" : "attn_stream_kernel<9, 7, false>";
-      else if (nkt == 8) *name = "attn_stream_kernel<8, 7, false>";
-      else if (nkt < 8) { static thread_local char buf[32]; snprintf(buf, sizeof buf, "attn_kernel<%d>", nkt); *name = buf; }
+      else if (nkt >= 3) { static thread_local char sb[40]; snprintf(sb, sizeof sb, "attn_stream_kernel<%d, 7, false>", nkt); *name = sb; }   // (launches of fewer than 64 tasks: attn_kernel<NKT>)
+      else { static thread_local char buf[32]; snprintf(buf, sizeof buf, "attn_kernel<%d>", nkt); *name = buf; }
     }
   }
   if (total_ms) *total_ms = e->prof.ms[kind];
